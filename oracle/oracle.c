@@ -1,0 +1,587 @@
+/*
+ * oracle.c — CPU restatement of the ath92/splat-renderer tile-raster hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED (see oracle.h): the reference has
+ * no golden vectors for this path; this file follows the reference's shader/host text line by
+ * line and is cross-checked by oracle/np_oracle.py.
+ *
+ * Arithmetic policy: every float operation below is a single IEEE-754 binary32 operation in
+ * the order written (compile with -ffp-contract=off, no -ffast-math).  The HIP projector is
+ * compiled the same way, which is what makes ProjectedSplat records / keys / sort order / tile
+ * lists bit-exact between this file and the GPU.  The composite uses libm expf/sqrtf; the GPU
+ * composite is compared to it within a stated tolerance (tests/test_composite_gpu.py).
+ *
+ * Citations are file:line under /root/reference.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* Camera (src/Camera.ts:85-128) with gl-matrix 3.4.4 semantics (package-lock.json:866-871).   */
+/* gl-matrix stores into Float32Array (each store rounds to f32) and computes in f64.          */
+/* ------------------------------------------------------------------------------------------ */
+
+static void mat4_look_at(float out[16], const float eye[3], const float center[3], const float up[3]) {
+    /* gl-matrix mat4.lookAt: z = normalize(eye-center), x = normalize(up x z), y = normalize(z x x) */
+    double eyex = eye[0], eyey = eye[1], eyez = eye[2];
+    double upx = up[0], upy = up[1], upz = up[2];
+    double cx = center[0], cy = center[1], cz = center[2];
+    const double EPS = 0.000001;
+    if (fabs(eyex - cx) < EPS && fabs(eyey - cy) < EPS && fabs(eyez - cz) < EPS) {
+        memset(out, 0, 16 * sizeof(float));
+        out[0] = out[5] = out[10] = out[15] = 1.0f;
+        return;
+    }
+    double z0 = eyex - cx, z1 = eyey - cy, z2 = eyez - cz;
+    double len = 1.0 / sqrt(z0 * z0 + z1 * z1 + z2 * z2);
+    z0 *= len; z1 *= len; z2 *= len;
+    double x0 = upy * z2 - upz * z1, x1 = upz * z0 - upx * z2, x2 = upx * z1 - upy * z0;
+    len = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+    if (!len) { x0 = x1 = x2 = 0; } else { len = 1.0 / len; x0 *= len; x1 *= len; x2 *= len; }
+    double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+    len = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+    if (!len) { y0 = y1 = y2 = 0; } else { len = 1.0 / len; y0 *= len; y1 *= len; y2 *= len; }
+    out[0] = (float)x0; out[1] = (float)y0; out[2] = (float)z0; out[3] = 0.0f;
+    out[4] = (float)x1; out[5] = (float)y1; out[6] = (float)z1; out[7] = 0.0f;
+    out[8] = (float)x2; out[9] = (float)y2; out[10] = (float)z2; out[11] = 0.0f;
+    out[12] = (float)(-(x0 * eyex + x1 * eyey + x2 * eyez));
+    out[13] = (float)(-(y0 * eyex + y1 * eyey + y2 * eyez));
+    out[14] = (float)(-(z0 * eyex + z1 * eyey + z2 * eyez));
+    out[15] = 1.0f;
+}
+
+static void mat4_perspective_no(float out[16], double fovy, double aspect, double near_, double far_) {
+    /* gl-matrix mat4.perspective == perspectiveNO: GL clip z in [-1,1] */
+    double f = 1.0 / tan(fovy / 2.0);
+    memset(out, 0, 16 * sizeof(float));
+    out[0] = (float)(f / aspect);
+    out[5] = (float)f;
+    out[11] = -1.0f;
+    if (isfinite(far_)) {
+        double nf = 1.0 / (near_ - far_);
+        out[10] = (float)((far_ + near_) * nf);
+        out[14] = (float)(2.0 * far_ * near_ * nf);
+    } else {
+        out[10] = -1.0f;
+        out[14] = (float)(-2.0 * near_);
+    }
+}
+
+static void mat4_multiply(float out[16], const float a[16], const float b[16]) {
+    /* gl-matrix mat4.multiply(out,a,b) = a*b, column-major, f64 accumulate left to right */
+    float r[16];
+    for (int c = 0; c < 4; ++c) {
+        double b0 = b[c * 4 + 0], b1 = b[c * 4 + 1], b2 = b[c * 4 + 2], b3 = b[c * 4 + 3];
+        for (int k = 0; k < 4; ++k)
+            r[c * 4 + k] = (float)(b0 * (double)a[k] + b1 * (double)a[4 + k] + b2 * (double)a[8 + k] +
+                                   b3 * (double)a[12 + k]);
+    }
+    memcpy(out, r, sizeof r);
+}
+
+void orc_camera(const float target[3], double distance, double azimuth, double elevation,
+                double fov_deg, double aspect, double near_, double far_, float vp_out[16],
+                float eye_out[3]) {
+    /* src/Camera.ts:85-95 getCameraPosition; vec3.fromValues rounds to f32 */
+    double x = distance * cos(elevation) * sin(azimuth);
+    double y = distance * sin(elevation);
+    double z = distance * cos(elevation) * cos(azimuth);
+    float eye[3] = {(float)((double)target[0] + x), (float)((double)target[1] + y),
+                    (float)((double)target[2] + z)};
+    const float up[3] = {0.0f, 1.0f, 0.0f};
+    float view[16], proj[16];
+    mat4_look_at(view, eye, target, up);                                           /* :104-109 */
+    mat4_perspective_no(proj, (fov_deg * 3.141592653589793) / 180.0, aspect, near_, far_); /* :112-118 */
+    mat4_multiply(vp_out, proj, view);                                             /* :121-125 */
+    eye_out[0] = eye[0]; eye_out[1] = eye[1]; eye_out[2] = eye[2];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SplatProjector (src/SplatProjector.ts:64-132)                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* clip = VP * vec4(p,1): column-major, each component summed left to right, no FMA */
+static inline void vp_mul(const float *m, float x, float y, float z, float *cx, float *cy,
+                          float *cz, float *cw) {
+    *cx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+    *cy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+    *cz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+    *cw = ((m[3] * x + m[7] * y) + m[11] * z) + m[15];
+}
+
+static inline void to_screen(const float *u, float x, float y, float z, float *sx, float *sy) {
+    float cx, cy, cz, cw;
+    vp_mul(u, x, y, z, &cx, &cy, &cz, &cw);
+    float nx = cx / cw, ny = cy / cw; /* :83 ndc = clip.xyz / clip.w */
+    (void)cz;
+    *sx = ((nx + 1.0f) * 0.5f) * u[20]; /* :86-89 */
+    *sy = ((1.0f - ny) * 0.5f) * u[21];
+}
+
+void orc_project(const float uniforms[22], const float *pos_radius, size_t stride, uint32_t n,
+                 float *projected) {
+    const float *u = uniforms;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *p = pos_radius + (size_t)i * stride;
+        float x = p[0], y = p[1], z = p[2], radius = p[3];
+        /* :77 depth = distance(worldPos, cameraPosition) */
+        float dx = x - u[16], dy = y - u[17], dz = z - u[18];
+        float depth = sqrtf((dx * dx + dy * dy) + dz * dz);
+        float scx, scy;
+        to_screen(u, x, y, z, &scx, &scy);
+        /* :93-113 six axis-aligned offsets, in the shader's order */
+        const float off[6][3] = {{radius, 0, 0}, {-radius, 0, 0}, {0, radius, 0},
+                                 {0, -radius, 0}, {0, 0, radius}, {0, 0, -radius}};
+        float max_r = 0.0f;
+        for (int k = 0; k < 6; ++k) {
+            float ox, oy;
+            to_screen(u, x + off[k][0], y + off[k][1], z + off[k][2], &ox, &oy);
+            float ex = scx - ox, ey = scy - oy;
+            float dist = sqrtf(ex * ex + ey * ey);
+            max_r = fmaxf(max_r, dist); /* WGSL max(): NaN handling is implementation-defined;
+                                           fmaxf drops a NaN operand, the HIP kernel does the same */
+        }
+        float padded = max_r * 1.5f; /* :119 */
+        float *o = projected + (size_t)i * ORC_PROJ_FLOATS;
+        o[0] = scx - padded; o[1] = scy - padded; /* :120 */
+        o[2] = scx + padded; o[3] = scy + padded; /* :121 */
+        o[4] = depth;
+        o[5] = max_r;
+        uint32_t idx = i;
+        memcpy(&o[6], &idx, 4); /* :128 originalIndex */
+        o[7] = 0.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DepthKeyExtractor (src/shaders/extract-depth-keys.wgsl:37-63)                               */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_extract_keys(const float *projected, uint32_t n, uint32_t n_padded, uint32_t *keys,
+                      uint32_t *payload) {
+    for (uint32_t i = 0; i < n_padded; ++i) {
+        if (i >= n) { /* :46-50 */
+            keys[i] = 0xffffffffu;
+            payload[i] = 0xffffffffu;
+            continue;
+        }
+        uint32_t bits;
+        memcpy(&bits, &projected[(size_t)i * ORC_PROJ_FLOATS + 4], 4);
+        uint32_t mask = ((bits >> 31) == 1u) ? 0xffffffffu : 0x80000000u; /* :57-58 */
+        keys[i] = bits ^ mask;
+        payload[i] = i; /* :62 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* RadixSorter contract: stable ascending (src/RadixSorter.ts:263-271)                         */
+/* A plain 4x8-bit LSD counting sort — stable by construction. The reference's WGSL internals   */
+/* (onesweep look-back) are not mirrored; only the result contract is.                         */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_sort_pairs(uint32_t *keys, uint32_t *payload, uint32_t n) {
+    if (n < 2) return;
+    uint32_t *k2 = (uint32_t *)malloc((size_t)n * 4), *p2 = (uint32_t *)malloc((size_t)n * 4);
+    uint32_t *ka = keys, *pa = payload, *kb = k2, *pb = p2;
+    for (int pass = 0; pass < 4; ++pass) {
+        size_t hist[256] = {0};
+        int sh = pass * 8;
+        for (uint32_t i = 0; i < n; ++i) hist[(ka[i] >> sh) & 255]++;
+        size_t run = 0;
+        for (int d = 0; d < 256; ++d) { size_t c = hist[d]; hist[d] = run; run += c; }
+        for (uint32_t i = 0; i < n; ++i) {
+            size_t dst = hist[(ka[i] >> sh) & 255]++;
+            kb[dst] = ka[i];
+            pb[dst] = pa[i];
+        }
+        uint32_t *t = ka; ka = kb; kb = t;
+        t = pa; pa = pb; pb = t;
+    }
+    /* 4 passes: result is back in the caller's arrays */
+    free(k2);
+    free(p2);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PrefixSumScanner (src/PrefixSumScanner.ts:150-155)                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+uint64_t orc_scan_exclusive(const uint32_t *in, uint32_t *out, uint32_t n) {
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t v = in[i]; /* in may alias out */
+        out[i] = (uint32_t)run;
+        run += v;
+    }
+    return run;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* TileBinner.binSorted (src/TileBinner.ts:426-495)                                            */
+/* JS does the arithmetic in f64 on f32 inputs; max/min/floor and the division by the tile      */
+/* size are done in double here too so the result is the JS result for any tile size.          */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int bin_range(const float *rec, uint32_t width, uint32_t height, uint32_t tile,
+                            uint32_t ntx, uint32_t nty, uint32_t *tx0, uint32_t *tx1,
+                            uint32_t *ty0, uint32_t *ty1) {
+    double min_x = fmax((double)rec[0], 0.0), min_y = fmax((double)rec[1], 0.0);
+    double max_x = fmin((double)rec[2], (double)width), max_y = fmin((double)rec[3], (double)height);
+    /* Math.max/min propagate NaN; `NaN >= x` is false and the tile loops then run zero times:
+       a NaN bound bins nowhere. */
+    if (isnan(rec[0]) || isnan(rec[1]) || isnan(rec[2]) || isnan(rec[3])) return 0;
+    if (min_x >= max_x || min_y >= max_y) return 0; /* :437 */
+    double a = floor(min_x / tile), b = fmin(floor(max_x / tile), (double)ntx - 1.0);
+    double c = floor(min_y / tile), d = fmin(floor(max_y / tile), (double)nty - 1.0);
+    if (a > b || c > d) return 0; /* loops run zero times */
+    *tx0 = (uint32_t)a; *tx1 = (uint32_t)b; *ty0 = (uint32_t)c; *ty1 = (uint32_t)d;
+    return 1;
+}
+
+uint64_t orc_bin_sorted(const float *projected, uint32_t n_splats, const uint32_t *sorted,
+                        uint32_t n_sorted, uint32_t width, uint32_t height, uint32_t tile,
+                        uint32_t *counts, uint32_t *offsets, uint32_t *indices, uint64_t cap) {
+    uint32_t ntx = (width + tile - 1) / tile, nty = (height + tile - 1) / tile; /* ensureBuffers */
+    uint32_t nt = ntx * nty;
+    memset(counts, 0, (size_t)nt * 4);
+    for (uint32_t i = 0; i < n_sorted; ++i) { /* :426-450 first pass: count */
+        uint32_t s = sorted[i];
+        if (s >= n_splats) continue; /* padding entries index past the readback -> NaN -> no tiles */
+        uint32_t a, b, c, d;
+        if (!bin_range(projected + (size_t)s * ORC_PROJ_FLOATS, width, height, tile, ntx, nty, &a, &b, &c, &d))
+            continue;
+        for (uint32_t ty = c; ty <= d; ++ty)
+            for (uint32_t tx = a; tx <= b; ++tx) counts[ty * ntx + tx]++;
+    }
+    uint64_t total = orc_scan_exclusive(counts, offsets, nt); /* :452-459 */
+    if (!indices || total > cap) return total;
+    uint32_t *cur = (uint32_t *)malloc((size_t)nt * 4);
+    memcpy(cur, offsets, (size_t)nt * 4);
+    for (uint32_t i = 0; i < n_sorted; ++i) { /* :470-495 second pass: fill in sorted order */
+        uint32_t s = sorted[i];
+        if (s >= n_splats) continue;
+        uint32_t a, b, c, d;
+        if (!bin_range(projected + (size_t)s * ORC_PROJ_FLOATS, width, height, tile, ntx, nty, &a, &b, &c, &d))
+            continue;
+        for (uint32_t ty = c; ty <= d; ++ty)
+            for (uint32_t tx = a; tx <= b; ++tx) indices[cur[ty * ntx + tx]++] = s;
+    }
+    free(cur);
+    return total;
+}
+
+void orc_gpu_tile_range(const float *rec, uint32_t tile, uint32_t ntx, uint32_t nty, uint32_t out[4]) {
+    /* src/shaders/count-tile-hits.wgsl:53-56, f32 arithmetic */
+    float ts = (float)tile;
+    out[0] = (uint32_t)fmaxf(0.0f, floorf(rec[0] / ts));
+    out[1] = (uint32_t)fmaxf(0.0f, floorf(rec[1] / ts));
+    out[2] = (uint32_t)fminf((float)(ntx - 1u), floorf(rec[2] / ts));
+    out[3] = (uint32_t)fminf((float)(nty - 1u), floorf(rec[3] / ts));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ComputeShaderRenderer (src/ComputeShaderRenderer.ts:97-198) — "model A"                     */
+/* ------------------------------------------------------------------------------------------ */
+
+uint8_t orc_unorm8(float v) {
+    if (!(v > 0.0f)) v = 0.0f; /* also maps NaN to 0 */
+    if (v > 1.0f) v = 1.0f;
+    return (uint8_t)(v * 255.0f + 0.5f);
+}
+
+typedef struct {
+    int mode, early_out;
+    const float *color; size_t cs;
+    const float *normals; size_t ns;
+    const float *proj;
+    const uint32_t *indices, *counts, *offsets;
+    uint32_t tile, ntx, width, height, row0, row1;
+    float *out_f32; uint8_t *out_u8;
+    uint64_t consumed;
+} comp_job;
+
+static void composite_rows(comp_job *j) {
+    const float inv_sqrt3 = 1.0f / sqrtf(3.0f); /* normalize(vec3(1,1,1)) :143 */
+    uint64_t consumed = 0;
+    for (uint32_t py = j->row0; py < j->row1; ++py) {
+        for (uint32_t px = 0; px < j->width; ++px) {
+            uint32_t tile_idx = (py / j->tile) * j->ntx + (px / j->tile); /* :161-163 */
+            float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;       /* :169 */
+            uint32_t off = j->offsets[tile_idx], cnt = j->counts[tile_idx];
+            float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            float alpha = 0.0f; /* literal mode */
+            float trans = 1.0f; /* front-to-back mode: T = prod(1-g) */
+            for (uint32_t i = 0; i < cnt; ++i) {
+                uint32_t s = j->indices[off + i];
+                ++consumed;
+                const float *rec = j->proj + (size_t)s * ORC_PROJ_FLOATS;
+                float g = 0.0f, lr = 0.0f, lg = 0.0f, lb = 0.0f;
+                /* evaluateSplat :98-148 */
+                if (!(pxf < rec[0] || pxf > rec[2] || pyf < rec[1] || pyf > rec[3])) {
+                    float scx = (rec[0] + rec[2]) * 0.5f, scy = (rec[1] + rec[3]) * 0.5f; /* :124 */
+                    float r = rec[5];
+                    if (!(r < 0.5f)) { /* :127-129 */
+                        float ox = pxf - scx, oy = pyf - scy;
+                        float dist = sqrtf(ox * ox + oy * oy);
+                        float nd = dist / r;
+                        g = expf(((-0.5f * nd) * nd) / (0.5f * 0.5f)); /* :139-140 */
+                        const float *c = j->color + (size_t)s * j->cs;
+                        const float *nrm = j->normals + (size_t)s * j->ns;
+                        float ndl = (nrm[0] * inv_sqrt3 + nrm[1] * inv_sqrt3) + nrm[2] * inv_sqrt3;
+                        float diffuse = fmaxf(ndl, 0.0f);
+                        float k = 0.85f + 0.15f * diffuse; /* :145 */
+                        lr = c[0] * k; lg = c[1] * k; lb = c[2] * k;
+                    }
+                }
+                if (j->mode == ORC_MODE_REFERENCE_LITERAL) {
+                    /* :183-185 exactly as written */
+                    cr = cr * (1.0f - g) + lr * g;
+                    cg = cg * (1.0f - g) + lg * g;
+                    cb = cb * (1.0f - g) + lb * g;
+                    alpha = alpha * (1.0f - g) + g;
+                    if (j->early_out && alpha >= 0.99f) break; /* :187-190 */
+                } else {
+                    /* SURVEY §8a contract 3: nearest on top, C += c*g*T, T *= (1-g) */
+                    float w = trans * g;
+                    cr = cr + lr * w; cg = cg + lg * w; cb = cb + lb * w;
+                    trans = trans * (1.0f - g);
+                    if (j->early_out && (1.0f - trans) >= 0.99f) break;
+                }
+            }
+            float rem = (j->mode == ORC_MODE_REFERENCE_LITERAL) ? (1.0f - alpha) : trans;
+            float fr = cr + 0.05f * rem, fg = cg + 0.05f * rem, fb = cb + 0.1f * rem; /* :193-195 */
+            size_t o = ((size_t)py * j->width + px) * 4;
+            if (j->out_f32) { j->out_f32[o] = fr; j->out_f32[o + 1] = fg; j->out_f32[o + 2] = fb; j->out_f32[o + 3] = 1.0f; }
+            if (j->out_u8) { j->out_u8[o] = orc_unorm8(fr); j->out_u8[o + 1] = orc_unorm8(fg); j->out_u8[o + 2] = orc_unorm8(fb); j->out_u8[o + 3] = 255; }
+        }
+    }
+    j->consumed = consumed;
+}
+
+uint64_t orc_composite(int mode, int early_out, const float *color_opacity, size_t color_stride,
+                       const float *normals, size_t normal_stride, const float *projected,
+                       const uint32_t *indices, const uint32_t *counts, const uint32_t *offsets,
+                       uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
+                       uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8) {
+    comp_job j = {mode, early_out, color_opacity, color_stride, normals, normal_stride, projected,
+                  indices, counts, offsets, tile, ntx, width, height, row0, row1, out_f32, out_u8, 0};
+    if (row1 > height) j.row1 = height;
+    composite_rows(&j);
+    return j.consumed;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SequentialRenderer (src/SequentialRenderer.ts:68-142,186-209,246-307) — "model B"          */
+/* Software restatement of what the fixed-function pipeline does with that shader pair:        */
+/* two triangles per splat, pixel centres at +0.5, top-left fill rule, perspective-correct uv, */
+/* blend src-alpha/one-minus-src-alpha in float (no 8-bit intermediate quantisation).          */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static inline int edge_top_left(double ax, double ay, double bx, double by) {
+    /* Framebuffer y grows downward; the triangle is oriented so that every edge function
+       w(p) = dx*(py-ay) - dy*(px-ax) is >= 0 inside.  dw/dpx = -dy, so the interior lies to the
+       right of an edge with dy < 0 (a left edge); for dy == 0, w = dx*(py-ay) and the interior
+       lies below when dx > 0 (a top edge). */
+    double dx = bx - ax, dy = by - ay;
+    return (dy < 0) || (dy == 0 && dx > 0);
+}
+
+typedef struct { double x, y, invw; float u, v; } rvert;
+
+static void raster_tri(const rvert *a, const rvert *b, const rvert *c, const float lit[3],
+                       uint32_t width, uint32_t height, float *fb) {
+    double area = (b->x - a->x) * (c->y - a->y) - (b->y - a->y) * (c->x - a->x);
+    if (area == 0) return;
+    const rvert *v0 = a, *v1 = b, *v2 = c;
+    if (area < 0) { v1 = c; v2 = b; area = -area; }
+    double minx = fmin(v0->x, fmin(v1->x, v2->x)), maxx = fmax(v0->x, fmax(v1->x, v2->x));
+    double miny = fmin(v0->y, fmin(v1->y, v2->y)), maxy = fmax(v0->y, fmax(v1->y, v2->y));
+    if (maxx < 0 || maxy < 0 || minx > width || miny > height) return;
+    long x0 = (long)floor(fmax(minx, 0.0)), x1 = (long)ceil(fmin(maxx, (double)width));
+    long y0 = (long)floor(fmax(miny, 0.0)), y1 = (long)ceil(fmin(maxy, (double)height));
+    int tl0 = edge_top_left(v1->x, v1->y, v2->x, v2->y);
+    int tl1 = edge_top_left(v2->x, v2->y, v0->x, v0->y);
+    int tl2 = edge_top_left(v0->x, v0->y, v1->x, v1->y);
+    for (long y = y0; y < y1 && y < (long)height; ++y) {
+        for (long x = x0; x < x1 && x < (long)width; ++x) {
+            double px = x + 0.5, py = y + 0.5;
+            double w0 = (v2->x - v1->x) * (py - v1->y) - (v2->y - v1->y) * (px - v1->x);
+            double w1 = (v0->x - v2->x) * (py - v2->y) - (v0->y - v2->y) * (px - v2->x);
+            double w2 = (v1->x - v0->x) * (py - v0->y) - (v1->y - v0->y) * (px - v0->x);
+            if (w0 < 0 || w1 < 0 || w2 < 0) continue;
+            if ((w0 == 0 && !tl0) || (w1 == 0 && !tl1) || (w2 == 0 && !tl2)) continue;
+            /* perspective-correct interpolation */
+            double b0 = w0 * v0->invw, b1 = w1 * v1->invw, b2 = w2 * v2->invw;
+            double s = b0 + b1 + b2;
+            float u = (float)((b0 * v0->u + b1 * v1->u + b2 * v2->u) / s);
+            float v = (float)((b0 * v0->v + b1 * v1->v + b2 * v2->v) / s);
+            float dist2 = u * u + v * v;                 /* :126 */
+            if (dist2 > 1.0f) continue;                  /* :128-130 discard */
+            float g = expf((-0.5f * dist2) / (0.4f * 0.4f)); /* :132-133 */
+            float *p = fb + ((size_t)y * width + (size_t)x) * 4;
+            /* :189-200 color: src*srcA + dst*(1-srcA); alpha: src*1 + dst*(1-srcA) */
+            p[0] = lit[0] * g + p[0] * (1.0f - g);
+            p[1] = lit[1] * g + p[1] * (1.0f - g);
+            p[2] = lit[2] * g + p[2] * (1.0f - g);
+            p[3] = g + p[3] * (1.0f - g);
+        }
+    }
+}
+
+void orc_sequential(const float uniforms[22], const float *pos_radius, size_t pr_stride,
+                    const float *color_opacity, size_t color_stride, const float *normals,
+                    size_t normal_stride, const uint32_t *order, uint32_t n_order, uint32_t width,
+                    uint32_t height, float *out_f32, uint8_t *out_u8) {
+    size_t npx = (size_t)width * height;
+    float *fb = out_f32 ? out_f32 : (float *)malloc(npx * 16);
+    for (size_t i = 0; i < npx; ++i) { /* :251 clear colour */
+        fb[i * 4] = 0.05f; fb[i * 4 + 1] = 0.05f; fb[i * 4 + 2] = 0.1f; fb[i * 4 + 3] = 1.0f;
+    }
+    const float inv_sqrt3 = 1.0f / sqrtf(3.0f);
+    static const float quad[6][2] = {{-1, -1}, {1, -1}, {-1, 1}, {-1, 1}, {1, -1}, {1, 1}}; /* :99-102 */
+    for (uint32_t i = 0; i < n_order; ++i) {
+        uint32_t s = order[i];
+        const float *p = pos_radius + (size_t)s * pr_stride;
+        const float *c = color_opacity + (size_t)s * color_stride;
+        const float *n = normals + (size_t)s * normal_stride;
+        float radius = p[3];
+        /* computeTangent :68-71 */
+        float up[3] = {0.0f, 1.0f, 0.0f};
+        if (fabsf(n[1]) > 0.9f) { up[0] = 1.0f; up[1] = 0.0f; }
+        float t[3], bt[3];
+        cross3(up, n, t);
+        float tl = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+        t[0] /= tl; t[1] /= tl; t[2] /= tl;
+        cross3(n, t, bt); /* :96 */
+        rvert rv[6];
+        int ok = 1;
+        for (int k = 0; k < 6; ++k) {
+            float ox = quad[k][0], oy = quad[k][1];
+            /* :107-111 */
+            float wx = p[0] + ((t[0] * ox) * radius + (bt[0] * oy) * radius);
+            float wy = p[1] + ((t[1] * ox) * radius + (bt[1] * oy) * radius);
+            float wz = p[2] + ((t[2] * ox) * radius + (bt[2] * oy) * radius);
+            float cx, cy, cz, cw;
+            vp_mul(uniforms, wx, wy, wz, &cx, &cy, &cz, &cw);
+            if (!(cw > 0.0f)) { ok = 0; break; }
+            rv[k].invw = 1.0 / (double)cw;
+            rv[k].x = ((double)cx * rv[k].invw + 1.0) * 0.5 * width;
+            rv[k].y = (1.0 - (double)cy * rv[k].invw) * 0.5 * height;
+            rv[k].u = ox; rv[k].v = oy;
+        }
+        if (!ok) continue;
+        float ndl = (n[0] * inv_sqrt3 + n[1] * inv_sqrt3) + n[2] * inv_sqrt3;
+        float kdiff = 0.85f + 0.15f * fmaxf(ndl, 0.0f); /* :135-137 */
+        float lit[3] = {c[0] * kdiff, c[1] * kdiff, c[2] * kdiff};
+        raster_tri(&rv[0], &rv[1], &rv[2], lit, width, height, fb);
+        raster_tri(&rv[3], &rv[4], &rv[5], lit, width, height, fb);
+    }
+    if (out_u8)
+        for (size_t i = 0; i < npx * 4; ++i) out_u8[i] = orc_unorm8(fb[i]);
+    if (!out_f32) free(fb);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SplatPropertyManager update kernel (src/SplatPropertyManager.ts:82-107)                     */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_update_props(const float *positions, const float *curvature, uint32_t n, float *props) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *p = positions + (size_t)i * 4, *cv = curvature + (size_t)i * 4;
+        float *o = props + (size_t)i * 8;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+        o[3] = 0.04f;                           /* :94 */
+        o[4] = fabsf(cv[0]) * 0.8f + 0.2f;      /* :97 */
+        o[5] = fabsf(cv[1]) * 0.8f + 0.2f;
+        o[6] = fabsf(cv[2]) * 0.8f + 0.2f;
+        o[7] = 1.0f;                            /* :101 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Whole frame, timed per stage (bench.py cpu_baseline leg).  `threads` bands the composite's   */
+/* rows and the projector's splat range over pthreads; sort and binning stay single-threaded    */
+/* like the reference's JS loops (src/TileBinner.ts:426-495).                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+typedef struct { const float *u; const float *props; uint32_t i0, i1; float *proj; } proj_job;
+static void *proj_thread(void *a) {
+    proj_job *j = (proj_job *)a;
+    /* orc_project writes originalIndex = local i; redo with global index afterwards */
+    orc_project(j->u, j->props + (size_t)j->i0 * 8, 8, j->i1 - j->i0, j->proj + (size_t)j->i0 * ORC_PROJ_FLOATS);
+    for (uint32_t i = j->i0; i < j->i1; ++i) memcpy(&j->proj[(size_t)i * ORC_PROJ_FLOATS + 6], &i, 4);
+    return NULL;
+}
+static void *comp_thread(void *a) { composite_rows((comp_job *)a); return NULL; }
+
+int orc_frame(int mode, int early_out, const float uniforms[22], const float *props,
+              const float *normals, uint32_t n, uint32_t width, uint32_t height, uint32_t tile,
+              int threads, float *out_f32, uint8_t *out_u8, uint64_t *total_pairs, double stage_ms[5]) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    uint32_t ntx = (width + tile - 1) / tile, nty = (height + tile - 1) / tile, nt = ntx * nty;
+    float *proj = (float *)malloc((size_t)n * 32 + 32);
+    uint32_t *keys = (uint32_t *)malloc((size_t)n * 4 + 4), *pay = (uint32_t *)malloc((size_t)n * 4 + 4);
+    uint32_t *counts = (uint32_t *)malloc((size_t)nt * 4), *offsets = (uint32_t *)malloc((size_t)nt * 4);
+    if (!proj || !keys || !pay || !counts || !offsets) return -1;
+    pthread_t th[256];
+    double t0 = now_ms();
+    {
+        proj_job pj[256];
+        for (int t = 0; t < threads; ++t) {
+            pj[t] = (proj_job){uniforms, props, (uint32_t)((uint64_t)n * t / threads),
+                               (uint32_t)((uint64_t)n * (t + 1) / threads), proj};
+            pthread_create(&th[t], NULL, proj_thread, &pj[t]);
+        }
+        for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    }
+    double t1 = now_ms();
+    orc_extract_keys(proj, n, n, keys, pay);
+    double t2 = now_ms();
+    orc_sort_pairs(keys, pay, n);
+    double t3 = now_ms();
+    uint64_t total = orc_bin_sorted(proj, n, pay, n, width, height, tile, counts, offsets, NULL, 0);
+    uint32_t *indices = (uint32_t *)malloc((size_t)(total ? total : 1) * 4);
+    if (!indices) return -1;
+    orc_bin_sorted(proj, n, pay, n, width, height, tile, counts, offsets, indices, total);
+    double t4 = now_ms();
+    {
+        comp_job cj[256];
+        for (int t = 0; t < threads; ++t) {
+            /* band whole tile rows so thread boundaries fall on tile boundaries */
+            uint32_t r0 = (uint32_t)((uint64_t)nty * t / threads) * tile;
+            uint32_t r1 = (uint32_t)((uint64_t)nty * (t + 1) / threads) * tile;
+            if (r1 > height) r1 = height;
+            if (r0 > height) r0 = height;
+            cj[t] = (comp_job){mode, early_out, props + 4, 8, normals, 4, proj, indices, counts, offsets,
+                               tile, ntx, width, height, r0, r1, out_f32, out_u8, 0};
+            pthread_create(&th[t], NULL, comp_thread, &cj[t]);
+        }
+        for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    }
+    double t5 = now_ms();
+    if (total_pairs) *total_pairs = total;
+    if (stage_ms) {
+        stage_ms[0] = t1 - t0; stage_ms[1] = t2 - t1; stage_ms[2] = t3 - t2;
+        stage_ms[3] = t4 - t3; stage_ms[4] = t5 - t4;
+    }
+    free(proj); free(keys); free(pay); free(counts); free(offsets); free(indices);
+    return 0;
+}

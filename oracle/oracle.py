@@ -1,0 +1,214 @@
+"""ctypes binding of oracle/_build/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (splat_renderer_amd) never does.  PARITY UNPINNED — see oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+MODE_FRONT_TO_BACK = 0
+MODE_REFERENCE_LITERAL = 1
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO) for f in ("oracle.c", "oracle.h")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp, u32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+        L.orc_camera.argtypes = [fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_double, C.c_double, fp, fp]
+        L.orc_project.argtypes = [fp, fp, C.c_size_t, C.c_uint32, fp]
+        L.orc_extract_keys.argtypes = [fp, C.c_uint32, C.c_uint32, u32p, u32p]
+        L.orc_sort_pairs.argtypes = [u32p, u32p, C.c_uint32]
+        L.orc_scan_exclusive.argtypes = [u32p, u32p, C.c_uint32]
+        L.orc_scan_exclusive.restype = C.c_uint64
+        L.orc_bin_sorted.argtypes = [fp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_uint32, u32p, u32p, u32p, C.c_uint64]
+        L.orc_bin_sorted.restype = C.c_uint64
+        L.orc_gpu_tile_range.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, u32p]
+        L.orc_composite.argtypes = [C.c_int, C.c_int, fp, C.c_size_t, fp, C.c_size_t, fp, u32p, u32p,
+                                    u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, fp, u8p]
+        L.orc_composite.restype = C.c_uint64
+        L.orc_sequential.argtypes = [fp, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, u32p,
+                                     C.c_uint32, C.c_uint32, C.c_uint32, fp, u8p]
+        L.orc_update_props.argtypes = [fp, fp, C.c_uint32, fp]
+        L.orc_frame.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_uint32, C.c_int, fp, u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.orc_frame.restype = C.c_int
+        L.orc_unorm8.argtypes = [C.c_float]
+        L.orc_unorm8.restype = C.c_uint8
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _b(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _c32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def camera(target=(0.0, 0.0, 0.0), distance=3.0, azimuth=0.5, elevation=0.5, fov=45.0, aspect=1.0,
+           near=0.1, far=100.0):
+    """Returns (vp[16] column-major f32, eye[3] f32) — src/Camera.ts:85-128."""
+    t = np.asarray(target, dtype=np.float32)
+    vp = np.zeros(16, np.float32)
+    eye = np.zeros(3, np.float32)
+    lib().orc_camera(_f(t), distance, azimuth, elevation, fov, aspect, near, far, _f(vp), _f(eye))
+    return vp, eye
+
+
+def uniforms(vp, eye, width, height, time=0.0):
+    u = np.zeros(22, np.float32)
+    u[:16] = vp
+    u[16:19] = eye
+    u[19] = time
+    u[20] = width
+    u[21] = height
+    return u
+
+
+def project(u, props):
+    """props: (n,8) interleaved or (n,4) pos_radius plane. Returns (n,8) f32 records."""
+    props = _c32(props)
+    n, stride = props.shape
+    out = np.zeros((n, 8), np.float32)
+    lib().orc_project(_f(_c32(u)), _f(props), stride, n, _f(out))
+    return out
+
+
+def extract_keys(projected, n_padded=None):
+    projected = _c32(projected)
+    n = projected.shape[0]
+    n_padded = n if n_padded is None else n_padded
+    keys = np.zeros(n_padded, np.uint32)
+    payload = np.zeros(n_padded, np.uint32)
+    lib().orc_extract_keys(_f(projected), n, n_padded, _u(keys), _u(payload))
+    return keys, payload
+
+
+def sort_pairs(keys, payload):
+    k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+    p = np.ascontiguousarray(payload, dtype=np.uint32).copy()
+    lib().orc_sort_pairs(_u(k), _u(p), k.shape[0])
+    return k, p
+
+
+def scan_exclusive(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.zeros_like(a)
+    total = lib().orc_scan_exclusive(_u(a), _u(out), a.shape[0])
+    return out, int(total)
+
+
+def bin_sorted(projected, sorted_idx, width, height, tile=16):
+    projected = _c32(projected)
+    sorted_idx = np.ascontiguousarray(sorted_idx, dtype=np.uint32)
+    ntx, nty = -(-width // tile), -(-height // tile)
+    counts = np.zeros(ntx * nty, np.uint32)
+    offsets = np.zeros(ntx * nty, np.uint32)
+    total = lib().orc_bin_sorted(_f(projected), projected.shape[0], _u(sorted_idx), sorted_idx.shape[0],
+                                 width, height, tile, _u(counts), _u(offsets), None, 0)
+    indices = np.zeros(max(int(total), 1), np.uint32)
+    lib().orc_bin_sorted(_f(projected), projected.shape[0], _u(sorted_idx), sorted_idx.shape[0],
+                         width, height, tile, _u(counts), _u(offsets), _u(indices), int(total))
+    return counts, offsets, indices[: int(total)]
+
+
+def gpu_tile_range(rec, tile, ntx, nty):
+    rec = _c32(rec)
+    out = np.zeros(4, np.uint32)
+    lib().orc_gpu_tile_range(_f(rec), tile, ntx, nty, _u(out))
+    return out
+
+
+def composite(mode, early_out, color_opacity, normals, projected, indices, counts, offsets, width,
+              height, tile=16, rows=None, want_u8=True):
+    """color_opacity: (n,4) plane or a view into (n,8) props[:,4:]; normals: (n,4)."""
+    color_opacity = np.asarray(color_opacity, dtype=np.float32)
+    cs = color_opacity.strides[0] // 4
+    normals = _c32(normals)
+    projected = _c32(projected)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    if indices.shape[0] == 0:
+        indices = np.zeros(1, np.uint32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    ntx = -(-width // tile)
+    r0, r1 = (0, height) if rows is None else rows
+    out = np.zeros((height, width, 4), np.float32)
+    out8 = np.zeros((height, width, 4), np.uint8) if want_u8 else None
+    cptr = C.cast(color_opacity.ctypes.data, C.POINTER(C.c_float))
+    consumed = lib().orc_composite(mode, int(early_out), cptr, cs, _f(normals), normals.shape[1], _f(projected),
+                                   _u(indices), _u(counts), _u(offsets), tile, ntx, width, height, r0, r1,
+                                   _f(out), _b(out8) if want_u8 else None)
+    return out, out8, int(consumed)
+
+
+def sequential(u, props, normals, order, width, height):
+    props = _c32(props)
+    assert props.shape[1] == 8
+    normals = _c32(normals)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    out = np.zeros((height, width, 4), np.float32)
+    out8 = np.zeros((height, width, 4), np.uint8)
+    base = props.ctypes.data
+    lib().orc_sequential(_f(_c32(u)), C.cast(base, C.POINTER(C.c_float)), 8,
+                         C.cast(base + 16, C.POINTER(C.c_float)), 8, _f(normals), normals.shape[1],
+                         _u(order), order.shape[0], width, height, _f(out), _b(out8))
+    return out, out8
+
+
+def update_props(positions, curvature):
+    positions = _c32(positions)
+    curvature = _c32(curvature)
+    n = positions.shape[0]
+    props = np.zeros((n, 8), np.float32)
+    lib().orc_update_props(_f(positions), _f(curvature), n, _f(props))
+    return props
+
+
+def frame(u, props, normals, width, height, tile=16, mode=MODE_FRONT_TO_BACK, early_out=True, threads=1,
+          want_f32=True):
+    """Whole CPU frame; returns dict(out_f32, out_u8, total_pairs, stage_ms[project,keys,sort,bin,composite])."""
+    props = _c32(props)
+    normals = _c32(normals)
+    n = props.shape[0]
+    out = np.zeros((height, width, 4), np.float32) if want_f32 else None
+    out8 = np.zeros((height, width, 4), np.uint8)
+    total = C.c_uint64(0)
+    ms = (C.c_double * 5)()
+    rc = lib().orc_frame(mode, int(early_out), _f(_c32(u)), _f(props), _f(normals), n, width, height, tile,
+                         threads, _f(out) if want_f32 else None, _b(out8), C.byref(total), ms)
+    if rc != 0:
+        raise MemoryError("orc_frame allocation failed")
+    return dict(out_f32=out, out_u8=out8, total_pairs=int(total.value), stage_ms=list(ms))
