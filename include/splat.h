@@ -1,0 +1,183 @@
+/*
+ * splat.h — C ABI of libsplat_hip.so: the MI355X (gfx950) tile-raster hot path of
+ * ath92/splat-renderer behind plain pointers and sizes.
+ *
+ * The reference has no FFI: its boundary is the TypeScript class surface of the stage classes
+ * (SURVEY.md §8b).  Each entry point below replaces the GPU work of one reference verb; the
+ * reference file:line it replaces is cited on every declaration (paths under /root/reference).
+ * The bindings a maintainer adds on the reference side (N-API stub + host classes) are shown in
+ * INTEGRATION.md; the Python mirror used by tests/bench is splat_renderer_amd/host.py.
+ *
+ * Conventions
+ *  - every function returns SPLAT_OK (0) or a negative SPLAT_ERR_*; the message is available
+ *    from splat_last_error(ctx).  No C++ exception crosses this boundary.
+ *  - one ctx = one HIP device + one stream.  All work is enqueued on that stream in call order
+ *    (the reference's "queue submission order").  A ctx is not thread-safe; distinct ctxs are
+ *    independent.  Functions do not synchronise with the host unless documented.
+ *  - "dptr" arguments are device pointers (from splat_buf_alloc, hipMalloc, or a
+ *    torch.Tensor.data_ptr()) and must be 16-byte aligned.
+ *  - there is NO CPU fallback anywhere behind this ABI.
+ */
+#ifndef SPLAT_H
+#define SPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPLAT_ABI_VERSION 1
+
+#define SPLAT_OK 0
+#define SPLAT_ERR_INVALID (-1)  /* bad argument */
+#define SPLAT_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define SPLAT_ERR_OOM (-3)      /* device allocation failed */
+#define SPLAT_ERR_CAPACITY (-4) /* a fixed-capacity object is too small for this call */
+#define SPLAT_ERR_STATE (-5)    /* getter called before the verb that produces its result */
+#define SPLAT_ERR_NO_DEVICE (-6)
+#define SPLAT_ERR_COMM (-7)     /* RCCL call failed */
+
+typedef struct splat_ctx splat_ctx;
+typedef struct splat_sorter splat_sorter;
+typedef struct splat_binner splat_binner;
+typedef struct splat_comm splat_comm;
+
+/* Sizes of the reference's records (bytes). */
+#define SPLAT_PROPS_BYTES 32     /* vec4(pos,radius), vec4(rgb,opacity): src/SplatPropertyManager.ts:1-5 */
+#define SPLAT_PROJECTED_BYTES 32 /* ProjectedSplat: src/SplatProjector.ts:47-54 */
+#define SPLAT_SORT_BLOCK 3840    /* key-buffer padding quantum: src/RadixSorter.ts:12-19,46-52 */
+
+/* stage ids for splat_stage_time_ms */
+enum {
+    SPLAT_STAGE_PROJECT = 0, /* project + depth keys */
+    SPLAT_STAGE_SORT = 1,
+    SPLAT_STAGE_BIN = 2,     /* count + scan + fill */
+    SPLAT_STAGE_COMPOSITE = 3,
+    SPLAT_STAGE_EXCHANGE = 4, /* multi-GPU all-gather */
+    SPLAT_STAGE_COUNT = 5
+};
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* GPUDevice + queue equivalent (src/main.ts:16-36). */
+int splat_ctx_create(int device_ordinal, splat_ctx **out);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int splat_ctx_create_on_stream(int device_ordinal, void *hip_stream, splat_ctx **out);
+void splat_ctx_destroy(splat_ctx *ctx);
+/* Last error text of this ctx (or of the calling thread when ctx is NULL). Never NULL. */
+const char *splat_last_error(splat_ctx *ctx);
+/* device.queue.onSubmittedWorkDone equivalent: wait for everything enqueued so far. */
+int splat_sync(splat_ctx *ctx);
+int splat_abi_version(void);
+/* Enable per-stage hipEvent timing (off by default: events cost a few us per stage). */
+int splat_set_timing(splat_ctx *ctx, int enabled);
+/* Duration of the most recent run of `stage`; synchronises on that stage's end event. */
+int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);
+
+/* ---- buffers (GPUBuffer equivalent: device.createBuffer / queue.writeBuffer / mapAsync) --- */
+int splat_buf_alloc(splat_ctx *ctx, size_t bytes, void **dptr);
+int splat_buf_free(splat_ctx *ctx, void *dptr);
+int splat_buf_upload(splat_ctx *ctx, void *dst_dptr, const void *src_host, size_t bytes);   /* async on the stream, src is staged */
+int splat_buf_download(splat_ctx *ctx, void *dst_host, const void *src_dptr, size_t bytes); /* synchronous */
+int splat_buf_zero(splat_ctx *ctx, void *dptr, size_t bytes);
+
+/* ---- SplatPropertyManager.updateFromCurvature  (src/SplatPropertyManager.ts:82-107,153-173) */
+/* positions, curvature: vec4 per splat; props: 32-byte interleaved records. */
+int splat_update_props(splat_ctx *ctx, const void *positions, const void *curvature, uint32_t n,
+                       void *props);
+
+/* ---- SplatProjector.project  (src/SplatProjector.ts:64-132,174-194) ----------------------- */
+/* uniforms: 22 host floats = VP column-major [0..15], eye [16..18], time [19], screenW [20],
+ * screenH [21] (src/main.ts:126-144, src/SplatProjector.ts:35-41).
+ * pos_radius: first vec4(pos,radius); consecutive splats are pr_stride_vec4 float4s apart
+ * (2 = the reference's interleaved property buffer, 1 = a split plane).
+ * projected: n 32-byte ProjectedSplat records (bit-exact vs oracle/orc_project).
+ * keys/payload: if non-NULL the DepthKeyExtractor pass is fused in (n_padded entries, tail =
+ * 0xFFFFFFFF); pass NULL to run the reference's unfused sequence. */
+int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
+                  uint32_t pr_stride_vec4, uint32_t n, void *projected, void *keys, void *payload,
+                  uint32_t n_padded);
+
+/* ---- DepthKeyExtractor.extract  (src/DepthKeyExtractor.ts:71-109, extract-depth-keys.wgsl:37-63) */
+int splat_extract_keys(splat_ctx *ctx, const void *projected, uint32_t n, uint32_t n_padded,
+                       void *keys, void *payload);
+
+/* ---- RadixSorter  (src/RadixSorter.ts:39-100,197-271) ------------------------------------- */
+/* Owns keys/keys_b/payload_a/payload_b for `capacity` pairs (capacity is rounded up to a
+ * multiple of SPLAT_SORT_BLOCK like the reference's paddedSize). */
+int splat_sort_create(splat_ctx *ctx, uint32_t capacity, splat_sorter **out);
+void splat_sort_destroy(splat_sorter *s);
+uint32_t splat_sort_capacity(const splat_sorter *s);
+void *splat_sort_keys(splat_sorter *s);    /* getKeysBuffer():    input keys (u32)    */
+void *splat_sort_payload(splat_sorter *s); /* getPayloadBuffer(): input payload (u32) */
+/* sort(): stable ascending LSD sort of the first n pairs on key bits [bit_begin, bit_end).
+ * The reference always sorts all 32 bits (4 x 8-bit passes). */
+int splat_sort_run(splat_sorter *s, uint32_t n, uint32_t bit_begin, uint32_t bit_end);
+/* getSortedIndicesBuffer(): payload in sorted order (valid after splat_sort_run). */
+void *splat_sort_sorted_payload(splat_sorter *s);
+void *splat_sort_sorted_keys(splat_sorter *s);
+
+/* ---- PrefixSumScanner.scan  (src/PrefixSumScanner.ts:74-87, prefix-sum.wgsl:28-96) -------- */
+/* Exclusive scan of n u32 (out[0] = 0); in may equal out.  total_dptr (optional) receives the
+ * sum of all inputs as one u32.  Entirely on the device for any n (the reference falls back to
+ * a CPU loop above 512 elements: src/PrefixSumScanner.ts:131-162). */
+int splat_scan_u32(splat_ctx *ctx, const void *in, void *out, uint32_t n, void *total_dptr);
+
+/* ---- GPUTileBinner  (src/GPUTileBinner.ts:35-50,190-377) ---------------------------------- */
+/* Lists are exactly TileBinner.binSorted's (src/TileBinner.ts:426-495): splats fully
+ * off-screen are culled and every tile's list is in `sorted` order. */
+int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out);
+void splat_bin_destroy(splat_binner *b);
+/* binSplats(): sorted = n_sorted u32 splat indices (entries >= n_splats are padding and are
+ * skipped).  Only tile rows [tile_row0, tile_row1) are binned (0, UINT32_MAX = all rows) —
+ * the multi-GPU band.  Makes one 4-byte device->host read of the pair total. */
+int splat_bin_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted,
+                  uint32_t n_sorted, uint32_t width, uint32_t height, uint32_t tile_row0,
+                  uint32_t tile_row1);
+uint32_t splat_bin_tile_size(const splat_binner *b);        /* getTileSize() */
+int splat_bin_counts(splat_binner *b, void **dptr);          /* getTileCountsBuffer()  u32[numTiles] */
+int splat_bin_offsets(splat_binner *b, void **dptr);         /* getTileOffsetsBuffer() u32[numTiles] */
+int splat_bin_indices(splat_binner *b, void **dptr);         /* getTileIndicesBuffer() u32[total]    */
+int splat_bin_total(splat_binner *b, uint64_t *total_pairs); /* sum of counts of the last run */
+int splat_bin_dims(splat_binner *b, uint32_t *ntx, uint32_t *nty);
+
+/* ---- ComputeShaderRenderer.render / TileRenderer.render  (src/ComputeShaderRenderer.ts:97-198,362-422) */
+#define SPLAT_COMPOSITE_FRONT_TO_BACK 0     /* SURVEY §8a contract 3: nearest on top (default) */
+#define SPLAT_COMPOSITE_REFERENCE_LITERAL 1 /* src/ComputeShaderRenderer.ts:175-190 as written */
+typedef struct splat_composite_cfg {
+    uint32_t mode;       /* SPLAT_COMPOSITE_* */
+    uint32_t early_out;  /* 1 = stop a pixel at alpha >= 0.99 (reference :187-190) */
+    uint32_t tile_size;  /* must equal the binner's; only 16 is implemented */
+    uint32_t tile_row0;  /* render tile rows [tile_row0, tile_row1) (multi-GPU band) */
+    uint32_t tile_row1;  /* UINT32_MAX = to the last row */
+    uint32_t reserved[3];
+} splat_composite_cfg;
+/* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
+ * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;
+ * only pixels of the rendered tile rows are written.  consumed_dptr (optional, u64) is
+ * incremented by the number of list entries staged before each tile saturated (P_used). */
+int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity,
+                    uint32_t color_stride_vec4, const void *normals, uint32_t normal_stride_vec4,
+                    const void *projected, const void *tile_indices, const void *tile_counts,
+                    const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8,
+                    void *out_rgba32f, void *consumed_dptr);
+
+/* ---- whole frame: project -> keys -> sort -> bin -> composite ---------------- */
+int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
+                       const splat_composite_cfg *cfg, const float *uniforms, const void *props,
+                       const void *normals, uint32_t n, uint32_t width, uint32_t height,
+                       void *projected, void *out_rgba8, void *out_rgba32f);
+
+/* ---- multi-GPU band path (no reference equivalent — the reference is single-device) */
+/* Stable compaction of the splats whose clamped tile-row range meets [tile_row0, tile_row1):
+ * writes (depth key, global index) pairs in ascending index order into the sorter's input
+ * buffers and the number kept to *n_kept_host (synchronises). */
+int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected, uint32_t n,
+                    uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_row0,
+                    uint32_t tile_row1, uint32_t *n_kept_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

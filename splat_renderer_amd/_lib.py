@@ -1,0 +1,103 @@
+"""ctypes loader for libsplat_hip.so (the C ABI in include/splat.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is visible the import of
+the library / creation of a context raises.  This module never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
+
+OK = 0
+ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -6: "NO_DEVICE", -7: "COMM"}
+
+STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2, 3, 4
+STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
+MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
+U32_MAX = 0xFFFFFFFF
+
+
+class SplatError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsplat_hip error {ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class CompositeCfg(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("early_out", C.c_uint32), ("tile_size", C.c_uint32),
+                ("tile_row0", C.c_uint32), ("tile_row1", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+# name -> (restype, argtypes); the single source of truth checked against include/splat.h by
+# tests/test_abi.py
+_vp, _u32, _sz, _i = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
+_pvp = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "splat_abi_version": (_i, []),
+    "splat_ctx_create": (_i, [_i, _pvp]),
+    "splat_ctx_create_on_stream": (_i, [_i, _vp, _pvp]),
+    "splat_ctx_destroy": (None, [_vp]),
+    "splat_last_error": (C.c_char_p, [_vp]),
+    "splat_sync": (_i, [_vp]),
+    "splat_set_timing": (_i, [_vp, _i]),
+    "splat_stage_time_ms": (_i, [_vp, _i, C.POINTER(C.c_float)]),
+    "splat_buf_alloc": (_i, [_vp, _sz, _pvp]),
+    "splat_buf_free": (_i, [_vp, _vp]),
+    "splat_buf_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "splat_buf_download": (_i, [_vp, _vp, _vp, _sz]),
+    "splat_buf_zero": (_i, [_vp, _vp, _sz]),
+    "splat_update_props": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "splat_project": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _vp, _vp, _vp, _u32]),
+    "splat_extract_keys": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "splat_sort_create": (_i, [_vp, _u32, _pvp]),
+    "splat_sort_destroy": (None, [_vp]),
+    "splat_sort_capacity": (_u32, [_vp]),
+    "splat_sort_keys": (_vp, [_vp]),
+    "splat_sort_payload": (_vp, [_vp]),
+    "splat_sort_run": (_i, [_vp, _u32, _u32, _u32]),
+    "splat_sort_sorted_payload": (_vp, [_vp]),
+    "splat_sort_sorted_keys": (_vp, [_vp]),
+    "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "splat_bin_create": (_i, [_vp, _u32, _pvp]),
+    "splat_bin_destroy": (None, [_vp]),
+    "splat_bin_run": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _u32]),
+    "splat_bin_tile_size": (_u32, [_vp]),
+    "splat_bin_counts": (_i, [_vp, _pvp]),
+    "splat_bin_offsets": (_i, [_vp, _pvp]),
+    "splat_bin_indices": (_i, [_vp, _pvp]),
+    "splat_bin_total": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "splat_bin_dims": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
+    "splat_composite": (_i, [_vp, C.POINTER(CompositeCfg), _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _u32,
+                             _vp, _vp, _vp]),
+    "splat_render_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), C.POINTER(C.c_float), _vp, _vp, _u32, _u32,
+                                _u32, _vp, _vp, _vp]),
+    "splat_band_keys": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsplat_hip.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). splat_renderer_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not export what splat.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != OK:
+        msg = load().splat_last_error(ctx)
+        raise SplatError(rc, msg.decode("utf-8", "replace") if msg else "")
+    return rc

@@ -1,0 +1,79 @@
+// common.h — shared by every translation unit of libsplat_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/splat.h"
+
+constexpr int kWave = 64; // CDNA wavefront
+
+struct StageTimer {
+    hipEvent_t beg = nullptr, end = nullptr;
+    bool recorded = false;
+};
+
+struct splat_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool timing = false;
+    StageTimer timers[SPLAT_STAGE_COUNT];
+    // scratch for the generic scan (block sums) and for small device scalars
+    void *scan_ws = nullptr;
+    size_t scan_ws_bytes = 0;
+    // pinned host staging for uploads / tiny readbacks
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+int ctx_fail(splat_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
+int ctx_ensure_scan_ws(splat_ctx *ctx, size_t bytes);
+int ctx_ensure_pinned(splat_ctx *ctx, size_t bytes);
+void stage_begin(splat_ctx *ctx, int stage);
+void stage_end(splat_ctx *ctx, int stage);
+
+#define HIP_TRY(ctx, expr)                                                   \
+    do {                                                                     \
+        hipError_t e__ = (expr);                                             \
+        if (e__ != hipSuccess) return ctx_fail((ctx), SPLAT_ERR_HIP, #expr, e__); \
+    } while (0)
+
+#define LAUNCH_CHECK(ctx, name)                                                       \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) return ctx_fail((ctx), SPLAT_ERR_HIP, "launch " name, e__); \
+    } while (0)
+
+#define ARG_CHECK(ctx, cond)                                               \
+    do {                                                                   \
+        if (!(cond)) return ctx_fail((ctx), SPLAT_ERR_INVALID, "argument check failed: " #cond); \
+    } while (0)
+
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+static inline uint64_t div_up64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ---- internal launchers shared between translation units ------------------------------------
+// scan.hip
+int scan_exclusive_u32(splat_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);
+// radix_sort.hip: sorts n pairs from (k0,p0) using (k1,p1) as the ping-pong partner; returns in
+// *result_in_primary whether the result ended in (k0,p0). hist is a workspace of
+// 256 * div_up(n, RADIX_PART) u32.
+constexpr uint32_t RADIX_PART = 4096; // keys per workgroup partition
+int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1,
+                     uint32_t *hist, uint32_t n, uint32_t bit_begin, uint32_t bit_end,
+                     bool *result_in_primary);
+
+struct splat_sorter {
+    splat_ctx *ctx = nullptr;
+    uint32_t capacity = 0;
+    uint32_t *keys = nullptr, *keys_b = nullptr, *payload = nullptr, *payload_b = nullptr;
+    uint32_t *hist = nullptr;
+    bool result_in_primary = true;
+    bool ran = false;
+};
+
+// grows the sorter's buffers (contents are NOT preserved)
+int sorter_reserve(splat_sorter *s, uint32_t capacity);

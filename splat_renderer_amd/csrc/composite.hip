@@ -1,0 +1,202 @@
+// composite.hip — the per-pixel alpha composite (ComputeShaderRenderer / TileRenderer front end).
+//
+// Reference: /root/reference/src/ComputeShaderRenderer.ts:97-198 (evaluateSplat + main, K11),
+// dispatched 8x8 with every pixel re-gathering idx/props/normal/projected per list entry
+// (:103-115).  CDNA4 design instead:
+//   - one 256-thread workgroup per 16x16 tile; wave w owns the 8x8 pixel quadrant w (one pixel per
+//     lane, so the 64-wide ballot/all of a wave is exactly "this quadrant")
+//   - the tile's list is consumed in batches of 256 entries: thread t gathers entry t ONCE
+//     (index, 32 B ProjectedSplat, colour vec4, normal vec4 — the reference's own layouts),
+//     pre-computes centre / exp2 scale / lit colour and parks 48 B in LDS
+//   - each wave tests the batch against its quadrant rectangle 64 entries per instruction and
+//     walks only the survivors (ballot mask, s_ff1), reading them back as LDS broadcasts
+//   - a pixel stops at alpha >= 0.99 exactly as :187-190; a wave whose 64 pixels have all
+//     stopped skips evaluation, and the workgroup leaves when all four waves have
+//
+// Roofline: HBM in the SURVEY §8d model — 68 B per consumed list entry (4 idx + 32 projected +
+// 16 colour + 16 normal) + 4 B per pixel written.  The inner loop is VALU/LDS work, so the
+// achieved fraction is reported honestly against that model.
+//
+// Compiled with -ffp-contract=fast; compared with the oracle within a stated tolerance.
+#include "common.h"
+
+constexpr int CT = 16;        // tile edge (pixels)
+constexpr int CBATCH = 256;   // list entries staged per round
+
+struct CompositeParams {
+    const float4 *color;  uint32_t color_stride;   // vec4(rgb, opacity)
+    const float4 *normals; uint32_t normal_stride; // vec4(normal, scaleFactor)
+    const float4 *projected;                       // 2 x float4 per splat
+    const uint32_t *indices, *counts, *offsets;
+    uint32_t width, height, ntx, tile_row0;
+    uint32_t *out_rgba8;
+    float4 *out_rgba32f;
+    unsigned long long *consumed;
+};
+
+__device__ __forceinline__ uint32_t unorm8(float v) {
+    v = fminf(fmaxf(v, 0.0f), 1.0f); // fmaxf(NaN,0) = 0
+    return (uint32_t)(v * 255.0f + 0.5f);
+}
+
+template <int MODE, bool EARLY_OUT>
+__global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
+    __shared__ float4 s_bounds[CBATCH]; // min.x, min.y, max.x, max.y   (+inf/-inf = never hit)
+    __shared__ float4 s_geo[CBATCH];    // centre.x, centre.y, exp2 scale, unused
+    __shared__ float4 s_col[CBATCH];    // lit colour rgb, unused
+    __shared__ uint32_t s_wave_done[4];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y + p.tile_row0;
+    const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
+    const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
+
+    const uint32_t qx0 = tx * CT + (w & 1) * 8, qy0 = ty * CT + (w >> 1) * 8;
+    const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool pixel_ok = px < p.width && py < p.height;
+    const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f; // :169
+    // quadrant rectangle of pixel centres, for the per-wave cull
+    const float X0 = (float)qx0 + 0.5f, X1 = (float)qx0 + 7.5f, Y0 = (float)qy0 + 0.5f, Y1 = (float)qy0 + 7.5f;
+
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    float acc = (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) ? 0.0f : 1.0f; // alpha (literal) or transmittance T
+    bool done = !pixel_ok;
+    bool wave_done = false;
+    if (tid < 4) s_wave_done[tid] = 0;
+
+    const float inv_sqrt3 = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
+    uint32_t staged = 0;
+
+    for (uint32_t base = 0; base < count; base += CBATCH) {
+        __syncthreads(); // previous batch fully consumed (and s_wave_done visible)
+        if (EARLY_OUT) {
+            if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
+        }
+        // ---- stage: one entry per thread ---------------------------------------------------------
+        {
+            const uint32_t e = base + tid;
+            float4 bnd = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+            float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), col = geo;
+            if (e < count) {
+                const uint32_t s = p.indices[off + e];
+                const float4 b = p.projected[(size_t)s * 2];
+                const float r = reinterpret_cast<const float *>(p.projected)[(size_t)s * 8 + 5];
+                if (!(r < 0.5f)) { // :127-129 "too small"
+                    const float4 c = p.color[(size_t)s * p.color_stride];
+                    const float4 nrm = p.normals[(size_t)s * p.normal_stride];
+                    const float ndl = (nrm.x * inv_sqrt3 + nrm.y * inv_sqrt3) + nrm.z * inv_sqrt3;
+                    const float kd = 0.85f + 0.15f * fmaxf(ndl, 0.0f); // :144-145
+                    col = make_float4(c.x * kd, c.y * kd, c.z * kd, 0.0f);
+                    // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(dist^2 * scale)
+                    geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), 0.0f); // :124
+                    bnd = b;
+                }
+            }
+            s_bounds[tid] = bnd;
+            s_geo[tid] = geo;
+            s_col[tid] = col;
+        }
+        staged = (count - base < CBATCH) ? count : base + CBATCH;
+        __syncthreads();
+        if (wave_done) continue;
+        // ---- consume: 4 chunks of 64 entries, each culled against this wave's quadrant ------------
+        const uint32_t batch_n = (count - base < CBATCH) ? (count - base) : CBATCH;
+        for (uint32_t c0 = 0; c0 < batch_n; c0 += 64) {
+            const float4 bb = s_bounds[c0 + lane];
+            const bool hit = (bb.x <= X1) && (bb.z >= X0) && (bb.y <= Y1) && (bb.w >= Y0);
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t e = c0 + j; // wave-uniform -> the three reads below are LDS broadcasts
+                const float4 B = s_bounds[e];
+                const float4 G = s_geo[e];
+                const float4 C = s_col[e];
+                const bool inside = !(pxf < B.x || pxf > B.z || pyf < B.y || pyf > B.w); // :118-121
+                const float dx = pxf - G.x, dy = pyf - G.y;
+                float g = __builtin_amdgcn_exp2f((dx * dx + dy * dy) * G.z);
+                g = (inside && !done) ? g : 0.0f;
+                if (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) { // :183-185 as written
+                    const float om = 1.0f - g;
+                    cr = cr * om + C.x * g;
+                    cg = cg * om + C.y * g;
+                    cb = cb * om + C.z * g;
+                    acc = acc * om + g;
+                    if (EARLY_OUT) done = done || (acc >= 0.99f); // :187-190
+                } else { // SURVEY §8a contract 3: nearest on top
+                    const float wgt = acc * g;
+                    cr += C.x * wgt;
+                    cg += C.y * wgt;
+                    cb += C.z * wgt;
+                    acc = acc * (1.0f - g);
+                    if (EARLY_OUT) done = done || ((1.0f - acc) >= 0.99f);
+                }
+            }
+            if (EARLY_OUT) {
+                if (__all(done)) {
+                    wave_done = true;
+                    if (lane == 0) s_wave_done[w] = 1;
+                    break;
+                }
+            }
+        }
+    }
+
+    if (p.consumed && tid == 0 && staged) atomicAdd(p.consumed, (unsigned long long)staged);
+
+    if (pixel_ok) {
+        const float rem = (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) ? (1.0f - acc) : acc;
+        const float fr = cr + 0.05f * rem, fg = cg + 0.05f * rem, fb = cb + 0.1f * rem; // :193-195
+        const size_t o = (size_t)py * p.width + px;
+        if (p.out_rgba8) p.out_rgba8[o] = unorm8(fr) | (unorm8(fg) << 8) | (unorm8(fb) << 16) | (255u << 24);
+        if (p.out_rgba32f) p.out_rgba32f[o] = make_float4(fr, fg, fb, 1.0f);
+    }
+}
+
+extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity,
+                               uint32_t color_stride_vec4, const void *normals, uint32_t normal_stride_vec4,
+                               const void *projected, const void *tile_indices, const void *tile_counts,
+                               const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8, void *out_rgba32f,
+                               void *consumed_dptr) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, cfg != nullptr);
+    ARG_CHECK(ctx, cfg->tile_size == CT); // the kernel's quadrant mapping is built for 16x16 tiles
+    ARG_CHECK(ctx, cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK || cfg->mode == SPLAT_COMPOSITE_REFERENCE_LITERAL);
+    ARG_CHECK(ctx, width >= 1 && height >= 1 && width <= 65535u * CT && height <= 65535u * CT);
+    ARG_CHECK(ctx, color_opacity && normals && projected && tile_indices && tile_counts && tile_offsets);
+    ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
+    ARG_CHECK(ctx, out_rgba8 || out_rgba32f);
+    ARG_CHECK(ctx, (((uintptr_t)color_opacity | (uintptr_t)normals | (uintptr_t)projected | (uintptr_t)out_rgba32f) & 15) == 0);
+    const uint32_t ntx = div_up(width, CT), nty = div_up(height, CT);
+    uint32_t r0 = cfg->tile_row0, r1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
+    if (r0 >= r1) return SPLAT_OK;
+    CompositeParams p;
+    p.color = (const float4 *)color_opacity;
+    p.color_stride = color_stride_vec4;
+    p.normals = (const float4 *)normals;
+    p.normal_stride = normal_stride_vec4;
+    p.projected = (const float4 *)projected;
+    p.indices = (const uint32_t *)tile_indices;
+    p.counts = (const uint32_t *)tile_counts;
+    p.offsets = (const uint32_t *)tile_offsets;
+    p.width = width;
+    p.height = height;
+    p.ntx = ntx;
+    p.tile_row0 = r0;
+    p.out_rgba8 = (uint32_t *)out_rgba8;
+    p.out_rgba32f = (float4 *)out_rgba32f;
+    p.consumed = (unsigned long long *)consumed_dptr;
+    dim3 grid(ntx, r1 - r0), block(256);
+    stage_begin(ctx, SPLAT_STAGE_COMPOSITE);
+    const bool eo = cfg->early_out != 0;
+    if (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
+        if (eo) hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_FRONT_TO_BACK, true>), grid, block, 0, ctx->stream, p);
+        else    hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_FRONT_TO_BACK, false>), grid, block, 0, ctx->stream, p);
+    } else {
+        if (eo) hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_REFERENCE_LITERAL, true>), grid, block, 0, ctx->stream, p);
+        else    hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_REFERENCE_LITERAL, false>), grid, block, 0, ctx->stream, p);
+    }
+    LAUNCH_CHECK(ctx, "k_composite");
+    stage_end(ctx, SPLAT_STAGE_COMPOSITE);
+    return SPLAT_OK;
+}

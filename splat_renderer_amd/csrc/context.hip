@@ -1,0 +1,195 @@
+// context.hip — ctx, buffers, timing.  Replaces the reference's GPUDevice/GPUBuffer plumbing
+// (/root/reference/src/main.ts:16-36; createBuffer/writeBuffer/mapAsync call sites throughout).
+#include "common.h"
+
+#include <cstdio>
+#include <cstring>
+
+static thread_local std::string g_tls_err = "";
+
+int ctx_fail(splat_ctx *ctx, int code, const char *what, hipError_t e) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (ctx) ctx->err = buf;
+    g_tls_err = buf;
+    return code;
+}
+
+int ctx_ensure_scan_ws(splat_ctx *ctx, size_t bytes) {
+    if (ctx->scan_ws_bytes >= bytes) return SPLAT_OK;
+    if (ctx->scan_ws) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->scan_ws));
+        ctx->scan_ws = nullptr;
+        ctx->scan_ws_bytes = 0;
+    }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipMalloc(&ctx->scan_ws, want) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "scan workspace hipMalloc");
+    ctx->scan_ws_bytes = want;
+    return SPLAT_OK;
+}
+
+int ctx_ensure_pinned(splat_ctx *ctx, size_t bytes) {
+    if (ctx->pinned_bytes >= bytes) return SPLAT_OK;
+    if (ctx->pinned) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    size_t want = bytes < (1u << 16) ? (1u << 16) : bytes;
+    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault) != hipSuccess)
+        return ctx_fail(ctx, SPLAT_ERR_OOM, "pinned staging hipHostMalloc");
+    ctx->pinned_bytes = want;
+    return SPLAT_OK;
+}
+
+void stage_begin(splat_ctx *ctx, int stage) {
+    if (!ctx->timing) return;
+    StageTimer &t = ctx->timers[stage];
+    if (!t.beg) {
+        (void)hipEventCreate(&t.beg);
+        (void)hipEventCreate(&t.end);
+    }
+    (void)hipEventRecord(t.beg, ctx->stream);
+}
+
+void stage_end(splat_ctx *ctx, int stage) {
+    if (!ctx->timing) return;
+    StageTimer &t = ctx->timers[stage];
+    (void)hipEventRecord(t.end, ctx->stream);
+    t.recorded = true;
+}
+
+static int ctx_create_impl(int device, void *stream, bool have_stream, splat_ctx **out) {
+    if (!out) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "splat_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return ctx_fail(nullptr, SPLAT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)", e);
+    if (device < 0 || device >= count) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "device ordinal out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return ctx_fail(nullptr, SPLAT_ERR_HIP, "hipSetDevice", e);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return ctx_fail(nullptr, SPLAT_ERR_HIP, "hipGetDeviceProperties", e);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string m = std::string("device is ") + prop.gcnArchName + "; libsplat_hip is built for gfx950 (MI355X) only";
+        return ctx_fail(nullptr, SPLAT_ERR_NO_DEVICE, m.c_str());
+    }
+    splat_ctx *ctx = new splat_ctx();
+    ctx->device = device;
+    if (have_stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return ctx_fail(nullptr, SPLAT_ERR_HIP, "hipStreamCreate", e);
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return SPLAT_OK;
+}
+
+extern "C" {
+
+int splat_abi_version(void) { return SPLAT_ABI_VERSION; }
+
+int splat_ctx_create(int device_ordinal, splat_ctx **out) { return ctx_create_impl(device_ordinal, nullptr, false, out); }
+
+int splat_ctx_create_on_stream(int device_ordinal, void *hip_stream, splat_ctx **out) {
+    return ctx_create_impl(device_ordinal, hip_stream, true, out);
+}
+
+void splat_ctx_destroy(splat_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->timers) {
+        if (t.beg) (void)hipEventDestroy(t.beg);
+        if (t.end) (void)hipEventDestroy(t.end);
+    }
+    if (ctx->scan_ws) (void)hipFree(ctx->scan_ws);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *splat_last_error(splat_ctx *ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+int splat_sync(splat_ctx *ctx) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SPLAT_OK;
+}
+
+int splat_set_timing(splat_ctx *ctx, int enabled) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ctx->timing = enabled != 0;
+    return SPLAT_OK;
+}
+
+int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, stage >= 0 && stage < SPLAT_STAGE_COUNT && ms);
+    StageTimer &t = ctx->timers[stage];
+    if (!t.recorded) return ctx_fail(ctx, SPLAT_ERR_STATE, "stage has not been timed (call splat_set_timing first)");
+    HIP_TRY(ctx, hipEventSynchronize(t.end));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, t.beg, t.end));
+    return SPLAT_OK;
+}
+
+int splat_buf_alloc(splat_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, dptr != nullptr);
+    *dptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "hipMalloc", e);
+    return SPLAT_OK;
+}
+
+int splat_buf_free(splat_ctx *ctx, void *dptr) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    if (!dptr) return SPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(dptr));
+    return SPLAT_OK;
+}
+
+int splat_buf_upload(splat_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, dst && (src || bytes == 0));
+    if (bytes == 0) return SPLAT_OK;
+    // pageable source: hipMemcpyAsync stages it before returning, so src may be reused at once
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SPLAT_OK;
+}
+
+int splat_buf_download(splat_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, src && (dst || bytes == 0));
+    if (bytes == 0) return SPLAT_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SPLAT_OK;
+}
+
+int splat_buf_zero(splat_ctx *ctx, void *dptr, size_t bytes) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, dptr || bytes == 0);
+    if (bytes == 0) return SPLAT_OK;
+    HIP_TRY(ctx, hipMemsetAsync(dptr, 0, bytes, ctx->stream));
+    return SPLAT_OK;
+}
+
+} // extern "C"

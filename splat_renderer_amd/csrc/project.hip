@@ -1,0 +1,149 @@
+// project.hip — SplatProjector + DepthKeyExtractor + SplatPropertyManager update as CDNA4 kernels.
+//
+// Reference: /root/reference/src/SplatProjector.ts:64-132 (K1), src/shaders/extract-depth-keys.wgsl:37-63
+// (K2), src/SplatPropertyManager.ts:82-107 (K12).
+//
+// Roofline: HBM.  Algorithmic bytes per splat: 16 (pos,radius) in + 32 (ProjectedSplat) + 4 (key)
+// + 4 (payload) out = 56 B.  One lane per splat, 16-byte vector load, two 16-byte stores per lane
+// that together fill a 32-byte record, 4-byte coalesced key/payload stores.
+//
+// This file is compiled with -ffp-contract=off: every float op below is one IEEE binary32 op in
+// the order written, identical to oracle/oracle.c, so records and keys are bit-exact.
+#include "common.h"
+
+struct FrameUniforms {
+    float m[16];   // VP, column-major
+    float eye[3];
+    float time;
+    float w, h;
+};
+
+__device__ __forceinline__ void to_screen(const FrameUniforms &u, float x, float y, float z, float &sx, float &sy) {
+    float cx = ((u.m[0] * x + u.m[4] * y) + u.m[8] * z) + u.m[12];
+    float cy = ((u.m[1] * x + u.m[5] * y) + u.m[9] * z) + u.m[13];
+    float cw = ((u.m[3] * x + u.m[7] * y) + u.m[11] * z) + u.m[15];
+    float nx = cx / cw, ny = cy / cw;
+    sx = ((nx + 1.0f) * 0.5f) * u.w;
+    sy = ((1.0f - ny) * 0.5f) * u.h;
+}
+
+__device__ __forceinline__ uint32_t depth_key(float depth) {
+    uint32_t bits = __float_as_uint(depth);
+    uint32_t mask = ((bits >> 31) == 1u) ? 0xffffffffu : 0x80000000u; // extract-depth-keys.wgsl:57-58
+    return bits ^ mask;
+}
+
+template <bool WITH_KEYS>
+__global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
+                                                 uint32_t stride_vec4, uint32_t n, uint32_t n_padded,
+                                                 float4 *__restrict__ projected, uint32_t *__restrict__ keys,
+                                                 uint32_t *__restrict__ payload) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) {
+        if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
+            keys[i] = 0xffffffffu;
+            payload[i] = 0xffffffffu;
+        }
+        return;
+    }
+    float4 pr = pos_radius[(size_t)i * stride_vec4];
+    float x = pr.x, y = pr.y, z = pr.z, radius = pr.w;
+    float dx = x - u.eye[0], dy = y - u.eye[1], dz = z - u.eye[2];
+    float depth = sqrtf((dx * dx + dy * dy) + dz * dz); // SplatProjector.ts:77
+    float scx, scy;
+    to_screen(u, x, y, z, scx, scy);
+    float max_r = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { // :93-113, same offset order as the shader
+        float ox = (k == 0) ? radius : (k == 1) ? -radius : 0.0f;
+        float oy = (k == 2) ? radius : (k == 3) ? -radius : 0.0f;
+        float oz = (k == 4) ? radius : (k == 5) ? -radius : 0.0f;
+        float sx, sy;
+        to_screen(u, x + ox, y + oy, z + oz, sx, sy);
+        float ex = scx - sx, ey = scy - sy;
+        max_r = fmaxf(max_r, sqrtf(ex * ex + ey * ey));
+    }
+    float padded = max_r * 1.5f; // :119
+    float4 a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
+    float4 b = make_float4(depth, max_r, __uint_as_float(i), 0.0f);
+    projected[(size_t)i * 2] = a;
+    projected[(size_t)i * 2 + 1] = b;
+    if (WITH_KEYS) {
+        keys[i] = depth_key(depth);
+        payload[i] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_extract_keys(const float4 *__restrict__ projected, uint32_t n, uint32_t n_padded,
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ payload) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_padded) return;
+    if (i >= n) {
+        keys[i] = 0xffffffffu;
+        payload[i] = 0xffffffffu;
+        return;
+    }
+    float depth = reinterpret_cast<const float *>(projected)[(size_t)i * 8 + 4];
+    keys[i] = depth_key(depth);
+    payload[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_update_props(const float4 *__restrict__ positions, const float4 *__restrict__ curvature,
+                                                      uint32_t n, float4 *__restrict__ props) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = positions[i], c = curvature[i];
+    props[(size_t)i * 2] = make_float4(p.x, p.y, p.z, 0.04f);                                                   // :94
+    props[(size_t)i * 2 + 1] = make_float4(fabsf(c.x) * 0.8f + 0.2f, fabsf(c.y) * 0.8f + 0.2f, fabsf(c.z) * 0.8f + 0.2f, 1.0f); // :97-101
+}
+
+extern "C" {
+
+int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
+                  void *projected, void *keys, void *payload, uint32_t n_padded) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, uniforms && (n == 0 || (pos_radius && projected)));
+    ARG_CHECK(ctx, pr_stride_vec4 >= 1);
+    ARG_CHECK(ctx, (keys == nullptr) == (payload == nullptr));
+    ARG_CHECK(ctx, keys == nullptr || n_padded >= n);
+    ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected) & 15) == 0);
+    FrameUniforms u;
+    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
+    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
+    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
+    uint32_t work = keys ? n_padded : n;
+    if (work == 0) return SPLAT_OK;
+    stage_begin(ctx, SPLAT_STAGE_PROJECT);
+    dim3 grid(div_up(work, 256)), block(256);
+    if (keys)
+        hipLaunchKernelGGL(k_project<true>, grid, block, 0, ctx->stream, u, (const float4 *)pos_radius, pr_stride_vec4, n,
+                           n_padded, (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload);
+    else
+        hipLaunchKernelGGL(k_project<false>, grid, block, 0, ctx->stream, u, (const float4 *)pos_radius, pr_stride_vec4, n,
+                           n, (float4 *)projected, nullptr, nullptr);
+    LAUNCH_CHECK(ctx, "k_project");
+    stage_end(ctx, SPLAT_STAGE_PROJECT);
+    return SPLAT_OK;
+}
+
+int splat_extract_keys(splat_ctx *ctx, const void *projected, uint32_t n, uint32_t n_padded, void *keys, void *payload) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, keys && payload && (n == 0 || projected) && n_padded >= n);
+    if (n_padded == 0) return SPLAT_OK;
+    hipLaunchKernelGGL(k_extract_keys, dim3(div_up(n_padded, 256)), dim3(256), 0, ctx->stream, (const float4 *)projected, n,
+                       n_padded, (uint32_t *)keys, (uint32_t *)payload);
+    LAUNCH_CHECK(ctx, "k_extract_keys");
+    return SPLAT_OK;
+}
+
+int splat_update_props(splat_ctx *ctx, const void *positions, const void *curvature, uint32_t n, void *props) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, n == 0 || (positions && curvature && props));
+    if (n == 0) return SPLAT_OK;
+    hipLaunchKernelGGL(k_update_props, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (const float4 *)positions,
+                       (const float4 *)curvature, n, (float4 *)props);
+    LAUNCH_CHECK(ctx, "k_update_props");
+    return SPLAT_OK;
+}
+
+} // extern "C"

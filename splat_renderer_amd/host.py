@@ -1,0 +1,516 @@
+"""Host-side mirror of the reference's stage classes over the C ABI (include/splat.h).
+
+Same class names, verbs, argument order and error behaviour as the TypeScript classes under
+/root/reference/src, so that tests read like tests of the reference would:
+
+    device = Device()                                   # GPUDevice + queue
+    props = SplatPropertyManager(device, n)
+    projector = SplatProjector(device, n)
+    sorter = RadixSorter(device, n)
+    extractor = DepthKeyExtractor(device)
+    binner = GPUTileBinner(device, 16)
+    renderer = ComputeShaderRenderer(device, None, "rgba8unorm")
+    enc = device.createCommandEncoder()
+    projector.project(enc, uniforms, props.getPropertyBuffer())
+    extractor.extract(enc, projector.getProjectedBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), n, n_padded)
+    sorter.sort()
+    binner.binSplats(enc, projector.getProjectedBuffer(), sorter.getSortedIndicesBuffer(), n, W, H)
+    renderer.render(uniforms, props.getPropertyBuffer(), binner.getTileIndicesBuffer(), normals, ...)
+
+A GPUCommandEncoder maps to "the ctx stream": recording is immediate enqueue, `enc` arguments are
+accepted for signature compatibility and ignored.  A GPUBuffer maps to `Buffer` (device pointer +
+size).  Nothing here computes on the CPU and nothing imports oracle/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CompositeCfg, SplatError, check
+
+U32_MAX = 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+class Buffer:
+    """GPUBuffer equivalent: an owned or borrowed device allocation with a byte size."""
+
+    def __init__(self, device, ptr, size, owned=True):
+        self.device, self.ptr, self.size, self._owned = device, ptr, int(size), owned
+        self._host_shadow = None  # small uniform buffers keep a host copy (the ABI takes host uniforms)
+
+    def destroy(self):
+        if self._owned and self.ptr:
+            check(self.device.lib.splat_buf_free(self.device.ctx, self.ptr), self.device.ctx)
+        self.ptr = None
+
+    def write(self, array, offset=0):
+        a = np.ascontiguousarray(array)
+        if offset + a.nbytes > self.size:
+            raise ValueError("write past the end of the buffer")
+        check(self.device.lib.splat_buf_upload(self.device.ctx, self.ptr + offset, a.ctypes.data, a.nbytes), self.device.ctx)
+        if self.size <= 256:
+            if self._host_shadow is None:
+                self._host_shadow = np.zeros(self.size, np.uint8)
+            self._host_shadow[offset:offset + a.nbytes] = a.view(np.uint8).reshape(-1)
+        return self
+
+    def read(self, dtype=np.uint8, count=None, offset=0):
+        dtype = np.dtype(dtype)
+        if count is None:
+            count = (self.size - offset) // dtype.itemsize
+        out = np.empty(count, dtype)
+        if out.nbytes:
+            check(self.device.lib.splat_buf_download(self.device.ctx, out.ctypes.data, self.ptr + offset, out.nbytes),
+                  self.device.ctx)
+        return out
+
+    def zero(self):
+        check(self.device.lib.splat_buf_zero(self.device.ctx, self.ptr, self.size), self.device.ctx)
+
+
+class _Queue:
+    def __init__(self, device):
+        self._d = device
+
+    def writeBuffer(self, buffer, offset, data):
+        buffer.write(data, offset)
+
+    def submit(self, _command_buffers=None):
+        pass  # work is enqueued on the stream as it is recorded
+
+    def onSubmittedWorkDone(self):
+        self._d.sync()
+
+
+class CommandEncoder:
+    """Accepted wherever the reference takes a GPUCommandEncoder; recording is immediate."""
+
+    def finish(self):
+        return None
+
+
+class Device:
+    """GPUDevice + queue equivalent: one HIP device + one stream (splat_ctx)."""
+
+    def __init__(self, ordinal=0, stream=None):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        if stream is None:
+            check(self.lib.splat_ctx_create(ordinal, C.byref(p)))
+        else:
+            check(self.lib.splat_ctx_create_on_stream(ordinal, C.c_void_p(stream), C.byref(p)))
+        self.ctx = p
+        self.ordinal = ordinal
+        self.queue = _Queue(self)
+
+    def createBuffer(self, size):
+        p = C.c_void_p()
+        check(self.lib.splat_buf_alloc(self.ctx, int(size), C.byref(p)), self.ctx)
+        return Buffer(self, p.value, size)
+
+    def createBufferFrom(self, array):
+        a = np.ascontiguousarray(array)
+        return self.createBuffer(max(a.nbytes, 16)).write(a)
+
+    def wrap(self, ptr, size):
+        """Borrow an existing device allocation (e.g. torch.Tensor.data_ptr())."""
+        return Buffer(self, int(ptr), size, owned=False)
+
+    def createCommandEncoder(self):
+        return CommandEncoder()
+
+    def sync(self):
+        check(self.lib.splat_sync(self.ctx), self.ctx)
+
+    def setTiming(self, enabled=True):
+        check(self.lib.splat_set_timing(self.ctx, int(enabled)), self.ctx)
+
+    def stageTimeMs(self, stage):
+        ms = C.c_float()
+        check(self.lib.splat_stage_time_ms(self.ctx, stage, C.byref(ms)), self.ctx)
+        return float(ms.value)
+
+    def destroy(self):
+        if self.ctx:
+            self.lib.splat_ctx_destroy(self.ctx)
+            self.ctx = None
+
+
+def _uniform_floats(u):
+    """Accepts a host float array or a small uniform Buffer written through queue.writeBuffer."""
+    if isinstance(u, Buffer):
+        if u._host_shadow is None:
+            raise SplatError(-1, "uniform buffer was never written")
+        u = u._host_shadow.view(np.float32)
+    u = np.ascontiguousarray(u, dtype=np.float32)
+    return u
+
+
+# ------------------------------------------------------------------------------------------------
+class PointManager:
+    """src/PointManager.ts:41,220-252 — ping-pong position buffers.  The reference seeds points
+    with unseeded Math.random on an SDF surface (out of scope); here `scene` is an (n,4) f32
+    position array (or a seed) and reinitialize() re-uploads it."""
+
+    def __init__(self, device, scene):
+        self.device = device
+        if isinstance(scene, (int, np.integer)):
+            from .scene import make_scene
+            props, _ = make_scene(int(scene))
+            scene = np.concatenate([props[:, :3], np.ones((props.shape[0], 1), np.float32)], axis=1)
+        self._positions = np.ascontiguousarray(scene, dtype=np.float32)
+        self.numPoints = self._positions.shape[0]
+        self._buffers = [device.createBuffer(self.numPoints * 16), device.createBuffer(self.numPoints * 16)]
+        self._current = 0
+        self.reinitialize()
+
+    def reinitialize(self):  # :220-231
+        self._buffers[self._current].write(self._positions)
+
+    def swap(self):  # :240-242
+        self._current = 1 - self._current
+
+    def getCurrentPositionBuffer(self):  # :233-235
+        return self._buffers[self._current]
+
+    def getNextPositionBuffer(self):  # :236-238
+        return self._buffers[1 - self._current]
+
+    def getNumPoints(self):  # :244-246
+        return self.numPoints
+
+    def destroy(self):  # :248-252
+        for b in self._buffers:
+            b.destroy()
+
+
+class SplatPropertyManager:
+    """src/SplatPropertyManager.ts:13-181 — owns the 32 B/splat interleaved property buffer."""
+
+    def __init__(self, device, numSplats):
+        self.device, self.numSplats = device, numSplats
+        self.propertyBuffer = device.createBuffer(numSplats * 32)
+        data = np.zeros((numSplats, 8), np.float32)  # initializeDefaults :33-50
+        data[:, 3] = 0.04
+        data[:, 4:7] = 1.0
+        data[:, 7] = 0.7
+        self.propertyBuffer.write(data)
+
+    def updateFromCurvature(self, commandEncoder, positionBuffer, curvatureBuffer):  # :153-173
+        d = self.device
+        check(d.lib.splat_update_props(d.ctx, positionBuffer.ptr, curvatureBuffer.ptr, self.numSplats,
+                                       self.propertyBuffer.ptr), d.ctx)
+
+    def setFromArrays(self, props):
+        """Synthetic scenes: upload (n,8) interleaved records directly."""
+        self.propertyBuffer.write(np.ascontiguousarray(props, np.float32))
+
+    def getPropertyBuffer(self):  # :175-177
+        return self.propertyBuffer
+
+    def destroy(self):  # :179-181
+        self.propertyBuffer.destroy()
+
+
+class SplatProjector:
+    """src/SplatProjector.ts:5-203."""
+
+    def __init__(self, device, numSplats):
+        self.device, self.numSplats = device, numSplats
+        self.projectedBuffer = device.createBuffer(numSplats * 32)  # :19-23
+
+    def project(self, commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer=None, payloadBuffer=None,
+                paddedSize=0):  # :174-194
+        """keysBuffer/payloadBuffer (extension): fuse DepthKeyExtractor.extract into the same kernel."""
+        d = self.device
+        u = _uniform_floats(uniformBuffer)
+        if u.shape[0] < 22:
+            raise SplatError(-1, "uniform block needs 22 floats (VP, eye, time, screenW, screenH)")
+        check(d.lib.splat_project(d.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), splatPropertyBuffer.ptr, 2, self.numSplats,
+                                  self.projectedBuffer.ptr, keysBuffer.ptr if keysBuffer else None,
+                                  payloadBuffer.ptr if payloadBuffer else None, paddedSize), d.ctx)
+
+    def getProjectedBuffer(self):  # :196-198
+        return self.projectedBuffer
+
+    def destroy(self):  # :200-202
+        self.projectedBuffer.destroy()
+
+
+class DepthKeyExtractor:
+    """src/DepthKeyExtractor.ts:5-115."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def extract(self, commandEncoder, projectedBuffer, keysBuffer, payloadBuffer, numSplats, paddedSize):  # :71-109
+        d = self.device
+        check(d.lib.splat_extract_keys(d.ctx, projectedBuffer.ptr, numSplats, paddedSize, keysBuffer.ptr, payloadBuffer.ptr),
+              d.ctx)
+
+    def cleanupTempBuffers(self):  # :111-114 (no per-call uniform buffers exist here)
+        pass
+
+
+class RadixSorter:
+    """src/RadixSorter.ts:21-301 — stable ascending sort of (key, payload) u32 pairs."""
+
+    def __init__(self, device, numSplats):
+        self.device, self.numSplats = device, numSplats
+        p = C.c_void_p()
+        check(device.lib.splat_sort_create(device.ctx, numSplats, C.byref(p)), device.ctx)
+        self._s = p
+        self.paddedSize = device.lib.splat_sort_capacity(p)  # :46-52
+
+    def sort(self, numKeys=None, bitBegin=0, bitEnd=32):  # :197-264
+        d = self.device
+        n = self.numSplats if numKeys is None else numKeys
+        check(d.lib.splat_sort_run(self._s, n, bitBegin, bitEnd), d.ctx)
+
+    def getSortedIndicesBuffer(self):  # :269-271
+        return Buffer(self.device, self.device.lib.splat_sort_sorted_payload(self._s), self.paddedSize * 4, owned=False)
+
+    def getSortedKeysBuffer(self):
+        return Buffer(self.device, self.device.lib.splat_sort_sorted_keys(self._s), self.paddedSize * 4, owned=False)
+
+    def getKeysBuffer(self):  # :273-275
+        return Buffer(self.device, self.device.lib.splat_sort_keys(self._s), self.paddedSize * 4, owned=False)
+
+    def getPayloadBuffer(self):  # :277-279
+        return Buffer(self.device, self.device.lib.splat_sort_payload(self._s), self.paddedSize * 4, owned=False)
+
+    def cleanupTempBuffers(self):  # :281-284
+        pass
+
+    def destroy(self):  # :286-300
+        if self._s:
+            self.device.lib.splat_sort_destroy(self._s)
+            self._s = None
+
+
+class PrefixSumScanner:
+    """src/PrefixSumScanner.ts:8-168 — exclusive scan; never leaves the device here."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def scan(self, commandEncoder, inputBuffer, outputBuffer, numElements, totalBuffer=None):  # :74-87
+        d = self.device
+        check(d.lib.splat_scan_u32(d.ctx, inputBuffer.ptr, outputBuffer.ptr, numElements,
+                                   totalBuffer.ptr if totalBuffer else None), d.ctx)
+
+    def cleanupTempBuffers(self):  # :164-167
+        pass
+
+
+class GPUTileBinner:
+    """src/GPUTileBinner.ts:11-378."""
+
+    def __init__(self, device, tileSize):
+        self.device, self.tileSize = device, tileSize
+        p = C.c_void_p()
+        check(device.lib.splat_bin_create(device.ctx, tileSize, C.byref(p)), device.ctx)
+        self._b = p
+        self.prefixSumScanner = PrefixSumScanner(device)  # :49
+        self._tiles = 0
+
+    def binSplats(self, commandEncoder, projectedBuffer, sortedIndicesBuffer, numSplats, screenWidth, screenHeight,
+                  tileRow0=0, tileRow1=U32_MAX, numSorted=None):  # :190-338
+        d = self.device
+        n_sorted = numSplats if numSorted is None else numSorted
+        check(d.lib.splat_bin_run(self._b, projectedBuffer.ptr, numSplats, sortedIndicesBuffer.ptr, n_sorted, screenWidth,
+                                  screenHeight, tileRow0, tileRow1), d.ctx)
+        self._tiles = -(-screenWidth // self.tileSize) * -(-screenHeight // self.tileSize)
+
+    def _get(self, fn, size):
+        p = C.c_void_p()
+        rc = fn(self._b, C.byref(p))
+        if rc != 0:
+            # the reference throws Error("Tile ... buffer not initialized") (:340-359)
+            raise SplatError(rc, self.device.lib.splat_last_error(self.device.ctx).decode())
+        return Buffer(self.device, p.value, size, owned=False)
+
+    def getTileOffsetsBuffer(self):  # :340-345
+        return self._get(self.device.lib.splat_bin_offsets, self._tiles * 4)
+
+    def getTileIndicesBuffer(self):  # :347-352
+        return self._get(self.device.lib.splat_bin_indices, max(self.getTotalIndices(), 1) * 4)
+
+    def getTileCountsBuffer(self):  # :354-359
+        return self._get(self.device.lib.splat_bin_counts, self._tiles * 4)
+
+    def getTotalIndices(self):
+        t = C.c_uint64()
+        check(self.device.lib.splat_bin_total(self._b, C.byref(t)), self.device.ctx)
+        return int(t.value)
+
+    def getTileSize(self):  # :361-363
+        return self.tileSize
+
+    def cleanupTempBuffers(self):  # :365-369
+        self.prefixSumScanner.cleanupTempBuffers()
+
+    def destroy(self):  # :371-377
+        if self._b:
+            self.device.lib.splat_bin_destroy(self._b)
+            self._b = None
+
+
+class PerTileSorter:
+    """src/PerTileSorter.ts:6-223.  The reference's per-tile LDS sort is racy and capped at 2048
+    entries; GPUTileBinner here already emits every list in sorted order, so sort()
+    has nothing to reorder and is a no-op kept for call-site compatibility."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def sort(self, commandEncoder, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, splatIndicesBuffer, numTiles,
+             maxSplatsPerTile):  # :174-213
+        return None
+
+    def cleanupTempBuffers(self):
+        pass
+
+    def destroy(self):
+        pass
+
+
+class ComputeShaderRenderer:
+    """src/ComputeShaderRenderer.ts:5-469 — the per-pixel composite.  The canvas blit (:268-338,
+    :425-456) is out of scope (no canvas); the rgba8unorm output texture is exposed instead."""
+
+    def __init__(self, device, context=None, presentationFormat="rgba8unorm", mode=_lib.MODE_FRONT_TO_BACK,
+                 earlyOut=True):
+        self.device = device
+        self.mode, self.earlyOut = mode, earlyOut
+        self.outputTexture = None
+        self.outputFloat = None
+        self._wh = (0, 0)
+        self.tileRows = (0, U32_MAX)
+        self.consumedBuffer = None
+
+    def ensureOutputTexture(self, width, height, wantFloat=False):  # :340-360
+        if self._wh != (width, height):
+            if self.outputTexture:
+                self.outputTexture.destroy()
+            if self.outputFloat:
+                self.outputFloat.destroy()
+                self.outputFloat = None
+            self.outputTexture = self.device.createBuffer(width * height * 4)
+            self._wh = (width, height)
+        if wantFloat and self.outputFloat is None:
+            self.outputFloat = self.device.createBuffer(width * height * 16)
+
+    def render(self, uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projectedBuffer,
+               tileListsBuffer, tileOffsetsBuffer, tileSize, numTilesX, width, height, wantFloat=False):  # :362-462
+        d = self.device
+        if numTilesX != -(-width // tileSize):
+            raise SplatError(-1, "numTilesX does not match ceil(width / tileSize)")
+        self.ensureOutputTexture(width, height, wantFloat)
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), tileSize, self.tileRows[0], self.tileRows[1])
+        check(d.lib.splat_composite(d.ctx, C.byref(cfg), splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
+                                    projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr,
+                                    width, height, self.outputTexture.ptr,
+                                    self.outputFloat.ptr if (wantFloat and self.outputFloat) else None,
+                                    self.consumedBuffer.ptr if self.consumedBuffer else None), d.ctx)
+
+    def readPixels(self):
+        w, h = self._wh
+        return self.outputTexture.read(np.uint8).reshape(h, w, 4)
+
+    def readPixelsFloat(self):
+        w, h = self._wh
+        return self.outputFloat.read(np.float32).reshape(h, w, 4)
+
+    def destroy(self):  # :464-468
+        if self.outputTexture:
+            self.outputTexture.destroy()
+        if self.outputFloat:
+            self.outputFloat.destroy()
+        if self.consumedBuffer:
+            self.consumedBuffer.destroy()
+        self.outputTexture = self.outputFloat = self.consumedBuffer = None
+
+
+class TileRenderer(ComputeShaderRenderer):
+    """src/TileRenderer.ts:5-355.  The reference draws instanced oriented quads per tile in a CPU
+    loop over a fixed-stride index layout (:291); north_star names this class for the per-pixel
+    composite, so here it fronts the same HIP composite as ComputeShaderRenderer.  render() keeps
+    the reference's argument list; the projected records and prefix-sum offsets the composite
+    needs (absent from that list) are bound beforehand with bindTileData()."""
+
+    def __init__(self, device, context=None, presentationFormat="rgba8unorm", **kw):
+        super().__init__(device, context, presentationFormat, **kw)
+        self._projected = self._offsets = self._counts = None
+
+    def bindTileData(self, projectedBuffer, tileCountsBuffer, tileOffsetsBuffer):
+        self._projected, self._counts, self._offsets = projectedBuffer, tileCountsBuffer, tileOffsetsBuffer
+
+    def render(self, uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, tileCountsData,
+               numTilesX, numTilesY, tileSize, maxSplatsPerTile, width, height, wantFloat=False):  # :234-348
+        if self._projected is None:
+            raise SplatError(-5, "TileRenderer.render: call bindTileData(projected, counts, offsets) first")
+        if numTilesY != -(-height // tileSize):
+            raise SplatError(-1, "numTilesY does not match ceil(height / tileSize)")
+        return ComputeShaderRenderer.render(self, uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer,
+                                            self._projected, self._counts, self._offsets, tileSize, numTilesX, width, height,
+                                            wantFloat)
+
+
+class Renderer:
+    """src/Renderer.ts:13,250,311 keeps its name as the whole-frame facade: the app's render call
+    (src/main.ts:183-190) becomes one call that runs project -> keys -> sort -> bin -> composite
+    on the device.  (The reference's body — opaque depth-tested quads — is out of scope.)"""
+
+    def __init__(self, device, context=None, presentationFormat="rgba8unorm", numPoints=0, tileSize=16,
+                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True):
+        self.device, self.numPoints, self.tileSize = device, numPoints, tileSize
+        self.projector = SplatProjector(device, numPoints)
+        self.sorter = RadixSorter(device, numPoints)
+        self.binner = GPUTileBinner(device, tileSize)
+        self.mode, self.earlyOut = mode, earlyOut
+        self.output = None
+        self.outputFloat = None
+        self._wh = (0, 0)
+
+    def render(self, uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height, tileRows=(0, U32_MAX),
+               wantFloat=False):
+        d = self.device
+        u = _uniform_floats(uniformData).copy()
+        if u.shape[0] < 22:
+            u = np.concatenate([u[:20], np.array([width, height], np.float32)])
+        if self._wh != (width, height):
+            if self.output:
+                self.output.destroy()
+            if self.outputFloat:
+                self.outputFloat.destroy()
+                self.outputFloat = None
+            self.output = d.createBuffer(width * height * 4)
+            self._wh = (width, height)
+        if wantFloat and self.outputFloat is None:
+            self.outputFloat = d.createBuffer(width * height * 16)
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1])
+        check(d.lib.splat_render_frame(d.ctx, self.sorter._s, self.binner._b, C.byref(cfg),
+                                       u.ctypes.data_as(C.POINTER(C.c_float)), propertyBuffer.ptr, normalsBuffer.ptr,
+                                       self.numPoints, width, height, self.projector.getProjectedBuffer().ptr,
+                                       self.output.ptr, self.outputFloat.ptr if wantFloat else None), d.ctx)
+        self.binner._tiles = -(-width // self.tileSize) * -(-height // self.tileSize)
+        return self.output
+
+    def readPixels(self):
+        w, h = self._wh
+        return self.output.read(np.uint8).reshape(h, w, 4)
+
+    def readPixelsFloat(self):
+        w, h = self._wh
+        return self.outputFloat.read(np.float32).reshape(h, w, 4)
+
+    def destroy(self):
+        self.projector.destroy()
+        self.sorter.destroy()
+        self.binner.destroy()
+        if self.output:
+            self.output.destroy()
+        if self.outputFloat:
+            self.outputFloat.destroy()

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def device():
+    """One splat ctx for the whole GPU session (a ctx is one device + one stream)."""
+    import splat_renderer_amd as sr
+    dev = sr.Device(0)
+    yield dev
+    dev.destroy()

@@ -1,0 +1,326 @@
+"""GPU parity tests: every stage through the C ABI (via the host classes) against the oracle.
+
+Bit-exact: ProjectedSplat records, keys, payload, sort order, scan, tile counts/offsets/lists.
+Tolerance (stated below): composited pixels.
+"""
+import numpy as np
+import pytest
+
+import splat_renderer_amd as sr
+from oracle import oracle as O
+from tests.helpers import make_case, oracle_pipeline
+
+pytestmark = pytest.mark.gpu
+
+# ---- composite tolerance (float RGBA in [0,1]) -------------------------------------------------
+# early-out OFF: the GPU evaluates exp2(d^2 * k) instead of exp(-0.5 nd^2 / 0.25) and contracts
+# FMAs; both are a few ulp per layer.
+TOL_NO_EARLY_OUT = 2e-5
+# early-out ON: a pixel whose alpha lands within float noise of the 0.99 threshold may stop one
+# entry earlier/later than the oracle; what it then gains/loses is bounded by (1-0.99) * max colour.
+TOL_EARLY_OUT_BOUND = 0.0101
+FRAC_ABOVE_TIGHT = 2e-3  # at most this fraction of pixels may exceed TOL_NO_EARLY_OUT with early-out on
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,w,h,seed", [(1, 64, 64, 1), (7, 64, 48, 2), (1000, 256, 256, 3), (10000, 256, 256, 1234),
+                                        (50000, 640, 360, 5)])
+def test_project_and_keys_bit_exact(device, n, w, h, seed):
+    props, normals, u = make_case(n, w, h, seed)
+    ref = oracle_pipeline(props, normals, u, w, h, n_padded=sr.scene.padded_size(n))
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    proj = sr.SplatProjector(device, n)
+    sorter = sr.RadixSorter(device, n)
+    ext = sr.DepthKeyExtractor(device)
+    enc = device.createCommandEncoder()
+    proj.project(enc, u, pm.getPropertyBuffer())
+    ext.extract(enc, proj.getProjectedBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), n, sorter.paddedSize)
+    got = proj.getProjectedBuffer().read(np.float32).reshape(n, 8)
+    assert np.array_equal(bits(got), bits(ref["proj"]))
+    assert sorter.paddedSize == sr.scene.padded_size(n)
+    assert np.array_equal(sorter.getKeysBuffer().read(np.uint32), ref["keys"])
+    assert np.array_equal(sorter.getPayloadBuffer().read(np.uint32), ref["payload"])
+    # fused form writes the same keys
+    sorter.getKeysBuffer().zero()
+    proj.project(enc, u, pm.getPropertyBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), sorter.paddedSize)
+    assert np.array_equal(sorter.getKeysBuffer().read(np.uint32), ref["keys"])
+    assert np.array_equal(bits(proj.getProjectedBuffer().read(np.float32)), bits(ref["proj"]).reshape(-1))
+    for o in (pm, proj, sorter):
+        o.destroy()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 1023, 4095, 4096, 4097, 8191, 12289, 100000, 1000003])
+@pytest.mark.parametrize("kind", ["random", "few_values", "all_equal", "sorted_desc"])
+def test_radix_sort_stable(device, n, kind):
+    rng = np.random.default_rng(n * 7 + len(kind))
+    if kind == "random":
+        keys = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    elif kind == "few_values":  # heavy duplicates -> stability matters, skewed digits
+        keys = rng.choice(np.array([0, 1, 0x80000000, 0xFFFFFFFF, 0x3F800000], np.uint32), size=n)
+    elif kind == "all_equal":
+        keys = np.full(n, 0xDEADBEEF, np.uint32)
+    else:
+        keys = np.arange(n, 0, -1, dtype=np.uint32) * np.uint32(2654435761)
+        keys = np.sort(keys)[::-1].copy()
+    payload = np.arange(n, dtype=np.uint32)
+    s = sr.RadixSorter(device, max(n, 1))
+    if n:
+        s.getKeysBuffer().write(keys)
+        s.getPayloadBuffer().write(payload)
+    s.sort(n)
+    order = np.argsort(keys, kind="stable").astype(np.uint32)
+    assert np.array_equal(s.getSortedIndicesBuffer().read(np.uint32, n), order)
+    assert np.array_equal(s.getSortedKeysBuffer().read(np.uint32, n), keys[order])
+    s.destroy()
+
+
+@pytest.mark.parametrize("bits_range", [(0, 8), (0, 13), (8, 16), (0, 15), (5, 6)])
+def test_radix_sort_bit_ranges(device, bits_range):
+    b0, b1 = bits_range
+    n = 50000
+    rng = np.random.default_rng(b0 * 100 + b1)
+    keys = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    payload = rng.permutation(n).astype(np.uint32)
+    s = sr.RadixSorter(device, n)
+    s.getKeysBuffer().write(keys)
+    s.getPayloadBuffer().write(payload)
+    s.sort(n, b0, b1)
+    sub = (keys >> np.uint32(b0)) & np.uint32((1 << (b1 - b0)) - 1)
+    order = np.argsort(sub, kind="stable")
+    assert np.array_equal(s.getSortedIndicesBuffer().read(np.uint32, n), payload[order])
+    assert np.array_equal(s.getSortedKeysBuffer().read(np.uint32, n), keys[order])
+    s.destroy()
+
+
+def test_sort_capacity_error(device):
+    s = sr.RadixSorter(device, 100)
+    with pytest.raises(sr.SplatError):
+        s.sort(s.paddedSize + 1)
+    s.destroy()
+
+
+@pytest.mark.parametrize("n", [1, 5, 255, 256, 1024, 1025, 8160, 16384, 16385, 32400, 100000, 1 << 20, 3000001])
+def test_scan_exclusive(device, n):
+    scanner = sr.PrefixSumScanner(device)
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 2000, size=n, dtype=np.uint32)
+    if n == 5:
+        a = np.array([1, 2, 3, 4, 5], np.uint32)  # the reference's one stated known answer
+    src = device.createBufferFrom(a)
+    dst = device.createBuffer(n * 4)
+    tot = device.createBuffer(16)
+    scanner.scan(None, src, dst, n, tot)
+    want = np.concatenate([[0], np.cumsum(a, dtype=np.uint64)[:-1]]).astype(np.uint32)
+    assert np.array_equal(dst.read(np.uint32, n), want)
+    assert int(tot.read(np.uint32, 1)[0]) == int(a.sum(dtype=np.uint64) & 0xFFFFFFFF)
+    if n == 5:
+        assert dst.read(np.uint32, 5).tolist() == [0, 1, 3, 6, 10]  # GPU_PIPELINE_PLAN.md:632-635
+    scanner.scan(None, src, src, n)  # in place
+    assert np.array_equal(src.read(np.uint32, n), want)
+    for b in (src, dst, tot):
+        b.destroy()
+
+
+CASES = [(1, 64, 64, 1, 1.0), (7, 64, 48, 2, 1.0), (1000, 256, 256, 3, 1.0), (10000, 256, 256, 1234, 1.0),
+         (20000, 250, 130, 9, 1.0),  # ragged: width/height not multiples of 16
+         (3000, 96, 80, 7, 3.0)]
+
+
+def run_gpu_pipeline(device, props, normals, u, n, w, h, tile=16):
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    proj = sr.SplatProjector(device, n)
+    sorter = sr.RadixSorter(device, n)
+    ext = sr.DepthKeyExtractor(device)
+    binner = sr.GPUTileBinner(device, tile)
+    enc = device.createCommandEncoder()
+    proj.project(enc, u, pm.getPropertyBuffer())
+    ext.extract(enc, proj.getProjectedBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), n, sorter.paddedSize)
+    sorter.sort()
+    binner.binSplats(enc, proj.getProjectedBuffer(), sorter.getSortedIndicesBuffer(), n, w, h)
+    return dict(pm=pm, nbuf=nbuf, proj=proj, sorter=sorter, binner=binner)
+
+
+def destroy_all(g):
+    for k in ("pm", "proj", "sorter", "binner"):
+        g[k].destroy()
+    g["nbuf"].destroy()
+
+
+@pytest.mark.parametrize("n,w,h,seed,rs", CASES)
+def test_sort_and_bin_bit_exact(device, n, w, h, seed, rs):
+    props, normals, u = make_case(n, w, h, seed, rs)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    g = run_gpu_pipeline(device, props, normals, u, n, w, h)
+    assert np.array_equal(g["sorter"].getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n])
+    b = g["binner"]
+    assert b.getTotalIndices() == ref["indices"].shape[0]
+    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
+    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    destroy_all(g)
+
+
+def test_binner_getters_throw_before_run(device):
+    b = sr.GPUTileBinner(device, 16)
+    for getter in (b.getTileOffsetsBuffer, b.getTileIndicesBuffer, b.getTileCountsBuffer):
+        with pytest.raises(sr.SplatError, match="not initialized"):  # GPUTileBinner.ts:340-359
+            getter()
+    assert b.getTileSize() == 16
+    b.destroy()
+
+
+def test_bin_offscreen_and_padding(device):
+    """Splats fully off-screen are culled (TileBinner.ts:437); 0xFFFFFFFF padding bins nowhere."""
+    n, w, h = 6, 64, 64
+    rec = np.zeros((n, 8), np.float32)
+    rec[0, :4] = [-50, 10, -20, 30]     # left of the screen
+    rec[1, :4] = [10, 70, 30, 90]       # below the screen
+    rec[2, :4] = [-5, -5, 5, 5]         # straddles the top-left corner -> tile 0
+    rec[3, :4] = [60, 60, 100, 100]     # straddles the bottom-right corner -> tile 15
+    rec[4, :4] = [16, 16, 32, 32]       # exactly on tile edges -> tiles (1..2, 1..2)
+    rec[5, :4] = [np.nan, 0, 10, 10]    # NaN bins nowhere
+    sorted_idx = np.array([3, 0xFFFFFFFF, 4, 2, 1, 0, 5, 0xFFFFFFFF], np.uint32)
+    counts, offsets, idx = O.bin_sorted(rec, sorted_idx, w, h)
+    assert counts.sum() == 1 + 1 + 4
+    pbuf = device.createBufferFrom(rec)
+    sbuf = device.createBufferFrom(sorted_idx)
+    b = sr.GPUTileBinner(device, 16)
+    b.binSplats(None, pbuf, sbuf, n, w, h, numSorted=sorted_idx.shape[0])
+    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), counts)
+    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), offsets)
+    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, idx.shape[0]), idx)
+    b.destroy()
+    pbuf.destroy()
+    sbuf.destroy()
+
+
+def test_bin_empty(device):
+    rec = np.zeros((4, 8), np.float32)
+    rec[:, :4] = [-10, -10, -5, -5]
+    b = sr.GPUTileBinner(device, 16)
+    pbuf = device.createBufferFrom(rec)
+    sbuf = device.createBufferFrom(np.arange(4, dtype=np.uint32))
+    b.binSplats(None, pbuf, sbuf, 4, 100, 50)
+    assert b.getTotalIndices() == 0
+    assert not b.getTileCountsBuffer().read(np.uint32).any()
+    assert not b.getTileOffsetsBuffer().read(np.uint32).any()
+    b.getTileIndicesBuffer()
+    b.destroy()
+
+
+@pytest.mark.parametrize("n,w,h,seed,rs", CASES)
+@pytest.mark.parametrize("mode", [sr.MODE_FRONT_TO_BACK, sr.MODE_REFERENCE_LITERAL])
+@pytest.mark.parametrize("early_out", [False, True])
+def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
+    props, normals, u = make_case(n, w, h, seed, rs)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    want, want8, _ = O.composite(mode, early_out, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
+                                 ref["offsets"], w, h)
+    g = run_gpu_pipeline(device, props, normals, u, n, w, h)
+    r = sr.ComputeShaderRenderer(device, None, "rgba8unorm", mode=mode, earlyOut=early_out)
+    b = g["binner"]
+    r.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], g["proj"].getProjectedBuffer(),
+             b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, -(-w // 16), w, h, wantFloat=True)
+    got = r.readPixelsFloat()
+    got8 = r.readPixels()
+    err = np.abs(got - want)
+    if early_out:
+        assert err.max() <= TOL_EARLY_OUT_BOUND
+        assert (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
+        assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 3
+    else:
+        assert err.max() <= TOL_NO_EARLY_OUT
+        assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 1
+    assert (got8[..., 3] == 255).all()
+    r.destroy()
+    destroy_all(g)
+
+
+def test_tile_renderer_fronts_composite(device):
+    n, w, h = 2000, 128, 96
+    props, normals, u = make_case(n, w, h, 11, 2.0)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    want, _, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
+                             ref["offsets"], w, h)
+    g = run_gpu_pipeline(device, props, normals, u, n, w, h)
+    b = g["binner"]
+    tr = sr.TileRenderer(device, None, "rgba8unorm")
+    with pytest.raises(sr.SplatError):
+        tr.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], ref["counts"], 8, 6, 16, 4096, w, h)
+    tr.bindTileData(g["proj"].getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer())
+    tr.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], ref["counts"], 8, 6, 16, 4096, w, h,
+              wantFloat=True)
+    assert np.abs(tr.readPixelsFloat() - want).max() <= TOL_EARLY_OUT_BOUND
+    tr.destroy()
+    destroy_all(g)
+
+
+@pytest.mark.parametrize("bands", [2, 3, 8])
+def test_band_rendering_stitches_bit_identically(device, bands):
+    """rendering tile-row bands separately (what each rank of a multi-GPU frame does)
+    and stitching gives the single-device image bit for bit."""
+    n, w, h = 20000, 320, 200
+    props, normals, u = make_case(n, w, h, 21, 1.5)
+    pbuf = device.createBufferFrom(props)
+    nbuf = device.createBufferFrom(normals)
+    full = sr.Renderer(device, None, "rgba8unorm", n)
+    full.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    want = full.readPixelsFloat().copy()
+    nty = -(-h // 16)
+    stitched = np.zeros_like(want)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    for k in range(bands):
+        r0, r1 = nty * k // bands, nty * (k + 1) // bands
+        r.output and r.output.zero()
+        r.render(u, pbuf, nbuf, None, w, h, tileRows=(r0, r1), wantFloat=True)
+        img = r.readPixelsFloat()
+        stitched[r0 * 16:min(r1 * 16, h)] = img[r0 * 16:min(r1 * 16, h)]
+    assert np.array_equal(stitched.view(np.uint32), want.view(np.uint32))
+    full.destroy()
+    r.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
+
+
+def test_update_props(device):
+    n = 5000
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    cur = rng.standard_normal((n, 4)).astype(np.float32)
+    want = O.update_props(pos, cur)
+    pm = sr.SplatPropertyManager(device, n)
+    d0 = pm.getPropertyBuffer().read(np.float32).reshape(n, 8)
+    assert np.allclose(d0[:, 3], 0.04) and np.allclose(d0[:, 7], 0.7) and (d0[:, 4:7] == 1).all()  # :33-50
+    pb, cb = device.createBufferFrom(pos), device.createBufferFrom(cur)
+    pm.updateFromCurvature(None, pb, cb)
+    got = pm.getPropertyBuffer().read(np.float32).reshape(n, 8)
+    assert np.array_equal(bits(got), bits(want))
+    for o in (pm, pb, cb):
+        o.destroy()
+
+
+def test_full_frame_C0(device):
+    """BASELINE configs[0]: 10k Gaussians @256x256, whole frame through splat_render_frame."""
+    n, w, h = sr.scene.CONFIGS["C0"]
+    props, normals, u = make_case(n, w, h)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    assert ref["indices"].shape[0] == 137051  # SURVEY §8 dry-run statistic for this scene
+    want, want8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"],
+                                 ref["counts"], ref["offsets"], w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    assert np.array_equal(r.sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"])
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32), ref["indices"])
+    err = np.abs(r.readPixelsFloat() - want)
+    assert err.max() <= TOL_EARLY_OUT_BOUND
+    assert (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
+    r.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
