@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — Msplats/s + frames/s of the tile-raster hot path on synthetic random-Gaussian scenes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one frame (project -> depth keys -> radix sort -> tile bin -> composite) over inputs
+already resident in HBM.  N=1: workload C2 (5M Gaussians @1920x1080, the configuration
+BASELINE.json's metric is quoted on).  N>1: the same frame sharded by tile-row bands with one
+RCCL all-gather of projected splats (strong scaling: total work fixed).  Prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import splat_renderer_amd as sr  # noqa: E402
+from splat_renderer_amd import _lib, dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+
+
+def composite_alg_bytes(p_used, width, height):
+    """per consumed list entry 4 (idx) + 32 (ProjectedSplat) + 16 (colour vec4) +
+    16 (normal vec4) = 68 B, plus 4 B per rgba8 pixel written."""
+    return 68 * p_used + 4 * width * height
+
+
+def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height):
+    """SURVEY §8d whole-frame model: project+key 56N, sort 68Np, count 20N, scan 8T, fill 20N+4P,
+    composite 68 P_used + 4WH."""
+    return 56 * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height)
+
+
+def cpu_baseline(name, props, normals, u, width, height):
+    """The oracle's whole frame (model A, front-to-back, early-out on) timed on this box's host
+    cores.  Sample = ONE full frame of the same workload (about 7 s single-threaded for C2), once
+    on 1 thread (the reference's path is one JS thread) and once on all cores."""
+    from oracle import oracle as O  # the checker, timed as the reported CPU baseline only
+    n = props.shape[0]
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    r1 = O.frame(u, props, normals, width, height, threads=1, want_f32=False)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rn = O.frame(u, props, normals, width, height, threads=cores, want_f32=False)
+    tn = time.perf_counter() - t0
+    return {"value": n / t1 / 1e6, "unit": "Msplats/s", "cores": 1, "kind": "port",
+            "sample": f"1 full frame of {name} (N={n}, {width}x{height}), oracle/oracle.c model A, 1 thread",
+            "seconds": round(t1, 3), "stage_ms": [round(x, 1) for x in r1["stage_ms"]],
+            "all_cores": {"value": n / tn / 1e6, "cores": cores, "seconds": round(tn, 3),
+                          "note": "projector + composite banded over pthreads; sort and binning stay serial"},
+            "frame_u8": rn["out_u8"]}
+
+
+def load_traffic(config):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f).get(config, {}).get("k_composite_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", choices=sorted(sr.scene.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    name = args.config
+    n, width, height = sr.scene.CONFIGS[name]
+    tile = sr.scene.TILE
+    ntx, nty = -(-width // tile), -(-height // tile)
+    props, normals = sr.scene.make_scene(n)
+    cam = sr.Camera()
+    cam.setAspect(width / height)
+    u = cam.uniforms(width, height)
+    workload = f"{name}: {n} synthetic Gaussians @{width}x{height}, {tile}x{tile} tiles"
+
+    if world == 1:
+        result = run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload)
+    else:
+        result = run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world)
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload):
+    dev = sr.Device(0)
+    lib, ctx = dev.lib, dev.ctx
+    pbuf = dev.createBufferFrom(props)
+    nbuf = dev.createBufferFrom(normals)
+    r = sr.Renderer(dev, None, "rgba8unorm", n, tile)
+
+    def frame():
+        r.render(u, pbuf, nbuf, None, width, height)
+
+    for _ in range(args.warmup):
+        frame()
+    dev.sync()
+    # timed region: exactly K frames, HIP-event stage timing on (a few us per stage)
+    dev.setTiming(True)
+    dev.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    dev.sync()
+    dt = time.perf_counter() - t0
+    stage_ms = {}
+    for sid, sname in enumerate(_lib.STAGE_NAMES[:4]):
+        cnt, tot = C.c_uint32(), C.c_double()
+        _lib.check(lib.splat_stage_time_stats(ctx, sid, C.byref(cnt), C.byref(tot)), ctx)
+        stage_ms[sname] = tot.value / max(cnt.value, 1)
+    consumed = C.c_uint64()
+    _lib.check(lib.splat_timing_consumed(ctx, C.byref(consumed)), ctx)
+    dev.setTiming(False)
+    p_used = consumed.value / args.steps
+    pairs = r.binner.getTotalIndices()
+
+    comp_bytes = composite_alg_bytes(p_used, width, height)
+    comp_s = stage_ms["composite"] / 1e3
+    achieved = comp_bytes / comp_s / 1e9
+    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height)
+    result = {
+        "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
+        "frames_per_s": args.steps / dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
+                   "pairs_P": pairs, "pairs_consumed_P_used": round(p_used), "parallelism": "1 GPU",
+                   "composite": "front-to-back, early-out at alpha>=0.99"},
+        "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name),
+                     "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"]},
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
+                           "achieved_GBps": frame_bytes / (dt / args.steps) / 1e9,
+                           "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+    }
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(name, props, normals, u, width, height)
+        ref8 = cb.pop("frame_u8")
+        if not args.no_parity:
+            got8 = r.readPixels()
+            diff = np.abs(got8.astype(np.int16) - ref8.astype(np.int16))
+            result["parity_vs_cpu_frame"] = {"max_abs_lsb": int(diff.max()),
+                                             "pixels_off_by_more_than_1": int((diff.max(axis=2) > 1).sum())}
+        result["cpu_baseline"] = cb
+    r.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
+    dev.destroy()
+    return result
+
+
+def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world):
+    import torch
+    import torch.distributed as td
+    torch.cuda.set_device(local_rank)
+    td.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    per = dist.shard_size(n, world)
+    stages = dist.HipStages(torch, local_rank, per * world, width, height, tile)
+    pt = torch.from_numpy(props).cuda()
+    nt = torch.from_numpy(normals).cuda()
+    br = dist.BandRenderer(stages, n, width, height, rank, world, td.all_gather_into_tensor, tile)
+
+    def frame():
+        br.render(u, pt.data_ptr(), nt.data_ptr())
+
+    for _ in range(args.warmup):
+        frame()
+    torch.cuda.synchronize()
+    td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    torch.cuda.synchronize()
+    td.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    td.all_reduce(tmax, op=td.ReduceOp.MAX)
+    dt = float(tmax.item())
+    kept = torch.tensor([stages.kept], dtype=torch.int64, device="cuda")
+    kept_all = [torch.zeros_like(kept) for _ in range(world)]
+    td.all_gather(kept_all, kept)
+    result = {
+        "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
+        "frames_per_s": args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
+                   "parallelism": f"tile-row bands x{world} + 1 RCCL all-gather of {per * 32} B shards per frame",
+                   "splats_kept_per_rank": [int(k.item()) for k in kept_all],
+                   "composite": "front-to-back, early-out at alpha>=0.99"},
+        "roofline": None, "cpu_baseline": None,
+    }
+    td.barrier()
+    stages.destroy()
+    td.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,12 @@ int splat_abi_version(void);
 int splat_set_timing(splat_ctx *ctx, int enabled);
 /* Duration of the most recent run of `stage`; synchronises on that stage's end event. */
 int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);
+/* Every timed run of `stage` since timing was last enabled: number of samples and their summed
+ * duration (synchronises).  Enabling timing again starts a new sample set. */
+int splat_stage_time_stats(splat_ctx *ctx, int stage, uint32_t *samples, double *total_ms);
+/* List entries staged by splat_render_frame's composite since timing was last enabled (P_used of
+ * SURVEY §8d, at the kernel's 256-entry batch granularity); synchronises. */
+int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries);
 
 /* ---- buffers (GPUBuffer equivalent: device.createBuffer / queue.writeBuffer / mapAsync) --- */
 int splat_buf_alloc(splat_ctx *ctx, size_t bytes, void **dptr);
@@ -170,6 +176,11 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
                        void *projected, void *out_rgba8, void *out_rgba32f);
 
 /* ---- multi-GPU band path (no reference equivalent — the reference is single-device) */
+/* Projects splats [first, first+count) of the scene into projected_slice[0..count) with
+ * originalIndex = global index: the per-rank share of the projector before the all-gather. */
+int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
+                        uint32_t pr_stride_vec4, uint32_t first, uint32_t count,
+                        void *projected_slice);
 /* Stable compaction of the splats whose clamped tile-row range meets [tile_row0, tile_row1):
  * writes (depth key, global index) pairs in ascending index order into the sorter's input
  * buffers and the number kept to *n_kept_host (synchronises). */

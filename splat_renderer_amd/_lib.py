@@ -42,6 +42,8 @@ SIGNATURES = {
     "splat_sync": (_i, [_vp]),
     "splat_set_timing": (_i, [_vp, _i]),
     "splat_stage_time_ms": (_i, [_vp, _i, C.POINTER(C.c_float)]),
+    "splat_stage_time_stats": (_i, [_vp, _i, C.POINTER(_u32), C.POINTER(C.c_double)]),
+    "splat_timing_consumed": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "splat_buf_alloc": (_i, [_vp, _sz, _pvp]),
     "splat_buf_free": (_i, [_vp, _vp]),
     "splat_buf_upload": (_i, [_vp, _vp, _vp, _sz]),
@@ -72,6 +74,7 @@ SIGNATURES = {
                              _vp, _vp, _vp]),
     "splat_render_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), C.POINTER(C.c_float), _vp, _vp, _u32, _u32,
                                 _u32, _vp, _vp, _vp]),
+    "splat_project_slice": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
     "splat_band_keys": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
 }
 

@@ -9,9 +9,12 @@
 
 constexpr int kWave = 64; // CDNA wavefront
 
+#include <vector>
+// One begin/end event pair per timed launch of a stage; pairs are pooled and reused after
+// splat_set_timing(ctx, 1) resets the cursor, so K frames give K samples per stage.
 struct StageTimer {
-    hipEvent_t beg = nullptr, end = nullptr;
-    bool recorded = false;
+    std::vector<hipEvent_t> beg, end;
+    size_t used = 0;
 };
 
 struct splat_ctx {
@@ -24,6 +27,7 @@ struct splat_ctx {
     // scratch for the generic scan (block sums) and for small device scalars
     void *scan_ws = nullptr;
     size_t scan_ws_bytes = 0;
+    unsigned long long *d_consumed = nullptr; // list entries staged by the composite while timing is on
     // pinned host staging for uploads / tiny readbacks
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -50,18 +50,22 @@ int ctx_ensure_pinned(splat_ctx *ctx, size_t bytes) {
 void stage_begin(splat_ctx *ctx, int stage) {
     if (!ctx->timing) return;
     StageTimer &t = ctx->timers[stage];
-    if (!t.beg) {
-        (void)hipEventCreate(&t.beg);
-        (void)hipEventCreate(&t.end);
+    if (t.used == t.beg.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        t.beg.push_back(a);
+        t.end.push_back(b);
     }
-    (void)hipEventRecord(t.beg, ctx->stream);
+    (void)hipEventRecord(t.beg[t.used], ctx->stream);
 }
 
 void stage_end(splat_ctx *ctx, int stage) {
     if (!ctx->timing) return;
     StageTimer &t = ctx->timers[stage];
-    (void)hipEventRecord(t.end, ctx->stream);
-    t.recorded = true;
+    if (t.used >= t.beg.size()) return;
+    (void)hipEventRecord(t.end[t.used], ctx->stream);
+    ++t.used;
 }
 
 static int ctx_create_impl(int device, void *stream, bool have_stream, splat_ctx **out) {
@@ -113,9 +117,10 @@ void splat_ctx_destroy(splat_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &t : ctx->timers) {
-        if (t.beg) (void)hipEventDestroy(t.beg);
-        if (t.end) (void)hipEventDestroy(t.end);
+        for (auto e : t.beg) (void)hipEventDestroy(e);
+        for (auto e : t.end) (void)hipEventDestroy(e);
     }
+    if (ctx->d_consumed) (void)hipFree(ctx->d_consumed);
     if (ctx->scan_ws) (void)hipFree(ctx->scan_ws);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -133,6 +138,39 @@ int splat_sync(splat_ctx *ctx) {
 int splat_set_timing(splat_ctx *ctx, int enabled) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ctx->timing = enabled != 0;
+    if (ctx->timing) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto &t : ctx->timers) t.used = 0; // start a new sample set
+        if (!ctx->d_consumed && hipMalloc((void **)&ctx->d_consumed, 16) != hipSuccess)
+            return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counter hipMalloc");
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, 16, ctx->stream));
+    }
+    return SPLAT_OK;
+}
+
+int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, entries != nullptr);
+    if (!ctx->d_consumed) return ctx_fail(ctx, SPLAT_ERR_STATE, "timing was never enabled");
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_consumed, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *entries = v;
+    return SPLAT_OK;
+}
+
+int splat_stage_time_stats(splat_ctx *ctx, int stage, uint32_t *samples, double *total_ms) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, stage >= 0 && stage < SPLAT_STAGE_COUNT && samples && total_ms);
+    StageTimer &t = ctx->timers[stage];
+    *samples = (uint32_t)t.used;
+    *total_ms = 0.0;
+    for (size_t i = 0; i < t.used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventSynchronize(t.end[i]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, t.beg[i], t.end[i]));
+        *total_ms += ms;
+    }
     return SPLAT_OK;
 }
 
@@ -140,9 +178,9 @@ int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, stage >= 0 && stage < SPLAT_STAGE_COUNT && ms);
     StageTimer &t = ctx->timers[stage];
-    if (!t.recorded) return ctx_fail(ctx, SPLAT_ERR_STATE, "stage has not been timed (call splat_set_timing first)");
-    HIP_TRY(ctx, hipEventSynchronize(t.end));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, t.beg, t.end));
+    if (t.used == 0) return ctx_fail(ctx, SPLAT_ERR_STATE, "stage has not been timed (call splat_set_timing first)");
+    HIP_TRY(ctx, hipEventSynchronize(t.end[t.used - 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, t.beg[t.used - 1], t.end[t.used - 1]));
     return SPLAT_OK;
 }
 

@@ -90,7 +90,7 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
     if ((rc = splat_bin_indices(binner, &indices)) != SPLAT_OK) return rc;
     const char *color = (const char *)props + 16; // second vec4 of each interleaved record
     return splat_composite(ctx, cfg, color, 2, normals, 1, projected, indices, counts, offsets, width, height, out_rgba8,
-                           out_rgba32f, nullptr);
+                           out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
 }
 
 } // extern "C"

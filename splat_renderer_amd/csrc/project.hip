@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t depth_key(float depth) {
 
 template <bool WITH_KEYS>
 __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
-                                                 uint32_t stride_vec4, uint32_t n, uint32_t n_padded,
+                                                 uint32_t stride_vec4, uint32_t n, uint32_t n_padded, uint32_t index_base,
                                                  float4 *__restrict__ projected, uint32_t *__restrict__ keys,
                                                  uint32_t *__restrict__ payload) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -65,12 +65,12 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
     }
     float padded = max_r * 1.5f; // :119
     float4 a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
-    float4 b = make_float4(depth, max_r, __uint_as_float(i), 0.0f);
+    float4 b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
     projected[(size_t)i * 2] = a;
     projected[(size_t)i * 2 + 1] = b;
     if (WITH_KEYS) {
         keys[i] = depth_key(depth);
-        payload[i] = i;
+        payload[i] = index_base + i;
     }
 }
 
@@ -117,11 +117,30 @@ int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
     dim3 grid(div_up(work, 256)), block(256);
     if (keys)
         hipLaunchKernelGGL(k_project<true>, grid, block, 0, ctx->stream, u, (const float4 *)pos_radius, pr_stride_vec4, n,
-                           n_padded, (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload);
+                           n_padded, 0u, (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload);
     else
         hipLaunchKernelGGL(k_project<false>, grid, block, 0, ctx->stream, u, (const float4 *)pos_radius, pr_stride_vec4, n,
-                           n, (float4 *)projected, nullptr, nullptr);
+                           n, 0u, (float4 *)projected, nullptr, nullptr);
     LAUNCH_CHECK(ctx, "k_project");
+    stage_end(ctx, SPLAT_STAGE_PROJECT);
+    return SPLAT_OK;
+}
+
+int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t first,
+                        uint32_t count, void *projected_slice) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, uniforms && (count == 0 || (pos_radius && projected_slice)) && pr_stride_vec4 >= 1);
+    ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected_slice) & 15) == 0);
+    if (count == 0) return SPLAT_OK;
+    FrameUniforms u;
+    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
+    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
+    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
+    stage_begin(ctx, SPLAT_STAGE_PROJECT);
+    const float4 *src = (const float4 *)pos_radius + (size_t)first * pr_stride_vec4;
+    hipLaunchKernelGGL(k_project<false>, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream, u, src, pr_stride_vec4, count,
+                       count, first, (float4 *)projected_slice, nullptr, nullptr);
+    LAUNCH_CHECK(ctx, "k_project(slice)");
     stage_end(ctx, SPLAT_STAGE_PROJECT);
     return SPLAT_OK;
 }

@@ -1,0 +1,134 @@
+"""Multi-GPU frame: tile-row bands + ONE all-gather of projected splats.
+
+The reference is single-device (no collective anywhere), so this module has no
+reference counterpart; it composes the same C-ABI stages:
+
+    rank r:  project splats [r*per, (r+1)*per)            splat_project_slice
+             all-gather the 32-byte ProjectedSplat shards  <- the frame's only exchange (RCCL/xGMI)
+             keep splats whose tile rows meet my band     splat_band_keys  (stable compaction)
+             sort kept (depth key, global index) pairs    splat_sort_run
+             bin + composite my tile rows only            splat_bin_run / splat_composite
+
+Per-tile lists are the global stable order restricted to the tile, so the stitched image is
+bit-identical to the single-GPU frame (tests/test_gpu_stages.py::test_band_rendering... on one GPU,
+tests/test_dist_cpu.py for the sharding logic under gloo).
+
+`stages` is the object that runs device work; the product always uses HipStages (below).  The
+gloo CPU tests inject a checker-backed stand-in to exercise THIS file's slicing / gathering /
+banding logic without a GPU — that stand-in lives under tests/, never here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CompositeCfg, check
+
+TILE = 16
+REC_FLOATS = 8
+
+
+def shard_size(n, world):
+    return -(-n // world)
+
+
+def slice_range(n, rank, world):
+    """Contiguous index range projected by `rank`: global index = rank*per + local."""
+    per = shard_size(n, world)
+    first = min(rank * per, n)
+    return first, min(per, n - first)
+
+
+def band_rows(nty, rank, world):
+    """Consecutive tile rows [r0, r1) composited by `rank`."""
+    return nty * rank // world, nty * (rank + 1) // world
+
+
+class HipStages:
+    """Device work of one rank through the C ABI.  Tensors are torch CUDA tensors; the splat ctx
+    is created on torch's current stream so that RCCL's stream dependencies order the exchange."""
+
+    def __init__(self, torch, device_ordinal, n_total_padded, width, height, tile=TILE, mode=_lib.MODE_FRONT_TO_BACK,
+                 early_out=True):
+        self.torch = torch
+        self.lib = _lib.load()
+        self.ordinal = device_ordinal
+        p = C.c_void_p()
+        stream = torch.cuda.current_stream().cuda_stream
+        check(self.lib.splat_ctx_create_on_stream(device_ordinal, C.c_void_p(stream), C.byref(p)))
+        self.ctx = p
+        s = C.c_void_p()
+        check(self.lib.splat_sort_create(self.ctx, n_total_padded, C.byref(s)), self.ctx)
+        self.sorter = s
+        b = C.c_void_p()
+        check(self.lib.splat_bin_create(self.ctx, tile, C.byref(b)), self.ctx)
+        self.binner = b
+        self.width, self.height, self.tile = width, height, tile
+        self.mode, self.early_out = mode, early_out
+        self.kept = 0
+        self.pairs = 0
+
+    def new_records(self, count, fill_nan=False):
+        t = self.torch.empty((count, REC_FLOATS), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
+        if fill_nan:
+            t.fill_(float("nan"))
+        return t
+
+    def new_image(self):
+        return self.torch.zeros((self.height, self.width, 4), dtype=self.torch.uint8, device=f"cuda:{self.ordinal}")
+
+    def project_slice(self, uniforms, props_ptr, first, count, out_records):
+        u = np.ascontiguousarray(uniforms, np.float32)
+        check(self.lib.splat_project_slice(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
+                                           out_records.data_ptr()), self.ctx)
+
+    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image):
+        lib, ctx = self.lib, self.ctx
+        kept = C.c_uint32()
+        check(lib.splat_band_keys(ctx, self.sorter, records.data_ptr(), n_records, self.width, self.height, self.tile,
+                                  row0, row1, C.byref(kept)), ctx)
+        self.kept = kept.value
+        check(lib.splat_sort_run(self.sorter, kept.value, 0, 32), ctx)
+        check(lib.splat_bin_run(self.binner, records.data_ptr(), n_records, lib.splat_sort_sorted_payload(self.sorter),
+                                kept.value, self.width, self.height, row0, row1), ctx)
+        counts, offsets, indices = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.splat_bin_counts(self.binner, C.byref(counts)), ctx)
+        check(lib.splat_bin_offsets(self.binner, C.byref(offsets)), ctx)
+        check(lib.splat_bin_indices(self.binner, C.byref(indices)), ctx)
+        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1)
+        check(lib.splat_composite(ctx, C.byref(cfg), props_ptr + 16, 2, normals_ptr, 1, records.data_ptr(), indices, counts,
+                                  offsets, self.width, self.height, out_image.data_ptr(), None, None), ctx)
+
+    def destroy(self):
+        self.lib.splat_bin_destroy(self.binner)
+        self.lib.splat_sort_destroy(self.sorter)
+        self.lib.splat_ctx_destroy(self.ctx)
+
+
+class BandRenderer:
+    """One rank of a multi-GPU frame.  `all_gather(out, shard)` is
+    torch.distributed.all_gather_into_tensor (RCCL on GPUs; gloo in the CPU tests)."""
+
+    def __init__(self, stages, n, width, height, rank, world, all_gather, tile=TILE):
+        self.stages, self.n, self.rank, self.world = stages, n, rank, world
+        self.width, self.height, self.tile = width, height, tile
+        self.per = shard_size(n, world)
+        self.first, self.count = slice_range(n, rank, world)
+        self.nty = -(-height // tile)
+        self.row0, self.row1 = band_rows(self.nty, rank, world)
+        self.all_gather = all_gather
+        # shard padding (indices >= n) is NaN-bounded once: NaN bins nowhere and never changes
+        self.shard = stages.new_records(self.per, fill_nan=True)
+        self.gathered = stages.new_records(self.per * world) if world > 1 else self.shard
+        self.image = stages.new_image()
+
+    def render(self, uniforms, props_ptr, normals_ptr):
+        st = self.stages
+        st.project_slice(uniforms, props_ptr, self.first, self.count, self.shard)
+        if self.world > 1:
+            self.all_gather(self.gathered, self.shard)
+        st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image)
+        return self.image
+
+    def pixel_rows(self):
+        return self.row0 * self.tile, min(self.row1 * self.tile, self.height)

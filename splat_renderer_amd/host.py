@@ -335,7 +335,9 @@ class GPUTileBinner:
         return self._get(self.device.lib.splat_bin_offsets, self._tiles * 4)
 
     def getTileIndicesBuffer(self):  # :347-352
-        return self._get(self.device.lib.splat_bin_indices, max(self.getTotalIndices(), 1) * 4)
+        buf = self._get(self.device.lib.splat_bin_indices, 4)  # raises "not initialized" first
+        buf.size = max(self.getTotalIndices(), 1) * 4  # "at least 4 bytes" (:288)
+        return buf
 
     def getTileCountsBuffer(self):  # :354-359
         return self._get(self.device.lib.splat_bin_counts, self._tiles * 4)
