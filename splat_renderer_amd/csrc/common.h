@@ -64,7 +64,7 @@ static inline uint64_t div_up64(uint64_t a, uint64_t b) { return (a + b - 1) / b
 int scan_exclusive_u32(splat_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);
 // radix_sort.hip: sorts n pairs from (k0,p0) using (k1,p1) as the ping-pong partner; returns in
 // *result_in_primary whether the result ended in (k0,p0). hist is a workspace of
-// 256 * div_up(n, RADIX_PART) u32.
+// 256 * div_up(n, RADIX_PART) + 256 u32.
 constexpr uint32_t RADIX_PART = 4096; // keys per workgroup partition
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1,
                      uint32_t *hist, uint32_t n, uint32_t bit_begin, uint32_t bit_end,

@@ -6,12 +6,16 @@
 //   - one 256-thread workgroup per 16x16 tile; wave w owns the 8x8 pixel quadrant w (one pixel per
 //     lane, so the 64-wide ballot/all of a wave is exactly "this quadrant")
 //   - the tile's list is consumed in batches of 256 entries: thread t gathers entry t ONCE
-//     (index, 32 B ProjectedSplat, colour vec4, normal vec4 — the reference's own layouts),
-//     pre-computes centre / exp2 scale / lit colour and parks 48 B in LDS
-//   - each wave tests the batch against its quadrant rectangle 64 entries per instruction and
-//     walks only the survivors (ballot mask, s_ff1), reading them back as LDS broadcasts
-//   - a pixel stops at alpha >= 0.99 exactly as :187-190; a wave whose 64 pixels have all
-//     stopped skips evaluation, and the workgroup leaves when all four waves have
+//     (index, 32 B ProjectedSplat, colour vec4, normal vec4 — the reference's own layouts) and
+//     does every per-entry computation there: centre, exp2 scale, lit colour, and for each of the
+//     four quadrants the exact 64-bit mask of pixels inside the entry's box (the reference's four
+//     float comparisons per pixel per entry become one mask per entry per quadrant)
+//   - each wave reads the 64 masks of a chunk with one LDS read, ballots the non-empty ones and
+//     walks only those (s_ff1); an entry whose covered pixels have all saturated is skipped on
+//     the scalar unit; the survivors' 32 B of parameters come back as LDS broadcasts
+//   - the set of pixels still accumulating is a wave-uniform 64-bit mask: a pixel leaves it at
+//     alpha >= 0.99 exactly as :187-190, a wave with none left stops, the workgroup leaves when
+//     all four waves have
 //
 // Roofline: HBM in the SURVEY §8d model — 68 B per consumed list entry (4 idx + 32 projected +
 // 16 colour + 16 normal) + 4 B per pixel written.  The inner loop is VALU/LDS work, so the
@@ -39,11 +43,34 @@ __device__ __forceinline__ uint32_t unorm8(float v) {
     return (uint32_t)(v * 255.0f + 0.5f);
 }
 
+// 64-bit lane mask of one 8x8 quadrant from its 8-bit column mask xb and row mask yb: lane
+// ly*8+lx is set iff bit lx of xb and bit ly of yb are.  (y & 15) * 0x00204081 drops bit i of y at
+// bit 8i (the four shifted copies do not overlap), & 0x01010101 keeps those, * xb copies xb into
+// every selected byte.
+__device__ __forceinline__ uint2 quadrant_mask(uint32_t xb, uint32_t yb) {
+    const uint32_t lo = (((yb & 15u) * 0x00204081u) & 0x01010101u) * xb;
+    const uint32_t hi = (((yb >> 4) * 0x00204081u) & 0x01010101u) * xb;
+    return make_uint2(lo, hi);
+}
+
+// Pixel columns j in [0,16) of a tile whose centres c0 + j lie inside [lo, hi]
+// (ComputeShaderRenderer.ts:118-121 keeps a pixel iff !(p < min || p > max)).  c0 = tile origin +
+// 0.5 >= 0.5.  For a result in [0,16) the subtraction is exact (lo >= c0 > 0 and the difference is a
+// multiple of ulp(lo) no larger than lo), outside that range only its sign / being >= 16 matters
+// and rounding is monotone (x - y == 0 only when x == y), so the mask is exactly the set the
+// reference's comparisons select.
+__device__ __forceinline__ uint32_t span_mask16(float lo, float hi, float c0) {
+    const float a = fmaxf(ceilf(lo - c0), 0.0f), b = fminf(floorf(hi - c0), 15.0f);
+    if (!(a <= b)) return 0u; // also NaN
+    const uint32_t ia = (uint32_t)a, ib = (uint32_t)b;
+    return ((2u << ib) - 1u) & ~((1u << ia) - 1u);
+}
+
 template <int MODE, bool EARLY_OUT>
 __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
-    __shared__ float4 s_bounds[CBATCH]; // min.x, min.y, max.x, max.y   (+inf/-inf = never hit)
-    __shared__ float4 s_geo[CBATCH];    // centre.x, centre.y, exp2 scale, unused
-    __shared__ float4 s_col[CBATCH];    // lit colour rgb, unused
+    __shared__ float4 s_geo[CBATCH];     // centre.x, centre.y, exp2 scale, unused
+    __shared__ float4 s_col[CBATCH];     // lit colour rgb, unused
+    __shared__ uint2 s_mask[4][CBATCH];  // per quadrant: which of its 64 pixels the entry's box covers
     __shared__ uint32_t s_wave_done[4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -51,17 +78,16 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
     const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
 
-    const uint32_t qx0 = tx * CT + (w & 1) * 8, qy0 = ty * CT + (w >> 1) * 8;
-    const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const uint32_t px = tx * CT + (w & 1) * 8 + (lane & 7), py = ty * CT + (w >> 1) * 8 + (lane >> 3);
     const bool pixel_ok = px < p.width && py < p.height;
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f; // :169
-    // quadrant rectangle of pixel centres, for the per-wave cull
-    const float X0 = (float)qx0 + 0.5f, X1 = (float)qx0 + 7.5f, Y0 = (float)qy0 + 0.5f, Y1 = (float)qy0 + 7.5f;
+    const float tile_cx = (float)(tx * CT) + 0.5f, tile_cy = (float)(ty * CT) + 0.5f;
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     float acc = (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) ? 0.0f : 1.0f; // alpha (literal) or transmittance T
-    bool done = !pixel_ok;
-    bool wave_done = false;
+    // wave-uniform mask of the pixels still accumulating; a pixel leaves it when its alpha reaches
+    // 0.99 (:187-190) and pixels outside the image never enter it
+    unsigned long long live = __ballot(pixel_ok);
     if (tid < 4) s_wave_done[tid] = 0;
 
     const float inv_sqrt3 = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
@@ -72,11 +98,11 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
         if (EARLY_OUT) {
             if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
         }
-        // ---- stage: one entry per thread ---------------------------------------------------------
+        // ---- stage: one entry per thread, everything per-entry is computed here, once per tile ----
         {
             const uint32_t e = base + tid;
-            float4 bnd = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
             float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), col = geo;
+            uint32_t xm = 0, ym = 0;
             if (e < count) {
                 const uint32_t s = p.indices[off + e];
                 const float4 b = p.projected[(size_t)s * 2];
@@ -89,57 +115,60 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     col = make_float4(c.x * kd, c.y * kd, c.z * kd, 0.0f);
                     // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(dist^2 * scale)
                     geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), 0.0f); // :124
-                    bnd = b;
+                    xm = span_mask16(b.x, b.z, tile_cx);
+                    ym = span_mask16(b.y, b.w, tile_cy);
                 }
             }
-            s_bounds[tid] = bnd;
             s_geo[tid] = geo;
             s_col[tid] = col;
+            s_mask[0][tid] = quadrant_mask(xm & 0xffu, ym & 0xffu);
+            s_mask[1][tid] = quadrant_mask(xm >> 8, ym & 0xffu);
+            s_mask[2][tid] = quadrant_mask(xm & 0xffu, ym >> 8);
+            s_mask[3][tid] = quadrant_mask(xm >> 8, ym >> 8);
         }
         staged = (count - base < CBATCH) ? count : base + CBATCH;
         __syncthreads();
-        if (wave_done) continue;
-        // ---- consume: 4 chunks of 64 entries, each culled against this wave's quadrant ------------
+        if (live == 0) { // nothing left to accumulate (or a quadrant wholly outside the image)
+            if (EARLY_OUT && lane == 0) s_wave_done[w] = 1;
+            continue;
+        }
+        // ---- consume: 4 chunks of 64 entries; lane j looks at entry c0+j's mask for this quadrant ---
         const uint32_t batch_n = (count - base < CBATCH) ? (count - base) : CBATCH;
-        for (uint32_t c0 = 0; c0 < batch_n; c0 += 64) {
-            const float4 bb = s_bounds[c0 + lane];
-            const bool hit = (bb.x <= X1) && (bb.z >= X0) && (bb.y <= Y1) && (bb.w >= Y0);
-            unsigned long long m = __ballot(hit);
-            while (m) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t e = c0 + j; // wave-uniform -> the three reads below are LDS broadcasts
-                const float4 B = s_bounds[e];
-                const float4 G = s_geo[e];
-                const float4 C = s_col[e];
-                const bool inside = !(pxf < B.x || pxf > B.z || pyf < B.y || pyf > B.w); // :118-121
+        for (uint32_t c0 = 0; c0 < batch_n && live != 0; c0 += 64) {
+            const uint2 mm = s_mask[w][c0 + lane];
+            unsigned long long hits = __ballot((mm.x | mm.y) != 0u);
+            while (hits) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(hits);
+                hits &= hits - 1;
+                // (readlane returns int: go through uint32_t or the low word sign-extends into the high one)
+                const unsigned long long cover = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j) << 32) |
+                                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j);
+                const unsigned long long active = cover & live;
+                if (active == 0) continue; // every pixel it covers has already saturated
+                const float4 G = s_geo[c0 + j]; // wave-uniform address: LDS broadcast
+                const float4 C = s_col[c0 + j];
                 const float dx = pxf - G.x, dy = pyf - G.y;
                 float g = __builtin_amdgcn_exp2f((dx * dx + dy * dy) * G.z);
-                g = (inside && !done) ? g : 0.0f;
+                g = __builtin_amdgcn_inverse_ballot_w64(active) ? g : 0.0f;
                 if (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) { // :183-185 as written
                     const float om = 1.0f - g;
                     cr = cr * om + C.x * g;
                     cg = cg * om + C.y * g;
                     cb = cb * om + C.z * g;
                     acc = acc * om + g;
-                    if (EARLY_OUT) done = done || (acc >= 0.99f); // :187-190
+                    if (EARLY_OUT) live &= ~__ballot(acc >= 0.99f); // :187-190
                 } else { // SURVEY §8a contract 3: nearest on top
                     const float wgt = acc * g;
                     cr += C.x * wgt;
                     cg += C.y * wgt;
                     cb += C.z * wgt;
                     acc = acc * (1.0f - g);
-                    if (EARLY_OUT) done = done || ((1.0f - acc) >= 0.99f);
+                    if (EARLY_OUT) live &= ~__ballot((1.0f - acc) >= 0.99f);
                 }
-            }
-            if (EARLY_OUT) {
-                if (__all(done)) {
-                    wave_done = true;
-                    if (lane == 0) s_wave_done[w] = 1;
-                    break;
-                }
+                if (EARLY_OUT && live == 0) break;
             }
         }
+        if (EARLY_OUT && live == 0 && lane == 0) s_wave_done[w] = 1;
     }
 
     if (p.consumed && tid == 0 && staged) atomicAdd(p.consumed, (unsigned long long)staged);
