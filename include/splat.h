@@ -123,6 +123,12 @@ int splat_sort_run(splat_sorter *s, uint32_t n, uint32_t bit_begin, uint32_t bit
 /* getSortedIndicesBuffer(): payload in sorted order (valid after splat_sort_run). */
 void *splat_sort_sorted_payload(splat_sorter *s);
 void *splat_sort_sorted_keys(splat_sorter *s);
+/* Sort algorithm of this sorter: 0 = per-pass histogram + row scan + scatter (default, fastest on
+ * MI355X), 1 = onesweep with decoupled look-back (the reference's structure), -1 = library default. */
+int splat_sort_set_mode(splat_sorter *s, int mode);
+/* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
+ * (the result is then invalid).  Synchronises. */
+int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag);
 
 /* ---- PrefixSumScanner.scan  (src/PrefixSumScanner.ts:74-87, prefix-sum.wgsl:28-96) -------- */
 /* Exclusive scan of n u32 (out[0] = 0); in may equal out.  total_dptr (optional) receives the

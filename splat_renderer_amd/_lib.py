@@ -60,6 +60,8 @@ SIGNATURES = {
     "splat_sort_run": (_i, [_vp, _u32, _u32, _u32]),
     "splat_sort_sorted_payload": (_vp, [_vp]),
     "splat_sort_sorted_keys": (_vp, [_vp]),
+    "splat_sort_set_mode": (_i, [_vp, _i]),
+    "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),
     "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_bin_create": (_i, [_vp, _u32, _pvp]),
     "splat_bin_destroy": (None, [_vp]),

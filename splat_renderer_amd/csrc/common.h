@@ -68,7 +68,9 @@ int scan_exclusive_u32(splat_ctx *ctx, const uint32_t *in, uint32_t *out, uint32
 constexpr uint32_t RADIX_PART = 4096; // keys per workgroup partition
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1,
                      uint32_t *hist, uint32_t n, uint32_t bit_begin, uint32_t bit_end,
-                     bool *result_in_primary);
+                     bool *result_in_primary, int mode = -1);
+
+int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);
 
 struct splat_sorter {
     splat_ctx *ctx = nullptr;
@@ -77,6 +79,7 @@ struct splat_sorter {
     uint32_t *hist = nullptr;
     bool result_in_primary = true;
     bool ran = false;
+    int mode = -1; // -1 = library default, 0 = upsweep/rowscan/downsweep, 1 = onesweep (chained scan)
 };
 
 // grows the sorter's buffers (contents are NOT preserved)

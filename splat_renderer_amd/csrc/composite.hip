@@ -66,10 +66,17 @@ __device__ __forceinline__ uint32_t span_mask16(float lo, float hi, float c0) {
     return ((2u << ib) - 1u) & ~((1u << ia) - 1u);
 }
 
+// Pins a wave-uniform 64-bit value into scalar registers (the compiler's divergence analysis gives
+// up on loop-carried masks and would otherwise keep them, and every test on them, in VGPRs).
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
 template <int MODE, bool EARLY_OUT>
 __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
-    __shared__ float4 s_geo[CBATCH];     // centre.x, centre.y, exp2 scale, unused
-    __shared__ float4 s_col[CBATCH];     // lit colour rgb, unused
+    __shared__ float4 s_geo[CBATCH];     // centre.x, centre.y, exp2 scale, lit blue   (one ds_read_b128)
+    __shared__ float2 s_col[CBATCH];     // lit red, lit green                         (one ds_read_b64)
     __shared__ uint2 s_mask[4][CBATCH];  // per quadrant: which of its 64 pixels the entry's box covers
     __shared__ uint32_t s_wave_done[4];
 
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     float acc = (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) ? 0.0f : 1.0f; // alpha (literal) or transmittance T
     // wave-uniform mask of the pixels still accumulating; a pixel leaves it when its alpha reaches
     // 0.99 (:187-190) and pixels outside the image never enter it
-    unsigned long long live = __ballot(pixel_ok);
+    unsigned long long live = uniform64(__ballot(pixel_ok));
     if (tid < 4) s_wave_done[tid] = 0;
 
     const float inv_sqrt3 = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
@@ -96,12 +103,15 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     for (uint32_t base = 0; base < count; base += CBATCH) {
         __syncthreads(); // previous batch fully consumed (and s_wave_done visible)
         if (EARLY_OUT) {
-            if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
+            // (readfirstlane: an LDS value is "divergent" to the compiler, which would then treat
+            // this whole loop, and every mask carried through it, as per-lane)
+            if (__builtin_amdgcn_readfirstlane((int)(s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]))) break;
         }
         // ---- stage: one entry per thread, everything per-entry is computed here, once per tile ----
         {
             const uint32_t e = base + tid;
-            float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), col = geo;
+            float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float2 col = make_float2(0.0f, 0.0f);
             uint32_t xm = 0, ym = 0;
             if (e < count) {
                 const uint32_t s = p.indices[off + e];
@@ -112,9 +122,9 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     const float4 nrm = p.normals[(size_t)s * p.normal_stride];
                     const float ndl = (nrm.x * inv_sqrt3 + nrm.y * inv_sqrt3) + nrm.z * inv_sqrt3;
                     const float kd = 0.85f + 0.15f * fmaxf(ndl, 0.0f); // :144-145
-                    col = make_float4(c.x * kd, c.y * kd, c.z * kd, 0.0f);
+                    col = make_float2(c.x * kd, c.y * kd);
                     // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(dist^2 * scale)
-                    geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), 0.0f); // :124
+                    geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), c.z * kd); // :124
                     xm = span_mask16(b.x, b.z, tile_cx);
                     ym = span_mask16(b.y, b.w, tile_cy);
                 }
@@ -128,25 +138,26 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
         }
         staged = (count - base < CBATCH) ? count : base + CBATCH;
         __syncthreads();
-        if (live == 0) { // nothing left to accumulate (or a quadrant wholly outside the image)
+        if (uniform64(live) == 0) { // nothing left to accumulate (or a quadrant wholly outside the image)
             if (EARLY_OUT && lane == 0) s_wave_done[w] = 1;
             continue;
         }
         // ---- consume: 4 chunks of 64 entries; lane j looks at entry c0+j's mask for this quadrant ---
         const uint32_t batch_n = (count - base < CBATCH) ? (count - base) : CBATCH;
-        for (uint32_t c0 = 0; c0 < batch_n && live != 0; c0 += 64) {
+        for (uint32_t c0 = 0; c0 < batch_n && uniform64(live) != 0; c0 += 64) {
             const uint2 mm = s_mask[w][c0 + lane];
-            unsigned long long hits = __ballot((mm.x | mm.y) != 0u);
+            unsigned long long hits = uniform64(__ballot((mm.x | mm.y) != 0u));
             while (hits) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(hits);
                 hits &= hits - 1;
                 // (readlane returns int: go through uint32_t or the low word sign-extends into the high one)
                 const unsigned long long cover = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j) << 32) |
                                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j);
-                const unsigned long long active = cover & live;
+                const unsigned long long lv = uniform64(live); // pinned at the use: see uniform64()
+                const unsigned long long active = cover & lv;
                 if (active == 0) continue; // every pixel it covers has already saturated
                 const float4 G = s_geo[c0 + j]; // wave-uniform address: LDS broadcast
-                const float4 C = s_col[c0 + j];
+                const float2 C = s_col[c0 + j];
                 const float dx = pxf - G.x, dy = pyf - G.y;
                 float g = __builtin_amdgcn_exp2f((dx * dx + dy * dy) * G.z);
                 g = __builtin_amdgcn_inverse_ballot_w64(active) ? g : 0.0f;
@@ -154,21 +165,21 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     const float om = 1.0f - g;
                     cr = cr * om + C.x * g;
                     cg = cg * om + C.y * g;
-                    cb = cb * om + C.z * g;
+                    cb = cb * om + G.w * g;
                     acc = acc * om + g;
-                    if (EARLY_OUT) live &= ~__ballot(acc >= 0.99f); // :187-190
+                    if (EARLY_OUT) live = lv & ~__ballot(acc >= 0.99f); // :187-190
                 } else { // SURVEY §8a contract 3: nearest on top
                     const float wgt = acc * g;
                     cr += C.x * wgt;
                     cg += C.y * wgt;
-                    cb += C.z * wgt;
+                    cb += G.w * wgt;
                     acc = acc * (1.0f - g);
-                    if (EARLY_OUT) live &= ~__ballot((1.0f - acc) >= 0.99f);
+                    if (EARLY_OUT) live = lv & ~__ballot((1.0f - acc) >= 0.99f);
                 }
-                if (EARLY_OUT && live == 0) break;
+                if (EARLY_OUT && uniform64(live) == 0) break;
             }
         }
-        if (EARLY_OUT && live == 0 && lane == 0) s_wave_done[w] = 1;
+        if (EARLY_OUT && uniform64(live) == 0 && lane == 0) s_wave_done[w] = 1;
     }
 
     if (p.consumed && tid == 0 && staged) atomicAdd(p.consumed, (unsigned long long)staged);

@@ -52,24 +52,43 @@ static uint32_t choose_items(uint32_t n) {
 // ---------------------------------------------------------------------------------------------
 // upsweep: hist[d * num_parts + part] = number of keys of this partition whose digit is d
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hist_add4(uint32_t *h, uint4 v, uint32_t shift, uint32_t mask) {
+    const uint32_t a = (v.x >> shift) & mask, b = (v.y >> shift) & mask, c = (v.z >> shift) & mask, d = (v.w >> shift) & mask;
+    // depth keys have a near-constant top byte: 64 lanes x 4 keys on one LDS counter serialise, so
+    // four equal digits become one atomic
+    if (a == b && b == c && c == d) {
+        atomicAdd(&h[a], 4u);
+    } else {
+        atomicAdd(&h[a], 1u);
+        atomicAdd(&h[b], 1u);
+        atomicAdd(&h[c], 1u);
+        atomicAdd(&h[d], 1u);
+    }
+}
+
 __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__restrict__ keys, uint32_t n,
                                                               uint32_t shift, uint32_t mask, uint32_t num_parts,
                                                               uint32_t part_keys, uint32_t *__restrict__ hist) {
     __shared__ uint32_t lh[RS_WAVES][256]; // one private histogram per wave: fewer same-bank collisions
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
-    __syncthreads();
     const uint32_t base = blockIdx.x * part_keys; // multiple of 256 keys = 1 KiB: uint4 loads stay aligned
     if (base + part_keys <= n) {
         const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
-        for (uint32_t j = tid; j < part_keys / 4; j += RS_THREADS) {
-            uint4 v = k4[j];
-            atomicAdd(&lh[w][(v.x >> shift) & mask], 1u);
-            atomicAdd(&lh[w][(v.y >> shift) & mask], 1u);
-            atomicAdd(&lh[w][(v.z >> shift) & mask], 1u);
-            atomicAdd(&lh[w][(v.w >> shift) & mask], 1u);
+        const uint32_t vecs = part_keys / 4; // multiple of 64
+        if (vecs == 4 * RS_THREADS) {        // the default 4096-key partition: all four loads in flight at once
+            const uint4 v0 = k4[tid], v1 = k4[tid + RS_THREADS], v2 = k4[tid + 2 * RS_THREADS], v3 = k4[tid + 3 * RS_THREADS];
+            __syncthreads();
+            hist_add4(lh[w], v0, shift, mask);
+            hist_add4(lh[w], v1, shift, mask);
+            hist_add4(lh[w], v2, shift, mask);
+            hist_add4(lh[w], v3, shift, mask);
+        } else {
+            __syncthreads();
+            for (uint32_t j = tid; j < vecs; j += RS_THREADS) hist_add4(lh[w], k4[j], shift, mask);
         }
     } else {
+        __syncthreads();
         for (uint32_t i = base + tid; i < n; i += RS_THREADS) atomicAdd(&lh[w][(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -80,13 +99,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__
 // ---------------------------------------------------------------------------------------------
 // rowscan: block d turns row d of hist into its exclusive prefix over partitions; totals[d] = row sum
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t num_parts,
-                                                              uint32_t *__restrict__ totals) {
-    __shared__ uint32_t wsum[RS_WAVES];
+constexpr uint32_t ROWSCAN_THREADS = 1024;
+__global__ __launch_bounds__(ROWSCAN_THREADS) void k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t num_parts,
+                                                                   uint32_t *__restrict__ totals) {
+    __shared__ uint32_t wsum[ROWSCAN_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t *row = hist + (size_t)blockIdx.x * num_parts;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_parts; base += RS_THREADS) {
+    for (uint32_t base = 0; base < num_parts; base += ROWSCAN_THREADS) {
         const uint32_t i = base + tid;
         const uint32_t v = (i < num_parts) ? row[i] : 0u;
         uint32_t incl = v;
@@ -97,11 +117,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_rowscan(uint32_t *__restri
         }
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
-        const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
-        __syncthreads();
-        const uint32_t wprefix = (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u);
+        // every wave scans the 16 wave totals itself (lanes 0..15)
+        uint32_t ws = (lane < ROWSCAN_THREADS / 64) ? wsum[lane] : 0u;
+        uint32_t wincl = ws;
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) {
+            uint32_t t = __shfl_up(wincl, s);
+            if ((int)lane >= s) wincl += t;
+        }
+        const uint32_t wprefix = __shfl(wincl - ws, w);
+        const uint32_t total = __shfl(wincl, ROWSCAN_THREADS / 64 - 1);
+        __syncthreads(); // wsum is rewritten by the next round
         if (i < num_parts) row[i] = carry + wprefix + incl - v;
-        carry += s0 + s1 + s2 + s3;
+        carry += total;
     }
     if (tid == 0) totals[blockIdx.x] = carry;
 }
@@ -122,22 +150,66 @@ struct DownsweepShared {
     uint32_t wave_gsums[RS_WAVES];
 };
 
-template <uint32_t ITEMS, bool FULL>
-__device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__restrict__ s_kp,
+// ---- decoupled look-back (onesweep mode) ---------------------------------------------------------
+// status[part*256 + d] = flag (2 bits) | count (30 bits): AGGREGATE = this partition's count of digit
+// d, PREFIX = the count summed over partitions 0..part.  One 4-byte word carries flag and data, so
+// no fence is needed: it is written with one relaxed agent-scope store (global_store sc1, write-
+// through) and polled with relaxed agent-scope loads (sc1: bypass this CU's L1) — the guide's
+// "granule" hand-off.  Partition ids come from an atomic ticket, so every partition a workgroup
+// waits on belongs to a workgroup that is already running and publishes its AGGREGATE before it
+// waits on anything: the chain cannot deadlock whatever the dispatch order or residency.  The spin
+// is bounded; on timeout the error word is set and the sort result is garbage but the grid drains.
+constexpr uint32_t LB_AGGREGATE = 1u << 30, LB_PREFIX = 2u << 30, LB_VALUE = (1u << 30) - 1u;
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ uint32_t lookback(uint32_t *status, uint32_t part, uint32_t d, uint32_t dcount, uint32_t *err) {
+    uint32_t *mine = status + (size_t)part * 256 + d;
+    if (part == 0) {
+        __hip_atomic_store(mine, LB_PREFIX | dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    __hip_atomic_store(mine, LB_AGGREGATE | dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0, spins = 0;
+    uint32_t p = part - 1;
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(status + (size_t)p * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = v & ~LB_VALUE;
+        if (flag == LB_PREFIX) {
+            excl += v & LB_VALUE;
+            break;
+        }
+        if (flag == LB_AGGREGATE) {
+            excl += v & LB_VALUE;
+            --p; // partition 0 always ends the walk with a PREFIX
+            continue;
+        }
+        if (++spins > LB_SPIN_LIMIT) {
+            atomicOr(err, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(mine, LB_PREFIX | (excl + dcount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <uint32_t ITEMS, bool FULL, bool ONESWEEP>
+__device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__restrict__ s_kp, uint32_t part,
                                                const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ pay_out, uint32_t n,
                                                uint32_t shift, uint32_t mask, uint32_t num_parts,
                                                const uint32_t *__restrict__ scanned_hist,
-                                               const uint32_t *__restrict__ totals) {
+                                               const uint32_t *__restrict__ totals, uint32_t *status, uint32_t *err) {
     constexpr uint32_t PART_KEYS = ITEMS * RS_THREADS, WAVE_KEYS = ITEMS * 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t part = blockIdx.x;
     const uint32_t base = part * PART_KEYS;
     const uint32_t valid = FULL ? PART_KEYS : (n - base);
 
-    for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
-    const uint32_t row_prefix = scanned_hist[(size_t)tid * num_parts + part]; // digit tid in earlier partitions
-    const uint32_t digit_total = totals[tid];
+    if (!ONESWEEP) // (onesweep: zeroed by the caller before its ticket barrier)
+        for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+    // rowscan mode: digit tid in earlier partitions; onesweep mode: found by look-back below
+    uint32_t row_prefix = ONESWEEP ? 0u : scanned_hist[(size_t)tid * num_parts + part];
+    const uint32_t digit_total = totals[tid]; // global count of digit tid (this pass)
 
     // striped load: item i of lane l of wave w is element w*WAVE_KEYS + i*64 + l (position order =
     // (wave, item, lane), which is the order the ranking below preserves).  Padding lanes of the
@@ -152,7 +224,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
         key[i] = keys_in[base + q];
         pay[i] = pay_in[base + q];
     }
-    __syncthreads(); // wave_hist zeroed
+    if (!ONESWEEP) __syncthreads(); // wave_hist zeroed
 
     // ---- rank, phase A: per item, the mask of lanes of this wave holding the same digit: 8 ballots,
     // each folded in with one v_bitop3 per mask half (peers &= ~(ballot ^ mybit)).  The lowest lane
@@ -192,6 +264,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     sh.wave_hist[1][tid] = c0;
     sh.wave_hist[2][tid] = c0 + c1;
     sh.wave_hist[3][tid] = c0 + c1 + c2;
+    if (ONESWEEP) row_prefix = lookback(status, part, tid, dcount, err);
     // exclusive scan of dcount over the 256 digits and, in the same shuffles, of the global digit
     // totals (start of digit d in the output)
     uint32_t incl = dcount, gincl = digit_total;
@@ -262,9 +335,11 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radi
     __shared__ uint2 s_kp[ITEMS * RS_THREADS]; // (key, payload) reordered by digit
     // every partition but (possibly) the last is full: it takes the path with no per-key bounds checks
     if ((blockIdx.x + 1) * ITEMS * RS_THREADS <= n)
-        downsweep_body<ITEMS, true>(sh, s_kp, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts, scanned_hist, totals);
+        downsweep_body<ITEMS, true, false>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+                                           scanned_hist, totals, nullptr, nullptr);
     else
-        downsweep_body<ITEMS, false>(sh, s_kp, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts, scanned_hist, totals);
+        downsweep_body<ITEMS, false, false>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+                                            scanned_hist, totals, nullptr, nullptr);
 }
 
 template <uint32_t ITEMS>
@@ -274,19 +349,86 @@ static void launch_downsweep(splat_ctx *ctx, uint32_t parts, const uint32_t *ki,
                        parts, hist, totals);
 }
 
-int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
-                     uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
-    static bool env_read = false;
-    if (!env_read) {
-        env_read = true;
-        if (const char *e = getenv("SPLAT_RADIX_ITEMS")) {
-            uint32_t v = (uint32_t)atoi(e);
-            for (uint32_t c : kItemChoices)
-                if (c == v) g_force_items = v;
+// ---------------------------------------------------------------------------------------------
+// onesweep: one histogram kernel for all passes + one chained-scan scatter kernel per pass
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t OS_ITEMS = RS_ITEMS;                    // 4096 keys per partition
+constexpr uint32_t OS_HIST_THREADS = 512, OS_HIST_BLOCKS = 512;
+
+// ghist[pass*256 + d] += number of keys whose digit of pass `pass` is d.  Global digit totals do
+// not depend on the order of the keys, so all passes are counted from the unsorted input at once.
+__global__ __launch_bounds__(OS_HIST_THREADS) void k_radix_hist(const uint32_t *__restrict__ keys, uint32_t n,
+                                                                uint32_t bit_begin, uint32_t bit_end,
+                                                                uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t lh[4][256];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 1024; i += OS_HIST_THREADS) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t passes = (bit_end - bit_begin + 7) / 8;
+    const uint32_t n4 = n / 4;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+    for (uint32_t i = blockIdx.x * OS_HIST_THREADS + tid; i < n4; i += OS_HIST_BLOCKS * OS_HIST_THREADS) {
+        const uint4 v = k4[i];
+        for (uint32_t ps = 0; ps < passes; ++ps) {
+            const uint32_t shift = bit_begin + 8 * ps;
+            const uint32_t mask = (bit_end - shift < 8) ? ((1u << (bit_end - shift)) - 1u) : 255u;
+            const uint32_t a = (v.x >> shift) & mask, b = (v.y >> shift) & mask, c = (v.z >> shift) & mask,
+                           d = (v.w >> shift) & mask;
+            // depth keys have a near-constant top byte: four equal digits become one LDS atomic
+            if (a == b && b == c && c == d) {
+                atomicAdd(&lh[ps][a], 4u);
+            } else {
+                atomicAdd(&lh[ps][a], 1u);
+                atomicAdd(&lh[ps][b], 1u);
+                atomicAdd(&lh[ps][c], 1u);
+                atomicAdd(&lh[ps][d], 1u);
+            }
         }
     }
-    *result_in_primary = true;
-    if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
+    if (blockIdx.x == 0 && tid < (n & 3u)) { // tail keys
+        const uint32_t k = keys[n4 * 4 + tid];
+        for (uint32_t ps = 0; ps < passes; ++ps) {
+            const uint32_t shift = bit_begin + 8 * ps;
+            const uint32_t mask = (bit_end - shift < 8) ? ((1u << (bit_end - shift)) - 1u) : 255u;
+            atomicAdd(&lh[ps][(k >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < passes * 256; i += OS_HIST_THREADS) {
+        const uint32_t c = (&lh[0][0])[i];
+        if (c) atomicAdd(&ghist[i], c);
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(OS_ITEMS)) void k_radix_onesweep(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ pay_out, uint32_t n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist,
+    uint32_t *status, uint32_t *ticket, uint32_t *err) {
+    __shared__ DownsweepShared sh;
+    __shared__ uint2 s_kp[OS_ITEMS * RS_THREADS];
+    __shared__ uint32_t s_part;
+    if (threadIdx.x == 0) s_part = atomicAdd(ticket, 1u); // partition id = order of arrival
+    for (uint32_t i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t part = s_part;
+    if ((part + 1) * OS_ITEMS * RS_THREADS <= n)
+        downsweep_body<OS_ITEMS, true, true>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
+                                             status, err);
+    else
+        downsweep_body<OS_ITEMS, false, true>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
+                                              status, err);
+}
+
+// Default mode: 0 = upsweep/rowscan/downsweep.  1 = onesweep is kept selectable (per sorter with
+// splat_sort_set_mode, or SPLAT_RADIX_MODE=onesweep for everything) because it is the reference's own
+// structure, but measured on MI355X it loses: 5M keys x 4 passes 227 us vs 176 us, 11.3M pairs x 2
+// passes 224 us vs 187 us (tools/sort_bench.py).  With ~1000 workgroups starting together the
+// look-back walks long chains of AGGREGATEs at ~1 us per cross-XCD hop, which costs more per pass
+// (+23 us) than the upsweep + rowscan it removes (18 us).
+static int g_radix_mode = -1;
+
+static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
+                              uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
     const uint32_t items = g_force_items ? g_force_items : choose_items(n);
     const uint32_t part_keys = items * RS_THREADS;
     const uint32_t parts = div_up(n, part_keys); // <= div_up(n, RS_MIN_ITEMS*256): the hist workspace is sized for that
@@ -299,7 +441,7 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
                            hist);
         LAUNCH_CHECK(ctx, "k_radix_upsweep");
         uint32_t *totals = hist + (size_t)256 * parts;
-        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(RS_THREADS), 0, ctx->stream, hist, parts, totals);
+        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals);
         LAUNCH_CHECK(ctx, "k_radix_rowscan");
         switch (items) {
         case 4: launch_downsweep<4>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
@@ -318,6 +460,59 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
         primary = !primary;
     }
     *result_in_primary = primary;
+    return SPLAT_OK;
+}
+
+// workspace layout (u32 words) for onesweep: [0,1024) global histograms of up to 4 passes,
+// [1024,1028) tickets, [1028] error word, pad to 1280, then status[pass][part][256]
+static int radix_sort_onesweep(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *ws, uint32_t n,
+                               uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
+    const uint32_t passes = (bit_end - bit_begin + 7) / 8;
+    const uint32_t parts = div_up(n, OS_ITEMS * RS_THREADS);
+    uint32_t *ghist = ws, *tickets = ws + 1024, *err = ws + 1028, *status = ws + 1280;
+    HIP_TRY(ctx, hipMemsetAsync(ws, 0, ((size_t)1280 + (size_t)passes * parts * 256) * 4, ctx->stream));
+    hipLaunchKernelGGL(k_radix_hist, dim3(OS_HIST_BLOCKS), dim3(OS_HIST_THREADS), 0, ctx->stream, k0, n, bit_begin, bit_end, ghist);
+    LAUNCH_CHECK(ctx, "k_radix_hist");
+    uint32_t *ki = k0, *pi = p0, *ko = k1, *po = p1;
+    bool primary = true;
+    for (uint32_t ps = 0; ps < passes; ++ps) {
+        const uint32_t shift = bit_begin + 8 * ps;
+        const uint32_t bits = bit_end - shift < 8 ? bit_end - shift : 8;
+        const uint32_t mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(k_radix_onesweep, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pi, ko, po, n, shift, mask,
+                           ghist + ps * 256, status + (size_t)ps * parts * 256, tickets + ps, err);
+        LAUNCH_CHECK(ctx, "k_radix_onesweep");
+        uint32_t *t = ki; ki = ko; ko = t;
+        t = pi; pi = po; po = t;
+        primary = !primary;
+    }
+    *result_in_primary = primary;
+    return SPLAT_OK;
+}
+
+int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
+                     uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode) {
+    if (g_radix_mode < 0) {
+        g_radix_mode = 0;
+        if (const char *e = getenv("SPLAT_RADIX_MODE")) g_radix_mode = (e[0] == 'o' || e[0] == '1') ? 1 : 0;
+        if (const char *e = getenv("SPLAT_RADIX_ITEMS")) {
+            uint32_t v = (uint32_t)atoi(e);
+            for (uint32_t c : kItemChoices)
+                if (c == v) g_force_items = v;
+        }
+    }
+    *result_in_primary = true;
+    if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
+    if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
+    if (mode < 0) mode = g_radix_mode;
+    if (mode == 1) return radix_sort_onesweep(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
+    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
+}
+
+// the look-back's timeout word (workspace word 1028): non-zero after a sort = a chained scan gave up
+int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value) {
+    HIP_TRY(ctx, hipMemcpyAsync(value, hist + 1028, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SPLAT_OK;
 }
 
@@ -342,13 +537,20 @@ int sorter_reserve(splat_sorter *s, uint32_t capacity) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     sorter_free(s);
     size_t bytes = (size_t)padded * 4;
-    // rows for the smallest partition size + the 256 row totals
-    size_t hist_bytes = ((size_t)256 * div_up((uint32_t)padded, RS_MIN_ITEMS * RS_THREADS) + 256) * 4;
+    // rowscan mode: rows for the smallest partition size + the 256 row totals; onesweep mode:
+    // 1280 header words + status words of 4 passes
+    size_t hist_a = ((size_t)256 * div_up((uint32_t)padded, RS_MIN_ITEMS * RS_THREADS) + 256) * 4;
+    size_t hist_b = ((size_t)1280 + (size_t)4 * div_up((uint32_t)padded, OS_ITEMS * RS_THREADS) * 256) * 4;
+    size_t hist_bytes = hist_a > hist_b ? hist_a : hist_b;
     if (hipMalloc((void **)&s->keys, bytes) != hipSuccess || hipMalloc((void **)&s->keys_b, bytes) != hipSuccess ||
         hipMalloc((void **)&s->payload, bytes) != hipSuccess || hipMalloc((void **)&s->payload_b, bytes) != hipSuccess ||
         hipMalloc((void **)&s->hist, hist_bytes) != hipSuccess) {
         sorter_free(s);
         return ctx_fail(ctx, SPLAT_ERR_OOM, "sorter hipMalloc");
+    }
+    if (hipMemset(s->hist, 0, hist_bytes) != hipSuccess) {
+        sorter_free(s);
+        return ctx_fail(ctx, SPLAT_ERR_HIP, "sorter workspace hipMemset");
     }
     s->capacity = (uint32_t)padded;
     s->ran = false;
@@ -391,7 +593,7 @@ int splat_sort_run(splat_sorter *s, uint32_t n, uint32_t bit_begin, uint32_t bit
     if (n > s->capacity) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_sort_run: n exceeds the sorter's capacity");
     stage_begin(ctx, SPLAT_STAGE_SORT);
     int rc = radix_sort_pairs(ctx, s->keys, s->payload, s->keys_b, s->payload_b, s->hist, n, bit_begin, bit_end,
-                              &s->result_in_primary);
+                              &s->result_in_primary, s->mode);
     stage_end(ctx, SPLAT_STAGE_SORT);
     if (rc == SPLAT_OK) s->ran = true;
     return rc;
@@ -400,6 +602,21 @@ int splat_sort_run(splat_sorter *s, uint32_t n, uint32_t bit_begin, uint32_t bit
 void *splat_sort_sorted_payload(splat_sorter *s) {
     if (!s) return nullptr;
     return s->result_in_primary ? s->payload : s->payload_b;
+}
+
+int splat_sort_set_mode(splat_sorter *s, int mode) {
+    if (!s) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "sorter is NULL");
+    if (mode < -1 || mode > 1) return ctx_fail(s->ctx, SPLAT_ERR_INVALID, "sort mode must be -1 (default), 0 (rowscan) or 1 (onesweep)");
+    s->mode = mode;
+    return SPLAT_OK;
+}
+
+int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag) {
+    if (!s || !flag) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "sorter/flag is NULL");
+    *flag = 0;
+    const int mode = s->mode < 0 ? g_radix_mode : s->mode;
+    if (mode != 1 || !s->ran) return SPLAT_OK; // only the onesweep mode has a look-back (and the word)
+    return radix_sort_error_word(s->ctx, s->hist, flag);
 }
 
 void *splat_sort_sorted_keys(splat_sorter *s) {

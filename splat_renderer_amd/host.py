@@ -268,6 +268,15 @@ class RadixSorter:
         n = self.numSplats if numKeys is None else numKeys
         check(d.lib.splat_sort_run(self._s, n, bitBegin, bitEnd), d.ctx)
 
+    def setMode(self, mode):
+        """0 = histogram + row scan + scatter per pass (default), 1 = onesweep / decoupled look-back."""
+        check(self.device.lib.splat_sort_set_mode(self._s, mode), self.device.ctx)
+
+    def lookbackTimeouts(self):
+        f = C.c_uint32()
+        check(self.device.lib.splat_sort_lookback_timeouts(self._s, C.byref(f)), self.device.ctx)
+        return int(f.value)
+
     def getSortedIndicesBuffer(self):  # :269-271
         return Buffer(self.device, self.device.lib.splat_sort_sorted_payload(self._s), self.paddedSize * 4, owned=False)
 

@@ -55,7 +55,8 @@ def test_project_and_keys_bit_exact(device, n, w, h, seed):
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 1023, 4095, 4096, 4097, 8191, 12289, 100000, 1000003])
 @pytest.mark.parametrize("kind", ["random", "few_values", "all_equal", "sorted_desc"])
-def test_radix_sort_stable(device, n, kind):
+@pytest.mark.parametrize("mode", [0, 1], ids=["rowscan", "onesweep"])
+def test_radix_sort_stable(device, n, kind, mode):
     rng = np.random.default_rng(n * 7 + len(kind))
     if kind == "random":
         keys = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
@@ -68,10 +69,12 @@ def test_radix_sort_stable(device, n, kind):
         keys = np.sort(keys)[::-1].copy()
     payload = np.arange(n, dtype=np.uint32)
     s = sr.RadixSorter(device, max(n, 1))
+    s.setMode(mode)
     if n:
         s.getKeysBuffer().write(keys)
         s.getPayloadBuffer().write(payload)
     s.sort(n)
+    assert s.lookbackTimeouts() == 0
     order = np.argsort(keys, kind="stable").astype(np.uint32)
     assert np.array_equal(s.getSortedIndicesBuffer().read(np.uint32, n), order)
     assert np.array_equal(s.getSortedKeysBuffer().read(np.uint32, n), keys[order])
