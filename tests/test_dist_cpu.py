@@ -1,0 +1,138 @@
+"""Multi-GPU path on CPU: world_size-2 (and 3) gloo runs of splat_renderer_amd.dist.BandRenderer
+with a checker-backed stand-in for the device stages (the stand-in is test infrastructure; the
+product always uses dist.HipStages).  What is tested is dist.py's own logic — slice ranges, NaN
+shard padding, the one all-gather, band rows, stitching — against the single-process frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import oracle as O  # noqa: E402
+from splat_renderer_amd import dist  # noqa: E402
+from tests.helpers import make_case, oracle_pipeline  # noqa: E402
+
+
+class OracleStages:
+    """Same surface as dist.HipStages, computed by the oracle on CPU tensors."""
+
+    def __init__(self, width, height, tile=16):
+        self.width, self.height, self.tile = width, height, tile
+        self.kept = 0
+
+    def new_records(self, count, fill_nan=False):
+        t = torch.zeros((count, 8), dtype=torch.float32)
+        if fill_nan:
+            t.fill_(float("nan"))
+        return t
+
+    def new_image(self):
+        return torch.zeros((self.height, self.width, 4), dtype=torch.uint8)
+
+    def project_slice(self, uniforms, props, first, count, out_records):
+        rec = O.project(uniforms, props[first:first + count])
+        rec[:, 6] = np.arange(first, first + count, dtype=np.uint32).view(np.float32)  # global originalIndex
+        out_records[:count] = torch.from_numpy(rec)
+
+    def band_frame(self, records, n_records, props, normals, row0, row1, out_image):
+        rec = records.numpy()
+        ntx, nty = -(-self.width // self.tile), -(-self.height // self.tile)
+        # splat_band_keys: keep splats whose clamped tile rows meet [row0,row1), ascending index
+        keep = []
+        for i in range(n_records):
+            b = rec[i]
+            if np.isnan(b[:4]).any():
+                continue
+            mny, mxy = max(b[1], 0.0), min(b[3], float(self.height))
+            mnx, mxx = max(b[0], 0.0), min(b[2], float(self.width))
+            if mnx >= mxx or mny >= mxy:
+                continue
+            ty0, ty1 = int(mny // self.tile), min(int(mxy // self.tile), nty - 1)
+            if max(ty0, row0) <= min(ty1, row1 - 1):
+                keep.append(i)
+        keep = np.array(keep, np.uint32)
+        self.kept = keep.shape[0]
+        keys, _ = O.extract_keys(rec[keep] if keep.size else np.zeros((0, 8), np.float32))
+        order = keep[np.argsort(keys, kind="stable")] if keep.size else keep
+        counts, offsets, idx = O.bin_sorted(rec, order, self.width, self.height, self.tile)
+        # restrict lists to the band's rows (splat_bin_run's tile_row0/1)
+        c2 = counts.reshape(nty, ntx).copy()
+        c2[:row0] = 0
+        c2[row1:] = 0
+        lists = [idx[offsets[t]:offsets[t] + counts[t]] if c2.reshape(-1)[t] else idx[:0] for t in range(ntx * nty)]
+        counts = c2.reshape(-1).astype(np.uint32)
+        offsets, _ = O.scan_exclusive(counts)
+        idx = np.concatenate(lists) if lists else idx[:0]
+        r0, r1 = row0 * self.tile, min(row1 * self.tile, self.height)
+        _, img8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, rec[:, :8], idx, counts, offsets,
+                                 self.width, self.height, self.tile, rows=(r0, r1))
+        out_image[r0:r1] = torch.from_numpy(img8[r0:r1])
+
+
+def _worker(rank, world, port, n, w, h, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    props, normals, u = make_case(n, w, h, 31, 1.5)
+    st = OracleStages(w, h)
+    br = dist.BandRenderer(st, n, w, h, rank, world, td.all_gather_into_tensor)
+    img = br.render(u, props, normals)
+    r0, r1 = br.pixel_rows()
+    np.save(os.path.join(out_dir, f"band{rank}.npy"), img.numpy()[r0:r1])
+    np.save(os.path.join(out_dir, f"rows{rank}.npy"), np.array([r0, r1, st.kept]))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_renderer_gloo_matches_single_process(world, tmp_path):
+    n, w, h = 1500, 160, 112  # 7 tile rows: uneven bands; n not divisible by 2 or 3 -> NaN shard padding
+    n += 1
+    props, normals, u = make_case(n, w, h, 31, 1.5)
+    a = oracle_pipeline(props, normals, u, w, h)
+    _, want8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, a["proj"], a["indices"], a["counts"],
+                              a["offsets"], w, h)
+    mp.spawn(_worker, args=(world, _free_port(), n, w, h, str(tmp_path)), nprocs=world, join=True)
+    got = np.zeros_like(want8)
+    covered = 0
+    kept_total = 0
+    for r in range(world):
+        r0, r1, kept = np.load(tmp_path / f"rows{r}.npy")
+        got[r0:r1] = np.load(tmp_path / f"band{r}.npy")
+        covered += r1 - r0
+        kept_total += kept
+    assert covered == h
+    assert np.array_equal(got, want8)  # bit-identical to the single-process frame
+    assert kept_total >= (a["counts"].reshape(7, 10).sum(axis=1) > 0).sum()  # every non-empty row has an owner
+
+
+def test_slice_and_band_partition_properties():
+    for n in (0, 1, 7, 1000, 5_000_000):
+        for world in (1, 2, 3, 8):
+            per = dist.shard_size(n, world) if n else 0
+            cover = []
+            for r in range(world):
+                first, count = dist.slice_range(n, r, world)
+                assert 0 <= count <= per and first + count <= n
+                cover.append((first, count))
+            assert sum(c for _, c in cover) == n
+            assert all(cover[i][0] + cover[i][1] == cover[i + 1][0] or cover[i + 1][1] == 0 for i in range(world - 1))
+    for nty in (1, 7, 68, 135):
+        for world in (1, 2, 4, 8):
+            rows = [dist.band_rows(nty, r, world) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == nty
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))

@@ -327,3 +327,134 @@ def test_full_frame_C0(device):
     r.destroy()
     pbuf.destroy()
     nbuf.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_band_frame_matches_single_gpu(device, world):
+    """SURVEY §8e without a cluster: every rank's device work (project_slice -> [gather] -> band_keys
+    -> sort -> bin -> composite) runs in turn on the one GPU, the all-gather is a concat; the
+    stitched rgba8 image must be bit-identical to the single-GPU frame."""
+    import torch
+    from splat_renderer_amd import dist
+    n, w, h = 30001, 400, 232  # odd n: the last shard is padded with NaN records
+    props, normals, u = make_case(n, w, h, 41, 1.5)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    full = sr.Renderer(device, None, "rgba8unorm", n)
+    full.render(u, pbuf, nbuf, None, w, h)
+    want = full.readPixels().copy()
+    device.sync()
+    pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+    per = dist.shard_size(n, world)
+    stages = dist.HipStages(torch, 0, per * world, w, h)
+    renderers = [dist.BandRenderer(stages, n, w, h, r, world, None) for r in range(world)]
+    for br in renderers:  # phase 1: every rank projects its slice
+        stages.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+    gathered = torch.cat([br.shard for br in renderers], dim=0).contiguous()
+    got = np.zeros_like(want)
+    kept = []
+    for br in renderers:  # phase 2: every rank renders its band from the gathered records
+        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image)
+        torch.cuda.synchronize()
+        r0, r1 = br.pixel_rows()
+        got[r0:r1] = br.image.cpu().numpy()[r0:r1]
+        kept.append(stages.kept)
+    assert np.array_equal(got, want)
+    assert all(0 < k < n for k in kept) and sum(kept) >= n * 0.9  # bands keep a subset; overlaps allowed
+    stages.destroy()
+    full.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
+
+
+@pytest.mark.parametrize("name", ["tiny7", "small300", "ragged1000"])
+def test_golden_fixtures(device, name):
+    """Committed vectors (tests/golden/*.npz, generated by the oracle): inputs in, every stage out."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    n, w, h, _ = (int(x) for x in g["dims"])
+    gpu = run_gpu_pipeline(device, g["props"], g["normals"], g["uniforms"], n, w, h)
+    assert np.array_equal(bits(gpu["proj"].getProjectedBuffer().read(np.float32)), bits(g["projected"]).reshape(-1))
+    assert np.array_equal(gpu["sorter"].getSortedIndicesBuffer().read(np.uint32, n), g["order"][:n])
+    b = gpu["binner"]
+    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), g["counts"])
+    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), g["offsets"])
+    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"])
+    for mode, key in ((sr.MODE_FRONT_TO_BACK, "image_front_to_back"), (sr.MODE_REFERENCE_LITERAL, "image_literal")):
+        r = sr.ComputeShaderRenderer(device, None, "rgba8unorm", mode=mode, earlyOut=True)
+        r.render(g["uniforms"], gpu["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), gpu["nbuf"],
+                 gpu["proj"].getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, -(-w // 16), w, h,
+                 wantFloat=True)
+        err = np.abs(r.readPixelsFloat() - g[key])
+        assert err.max() <= TOL_EARLY_OUT_BOUND and (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
+        assert np.abs(r.readPixels().astype(int) - g[key + "_u8"].astype(int)).max() <= 3
+        r.destroy()
+    destroy_all(gpu)
+
+
+@pytest.mark.parametrize("tile", [8, 10, 24, 32])
+def test_bin_other_tile_sizes(device, tile):
+    """Binning is tile-size generic (GPUTileBinner's ctor takes any tileSize); power-of-two sizes
+    take the exact f32 path, the others the f64 path — both must equal binSorted."""
+    n, w, h = 20000, 333, 211
+    props, normals, u = make_case(n, w, h, 17, 1.5)
+    ref = oracle_pipeline(props, normals, u, w, h, tile=tile)
+    g = run_gpu_pipeline(device, props, normals, u, n, w, h, tile=tile)
+    b = g["binner"]
+    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
+    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    destroy_all(g)
+
+
+def test_full_size_C2_properties(device):
+    """BASELINE's headline size (5M @1080p): too big for the oracle's composite in a unit test, so
+    the size-independent properties: the sort is a permutation in non-decreasing key order with
+    index-ascending ties; per-tile lists are depth-ordered sub-sequences of it; counts sum to P;
+    offsets are their exclusive scan; sampled pairs overlap their tile; the image is opaque."""
+    n, w, h = sr.scene.CONFIGS["C2"]
+    props, normals, u = make_case(n, w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r.render(u, pbuf, nbuf, None, w, h)
+    order = r.sorter.getSortedIndicesBuffer().read(np.uint32, n)
+    keys = r.sorter.getSortedKeysBuffer().read(np.uint32, n)
+    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+    dk = np.diff(keys.astype(np.int64))
+    assert (dk >= 0).all()
+    ties = dk == 0
+    assert (np.diff(order.astype(np.int64))[ties] > 0).all()  # stable: equal keys keep index order
+    proj = r.projector.getProjectedBuffer().read(np.float32).reshape(n, 8)
+    assert np.array_equal(keys, (proj[order, 4].view(np.uint32) ^ np.uint32(0x80000000)))  # all depths positive
+    counts = r.binner.getTileCountsBuffer().read(np.uint32)
+    offsets = r.binner.getTileOffsetsBuffer().read(np.uint32)
+    total = r.binner.getTotalIndices()
+    assert int(counts.sum(dtype=np.uint64)) == total
+    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32))
+    idx = r.binner.getTileIndicesBuffer().read(np.uint32, total)
+    rank = np.empty(n, np.uint32)
+    rank[order] = np.arange(n, dtype=np.uint32)
+    ranks = rank[idx].astype(np.int64)
+    d = np.diff(ranks)
+    starts = offsets[counts > 0][1:]  # list boundaries: the only places a decrease is allowed
+    bad = np.nonzero(d <= 0)[0] + 1
+    assert np.isin(bad, starts).all()
+    # every pair really overlaps its tile (spot check 200k pairs)
+    rng = np.random.default_rng(0)
+    pick = rng.integers(0, total, 200000)
+    tile_of = np.searchsorted(offsets, pick, side="right") - 1
+    # skip empty tiles that share an offset with the next one
+    while True:
+        emp = counts[tile_of] == 0
+        if not emp.any():
+            break
+        tile_of[emp] += 1
+    tx, ty = tile_of % 120, tile_of // 120
+    b = proj[idx[pick]]
+    assert (np.maximum(b[:, 0], 0) < (tx + 1) * 16).all() and (np.minimum(b[:, 2], w) >= tx * 16).all()
+    assert (np.maximum(b[:, 1], 0) < (ty + 1) * 16).all() and (np.minimum(b[:, 3], h) >= ty * 16).all()
+    img = r.readPixels()
+    assert (img[..., 3] == 255).all()
+    assert img[..., :3].std() > 10  # not a constant image
+    r.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
