@@ -1,0 +1,26 @@
+// Type declarations for splat_renderer_amd/napi/index.js — the reference's class surface
+// (ath92/splat-renderer src/*.ts) over libsplat_hip.so.
+export type TypedArray = Float32Array | Uint32Array | Uint8Array | Int32Array;
+export class Buffer { readonly device: Device; ptr: number; size: number; destroy(): void; write(data: TypedArray): this; read<T extends TypedArray>(out: T): T; zero(): void; }
+export class Device {
+  constructor(ordinal?: number);
+  queue: { writeBuffer(buffer: Buffer, offset: number, data: TypedArray): void; submit(commandBuffers?: unknown[]): void; onSubmittedWorkDone(): Promise<void> };
+  createBuffer(desc: number | { size: number }): Buffer; createBufferFrom(data: TypedArray): Buffer; createCommandEncoder(): CommandEncoder; sync(): void; destroy(): void;
+}
+export interface CommandEncoder { finish(): null; }
+export class Camera {
+  target: Float32Array; distance: number; azimuth: number; elevation: number; fov: number; aspect: number; near: number; far: number;
+  setAspect(aspect: number): void; rotate(deltaAzimuth: number, deltaElevation: number): void; zoom(deltaDistance: number): void;
+  getViewProjectionMatrix(): Float32Array; getPosition(): Float32Array; uniforms(width: number, height: number, time?: number): Float32Array;
+}
+export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; destroy(): void; }
+export class SplatProjector { constructor(device: Device, numSplats: number); project(enc: CommandEncoder | null, uniformBuffer: Buffer | Float32Array, splatPropertyBuffer: Buffer, keysBuffer?: Buffer | null, payloadBuffer?: Buffer | null, paddedSize?: number): void; getProjectedBuffer(): Buffer; destroy(): void; }
+export class DepthKeyExtractor { constructor(device: Device); extract(enc: CommandEncoder | null, projectedBuffer: Buffer, keysBuffer: Buffer, payloadBuffer: Buffer, numSplats: number, paddedSize: number): void; cleanupTempBuffers(): void; }
+export class RadixSorter { constructor(device: Device, numSplats: number); readonly paddedSize: number; sort(numKeys?: number, bitBegin?: number, bitEnd?: number): void; getSortedIndicesBuffer(): Buffer; getKeysBuffer(): Buffer; getPayloadBuffer(): Buffer; cleanupTempBuffers(): void; destroy(): void; }
+export class PrefixSumScanner { constructor(device: Device); scan(enc: CommandEncoder | null, inputBuffer: Buffer, outputBuffer: Buffer, numElements: number): Promise<void>; cleanupTempBuffers(): void; }
+export class GPUTileBinner { constructor(device: Device, tileSize: number); binSplats(enc: CommandEncoder | null, projectedBuffer: Buffer, sortedIndicesBuffer: Buffer, numSplats: number, screenWidth: number, screenHeight: number): Promise<void>; getTileOffsetsBuffer(): Buffer; getTileIndicesBuffer(): Buffer; getTileCountsBuffer(): Buffer; getTotalIndices(): number; getTileSize(): number; cleanupTempBuffers(): void; destroy(): void; }
+export class PerTileSorter { constructor(device: Device); sort(...args: unknown[]): void; cleanupTempBuffers(): void; destroy(): void; }
+export class ComputeShaderRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean }); render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
+export class TileRenderer extends ComputeShaderRenderer { bindTileData(projectedBuffer: Buffer, tileCountsBuffer: Buffer, tileOffsetsBuffer: Buffer): void; }
+export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
+export const MODE_FRONT_TO_BACK: 0; export const MODE_REFERENCE_LITERAL: 1;

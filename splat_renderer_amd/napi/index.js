@@ -1,0 +1,240 @@
+'use strict';
+/**
+ * Host classes of the tile-raster hot path over the N-API addon (splat_napi.node -> libsplat_hip.so).
+ *
+ * Same class names, constructor arguments, verbs and error behaviour as the TypeScript classes of
+ * ath92/splat-renderer (file:line below are under that repository's src/), so a call site written
+ * against the reference keeps working: `device` is a Device (GPUDevice equivalent: one HIP device +
+ * one stream), a GPUBuffer is a Buffer {ptr, size}, a GPUCommandEncoder argument is accepted and
+ * ignored (recording = immediate enqueue on the stream).  CommonJS / ES2019: this image has Node 12
+ * and no TypeScript compiler; index.d.ts carries the types.
+ */
+const native = require('./splat_napi.node');
+
+const U32_MAX = 0xffffffff;
+const MODE_FRONT_TO_BACK = 0;
+const MODE_REFERENCE_LITERAL = 1;
+
+class Buffer_ {
+  constructor(device, ptr, size, owned = true) {
+    this.device = device; this.ptr = ptr; this.size = size; this.owned = owned; this.hostShadow = null;
+  }
+  destroy() { if (this.owned && this.ptr) native.buf_free(this.device.ctx, this.ptr); this.ptr = 0; }
+  write(typedArray) {
+    native.buf_upload(this.device.ctx, this.ptr, typedArray);
+    if (this.size <= 256) this.hostShadow = new Float32Array(typedArray.buffer.slice(typedArray.byteOffset, typedArray.byteOffset + typedArray.byteLength));
+    return this;
+  }
+  read(typedArray) { native.buf_download(this.device.ctx, typedArray, this.ptr); return typedArray; }
+  zero() { native.buf_zero(this.device.ctx, this.ptr, this.size); }
+}
+
+class Device {
+  constructor(ordinal = 0) {
+    this.ctx = native.ctx_create(ordinal);
+    const self = this;
+    this.queue = {
+      writeBuffer(buffer, offset, data) { if (offset !== 0) throw new Error('writeBuffer: only offset 0 is supported'); buffer.write(data); },
+      submit() {},
+      onSubmittedWorkDone() { self.sync(); return Promise.resolve(); },
+    };
+  }
+  createBuffer(desc) { const size = typeof desc === 'number' ? desc : desc.size; return new Buffer_(this, native.buf_alloc(this.ctx, size), size); }
+  createBufferFrom(typedArray) { return this.createBuffer(Math.max(typedArray.byteLength, 16)).write(typedArray); }
+  createCommandEncoder() { return { finish() { return null; } }; }
+  sync() { native.sync(this.ctx); }
+  destroy() { if (this.ctx) native.ctx_destroy(this.ctx); this.ctx = null; }
+}
+
+function uniformFloats(u) {
+  if (u instanceof Buffer_) {
+    if (!u.hostShadow) throw new Error('uniform buffer was never written');
+    u = u.hostShadow;
+  }
+  if (!(u instanceof Float32Array)) u = Float32Array.from(u);
+  return u;
+}
+
+/** src/SplatPropertyManager.ts:13-181 */
+class SplatPropertyManager {
+  constructor(device, numSplats) {
+    this.device = device; this.numSplats = numSplats;
+    this.propertyBuffer = device.createBuffer(numSplats * 32);
+    const data = new Float32Array(numSplats * 8); // initializeDefaults :33-50
+    for (let i = 0; i < numSplats; i++) { data[i * 8 + 3] = 0.04; data[i * 8 + 4] = 1; data[i * 8 + 5] = 1; data[i * 8 + 6] = 1; data[i * 8 + 7] = 0.7; }
+    this.propertyBuffer.write(data);
+  }
+  updateFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) { // :153-173
+    native.update_props(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, this.propertyBuffer.ptr);
+  }
+  setFromArrays(props) { this.propertyBuffer.write(props); }
+  getPropertyBuffer() { return this.propertyBuffer; } // :175-177
+  destroy() { this.propertyBuffer.destroy(); }          // :179-181
+}
+
+/** src/SplatProjector.ts:5-203 */
+class SplatProjector {
+  constructor(device, numSplats) { this.device = device; this.numSplats = numSplats; this.projectedBuffer = device.createBuffer(numSplats * 32); }
+  project(commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer = null, payloadBuffer = null, paddedSize = 0) { // :174-194
+    const u = uniformFloats(uniformBuffer);
+    if (u.length < 22) throw new Error('uniform block needs 22 floats (VP, eye, time, screenW, screenH)');
+    native.project(this.device.ctx, u, splatPropertyBuffer.ptr, 2, this.numSplats, this.projectedBuffer.ptr,
+      keysBuffer ? keysBuffer.ptr : null, payloadBuffer ? payloadBuffer.ptr : null, paddedSize);
+  }
+  getProjectedBuffer() { return this.projectedBuffer; } // :196-198
+  destroy() { this.projectedBuffer.destroy(); }          // :200-202
+}
+
+/** src/DepthKeyExtractor.ts:5-115 */
+class DepthKeyExtractor {
+  constructor(device) { this.device = device; }
+  extract(commandEncoder, projectedBuffer, keysBuffer, payloadBuffer, numSplats, paddedSize) { // :71-109
+    native.extract_keys(this.device.ctx, projectedBuffer.ptr, numSplats, paddedSize, keysBuffer.ptr, payloadBuffer.ptr);
+  }
+  cleanupTempBuffers() {}
+}
+
+/** src/RadixSorter.ts:21-301 */
+class RadixSorter {
+  constructor(device, numSplats) {
+    this.device = device; this.numSplats = numSplats;
+    this.handle = native.sort_create(device.ctx, numSplats);
+    this.paddedSize = native.sort_capacity(this.handle); // :46-52
+  }
+  sort(numKeys = this.numSplats, bitBegin = 0, bitEnd = 32) { native.sort_run(this.device.ctx, this.handle, numKeys, bitBegin, bitEnd); } // :197-264
+  getSortedIndicesBuffer() { return new Buffer_(this.device, native.sort_sorted_payload(this.handle), this.paddedSize * 4, false); } // :269-271
+  getKeysBuffer() { return new Buffer_(this.device, native.sort_keys(this.handle), this.paddedSize * 4, false); }       // :273-275
+  getPayloadBuffer() { return new Buffer_(this.device, native.sort_payload(this.handle), this.paddedSize * 4, false); } // :277-279
+  cleanupTempBuffers() {}
+  destroy() { if (this.handle) native.sort_destroy(this.handle); this.handle = null; }
+}
+
+/** src/PrefixSumScanner.ts:8-168 */
+class PrefixSumScanner {
+  constructor(device) { this.device = device; }
+  async scan(commandEncoder, inputBuffer, outputBuffer, numElements) { // :74-87 (async in the reference because of its CPU fallback)
+    native.scan_u32(this.device.ctx, inputBuffer.ptr, outputBuffer.ptr, numElements, null);
+  }
+  cleanupTempBuffers() {}
+}
+
+/** src/GPUTileBinner.ts:11-378 */
+class GPUTileBinner {
+  constructor(device, tileSize) {
+    this.device = device; this.tileSize = tileSize; this.handle = native.bin_create(device.ctx, tileSize);
+    this.prefixSumScanner = new PrefixSumScanner(device); // :49
+    this.numTiles = 0;
+  }
+  async binSplats(commandEncoder, projectedBuffer, sortedIndicesBuffer, numSplats, screenWidth, screenHeight) { // :190-338
+    native.bin_run(this.device.ctx, this.handle, projectedBuffer.ptr, numSplats, sortedIndicesBuffer.ptr, numSplats, screenWidth, screenHeight, 0, U32_MAX);
+    this.numTiles = Math.ceil(screenWidth / this.tileSize) * Math.ceil(screenHeight / this.tileSize);
+  }
+  // the natives throw Error("... Tile offsets buffer not initialized") etc. before binSplats, as :340-359
+  getTileOffsetsBuffer() { return new Buffer_(this.device, native.bin_offsets(this.device.ctx, this.handle), this.numTiles * 4, false); }
+  getTileIndicesBuffer() { const p = native.bin_indices(this.device.ctx, this.handle); return new Buffer_(this.device, p, Math.max(4, this.getTotalIndices() * 4), false); }
+  getTileCountsBuffer() { return new Buffer_(this.device, native.bin_counts(this.device.ctx, this.handle), this.numTiles * 4, false); }
+  getTotalIndices() { return native.bin_total(this.device.ctx, this.handle); }
+  getTileSize() { return this.tileSize; } // :361-363
+  cleanupTempBuffers() { this.prefixSumScanner.cleanupTempBuffers(); }
+  destroy() { if (this.handle) native.bin_destroy(this.handle); this.handle = null; }
+}
+
+/** src/PerTileSorter.ts:6-223 — lists leave GPUTileBinner already sorted; kept for call-site compatibility */
+class PerTileSorter {
+  constructor(device) { this.device = device; }
+  sort() {}
+  cleanupTempBuffers() {}
+  destroy() {}
+}
+
+/** src/ComputeShaderRenderer.ts:5-469 (the canvas blit :268-338 is out of scope) */
+class ComputeShaderRenderer {
+  constructor(device, context = null, presentationFormat = 'rgba8unorm', options = {}) {
+    this.device = device; this.mode = options.mode || MODE_FRONT_TO_BACK; this.earlyOut = options.earlyOut !== false;
+    this.outputTexture = null; this.width = 0; this.height = 0;
+  }
+  ensureOutputTexture(width, height) { // :340-360
+    if (this.width !== width || this.height !== height) {
+      if (this.outputTexture) this.outputTexture.destroy();
+      this.outputTexture = this.device.createBuffer(width * height * 4); this.width = width; this.height = height;
+    }
+  }
+  render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, tileSize, numTilesX, width, height) { // :362-462
+    if (numTilesX !== Math.ceil(width / tileSize)) throw new Error('numTilesX does not match ceil(width / tileSize)');
+    this.ensureOutputTexture(width, height);
+    native.composite(this.device.ctx, [this.mode, this.earlyOut ? 1 : 0, tileSize, 0, U32_MAX], splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
+      projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr, width, height, this.outputTexture.ptr, null);
+  }
+  readPixels() { return this.outputTexture.read(new Uint8Array(this.width * this.height * 4)); }
+  destroy() { if (this.outputTexture) this.outputTexture.destroy(); this.outputTexture = null; } // :464-468
+}
+
+/** src/TileRenderer.ts:5-355 — fronts the same composite; bindTileData supplies what render()'s reference signature lacks */
+class TileRenderer extends ComputeShaderRenderer {
+  bindTileData(projectedBuffer, tileCountsBuffer, tileOffsetsBuffer) { this.bound = [projectedBuffer, tileCountsBuffer, tileOffsetsBuffer]; }
+  async render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, tileCountsData, numTilesX, numTilesY, tileSize, maxSplatsPerTile, width, height) { // :234-348
+    if (!this.bound) throw new Error('TileRenderer.render: call bindTileData(projected, counts, offsets) first');
+    super.render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, this.bound[0], this.bound[1], this.bound[2], tileSize, numTilesX, width, height);
+  }
+}
+
+/** src/Renderer.ts:13,250,311 — name kept as the whole-frame facade (project -> keys -> sort -> bin -> composite) */
+class Renderer {
+  constructor(device, context = null, presentationFormat = 'rgba8unorm', numPoints = 0, tileSize = 16) {
+    this.device = device; this.numPoints = numPoints; this.tileSize = tileSize;
+    this.projector = new SplatProjector(device, numPoints); this.sorter = new RadixSorter(device, numPoints); this.binner = new GPUTileBinner(device, tileSize);
+    this.output = null; this.width = 0; this.height = 0;
+  }
+  render(uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height) {
+    let u = uniformFloats(uniformData);
+    if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
+    if (this.width !== width || this.height !== height) { if (this.output) this.output.destroy(); this.output = this.device.createBuffer(width * height * 4); this.width = width; this.height = height; }
+    native.render_frame(this.device.ctx, this.sorter.handle, this.binner.handle, [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX], u,
+      propertyBuffer.ptr, normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
+    this.binner.numTiles = Math.ceil(width / this.tileSize) * Math.ceil(height / this.tileSize);
+    return this.output;
+  }
+  readPixels() { return this.output.read(new Uint8Array(this.width * this.height * 4)); }
+  destroy() { this.projector.destroy(); this.sorter.destroy(); this.binner.destroy(); if (this.output) this.output.destroy(); }
+}
+
+/** src/Camera.ts:3-139 with gl-matrix 3.4.4 semantics (Float32Array stores, f64 arithmetic) */
+class Camera {
+  constructor() {
+    this.target = new Float32Array([0, 0, 0]); this.distance = 3.0; this.azimuth = 0.5; this.elevation = 0.5;
+    this.fov = 45; this.aspect = 1.0; this.near = 0.1; this.far = 100.0;
+    this.viewProjectionMatrix = new Float32Array(16); this.cameraPosition = new Float32Array(3); this.isDirty = true;
+  }
+  setAspect(aspect) { this.aspect = aspect; this.isDirty = true; }
+  rotate(dAz, dEl) { this.azimuth += dAz; this.elevation += dEl; const m = Math.PI / 2 - 0.01; this.elevation = Math.max(-m, Math.min(m, this.elevation)); this.isDirty = true; }
+  zoom(d) { this.distance += d; this.distance = Math.max(0.5, Math.min(20.0, this.distance)); this.isDirty = true; }
+  getCameraPosition() {
+    const x = this.distance * Math.cos(this.elevation) * Math.sin(this.azimuth), y = this.distance * Math.sin(this.elevation), z = this.distance * Math.cos(this.elevation) * Math.cos(this.azimuth);
+    return new Float32Array([this.target[0] + x, this.target[1] + y, this.target[2] + z]);
+  }
+  updateMatrices() {
+    if (!this.isDirty) return;
+    const eye = this.getCameraPosition(); this.cameraPosition = eye;
+    const view = new Float32Array(16), proj = new Float32Array(16);
+    let z0 = eye[0] - this.target[0], z1 = eye[1] - this.target[1], z2 = eye[2] - this.target[2];
+    if (Math.abs(z0) < 1e-6 && Math.abs(z1) < 1e-6 && Math.abs(z2) < 1e-6) { view[0] = view[5] = view[10] = view[15] = 1; } else {
+      let len = 1 / Math.sqrt(z0 * z0 + z1 * z1 + z2 * z2); z0 *= len; z1 *= len; z2 *= len;
+      let x0 = 1 * z2 - 0 * z1, x1 = 0 * z0 - 0 * z2, x2 = 0 * z1 - 1 * z0; // up = (0,1,0)
+      len = Math.sqrt(x0 * x0 + x1 * x1 + x2 * x2); if (!len) { x0 = x1 = x2 = 0; } else { len = 1 / len; x0 *= len; x1 *= len; x2 *= len; }
+      let y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+      len = Math.sqrt(y0 * y0 + y1 * y1 + y2 * y2); if (!len) { y0 = y1 = y2 = 0; } else { len = 1 / len; y0 *= len; y1 *= len; y2 *= len; }
+      view.set([x0, y0, z0, 0, x1, y1, z1, 0, x2, y2, z2, 0, -(x0 * eye[0] + x1 * eye[1] + x2 * eye[2]), -(y0 * eye[0] + y1 * eye[1] + y2 * eye[2]), -(z0 * eye[0] + z1 * eye[1] + z2 * eye[2]), 1]);
+    }
+    const f = 1 / Math.tan(((this.fov * Math.PI) / 180) / 2), nf = 1 / (this.near - this.far);
+    proj[0] = f / this.aspect; proj[5] = f; proj[11] = -1; proj[10] = (this.far + this.near) * nf; proj[14] = 2 * this.far * this.near * nf;
+    const out = this.viewProjectionMatrix;
+    for (let c = 0; c < 4; c++) for (let k = 0; k < 4; k++) out[c * 4 + k] = view[c * 4] * proj[k] + view[c * 4 + 1] * proj[4 + k] + view[c * 4 + 2] * proj[8 + k] + view[c * 4 + 3] * proj[12 + k];
+    this.isDirty = false;
+  }
+  getViewProjectionMatrix() { this.updateMatrices(); return this.viewProjectionMatrix; }
+  getPosition() { this.updateMatrices(); return this.cameraPosition; }
+  uniforms(width, height, time = 0) { const u = new Float32Array(22); u.set(this.getViewProjectionMatrix(), 0); u.set(this.getPosition(), 16); u[19] = time; u[20] = width; u[21] = height; return u; }
+}
+
+module.exports = { native, Device, Buffer: Buffer_, Camera, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
+  GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL };

@@ -1,0 +1,33 @@
+'use strict';
+// node render_frame.js <props.f32> <normals.f32> <n> <W> <H> <out.rgba8> [<order.u32> <counts.u32> <indices.u32>]
+// Renders one frame through the JS host classes (stage by stage, like the reference's call order)
+// and writes the raw outputs for tests/test_napi.py to compare with the oracle.
+const fs = require('fs');
+const sr = require('./index.js');
+const [propsPath, normalsPath, nStr, wStr, hStr, outPath, orderPath, countsPath, indicesPath] = process.argv.slice(2);
+const n = +nStr, W = +wStr, H = +hStr;
+const f32 = (p) => { const b = fs.readFileSync(p); return new Float32Array(b.buffer, b.byteOffset, b.length / 4); };
+const device = new sr.Device(0);
+const props = new sr.SplatPropertyManager(device, n); props.setFromArrays(f32(propsPath));
+const normals = device.createBufferFrom(f32(normalsPath));
+const camera = new sr.Camera(); camera.setAspect(W / H);
+const uniforms = camera.uniforms(W, H);
+const projector = new sr.SplatProjector(device, n), sorter = new sr.RadixSorter(device, n), extractor = new sr.DepthKeyExtractor(device);
+const binner = new sr.GPUTileBinner(device, 16), renderer = new sr.ComputeShaderRenderer(device, null, 'rgba8unorm');
+let threw = false;
+try { binner.getTileOffsetsBuffer(); } catch (e) { threw = /not initialized/.test(e.message); }
+if (!threw) throw new Error('getter before binSplats did not throw');
+(async () => {
+  const enc = device.createCommandEncoder();
+  projector.project(enc, uniforms, props.getPropertyBuffer());
+  extractor.extract(enc, projector.getProjectedBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), n, sorter.paddedSize);
+  sorter.sort();
+  await binner.binSplats(enc, projector.getProjectedBuffer(), sorter.getSortedIndicesBuffer(), n, W, H);
+  renderer.render(uniforms, props.getPropertyBuffer(), binner.getTileIndicesBuffer(), normals, projector.getProjectedBuffer(),
+    binner.getTileCountsBuffer(), binner.getTileOffsetsBuffer(), 16, Math.ceil(W / 16), W, H);
+  fs.writeFileSync(outPath, Buffer.from(renderer.readPixels().buffer));
+  if (orderPath) fs.writeFileSync(orderPath, Buffer.from(sorter.getSortedIndicesBuffer().read(new Uint32Array(n)).buffer));
+  if (countsPath) fs.writeFileSync(countsPath, Buffer.from(binner.getTileCountsBuffer().read(new Uint32Array(binner.numTiles)).buffer));
+  if (indicesPath) fs.writeFileSync(indicesPath, Buffer.from(binner.getTileIndicesBuffer().read(new Uint32Array(binner.getTotalIndices())).buffer));
+  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), uniforms: Array.from(uniforms) }));
+})().catch((e) => { console.error(e); process.exit(1); });

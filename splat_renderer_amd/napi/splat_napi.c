@@ -1,0 +1,273 @@
+/*
+ * splat_napi.c — thin N-API addon over the C ABI of libsplat_hip.so (include/splat.h).
+ *
+ * One JS function per ABI entry point, same name without the "splat_" prefix.  Handles (ctx,
+ * sorter, binner) are napi_externals; device pointers cross as JS numbers (GPU virtual addresses
+ * are < 2^53); host data crosses as TypedArrays/ArrayBuffers.  A negative status becomes a thrown
+ * JS Error carrying splat_last_error(), which is the reference's error behaviour (its getters
+ * `throw new Error(...)`: /root/reference/src/GPUTileBinner.ts:340-359).
+ *
+ * Plain C, no node-addon-api, no node-gyp: built by the Makefile next to this file with
+ *   gcc -shared -fPIC -I/usr/include/node splat_napi.c -o splat_napi.node -L.. -lsplat_hip
+ */
+#define NAPI_VERSION 6
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/splat.h"
+
+#define MAX_ARGS 16
+
+typedef struct {
+    napi_env env;
+    size_t argc;
+    napi_value argv[MAX_ARGS];
+    int failed;
+} call_t;
+
+static int get_args(napi_env env, napi_callback_info info, call_t *c, size_t want) {
+    c->env = env;
+    c->argc = MAX_ARGS;
+    c->failed = 0;
+    if (napi_get_cb_info(env, info, &c->argc, c->argv, NULL, NULL) != napi_ok || c->argc < want) {
+        napi_throw_type_error(env, NULL, "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static void *arg_external(call_t *c, size_t i) {
+    void *p = NULL;
+    napi_valuetype t;
+    napi_typeof(c->env, c->argv[i], &t);
+    if (t == napi_null || t == napi_undefined) return NULL;
+    if (napi_get_value_external(c->env, c->argv[i], &p) != napi_ok) {
+        c->failed = 1;
+        napi_throw_type_error(c->env, NULL, "expected a handle");
+    }
+    return p;
+}
+
+static double arg_number(call_t *c, size_t i) {
+    double d = 0;
+    if (napi_get_value_double(c->env, c->argv[i], &d) != napi_ok) {
+        c->failed = 1;
+        napi_throw_type_error(c->env, NULL, "expected a number");
+    }
+    return d;
+}
+
+static void *arg_dptr(call_t *c, size_t i) { /* device pointer as a number; null/undefined -> NULL */
+    napi_valuetype t;
+    napi_typeof(c->env, c->argv[i], &t);
+    if (t == napi_null || t == napi_undefined) return NULL;
+    return (void *)(uintptr_t)arg_number(c, i);
+}
+
+static void *arg_hostbuf(call_t *c, size_t i, size_t *bytes) { /* TypedArray, DataView or ArrayBuffer */
+    bool is = false;
+    void *data = NULL;
+    size_t len = 0;
+    napi_is_typedarray(c->env, c->argv[i], &is);
+    if (is) {
+        napi_typedarray_type tt;
+        napi_value ab;
+        size_t off;
+        napi_get_typedarray_info(c->env, c->argv[i], &tt, &len, &data, &ab, &off);
+        static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        len *= esz[tt];
+    } else {
+        napi_is_arraybuffer(c->env, c->argv[i], &is);
+        if (is) {
+            napi_get_arraybuffer_info(c->env, c->argv[i], &data, &len);
+        } else {
+            c->failed = 1;
+            napi_throw_type_error(c->env, NULL, "expected a TypedArray or ArrayBuffer");
+        }
+    }
+    if (bytes) *bytes = len;
+    return data;
+}
+
+static napi_value mk_number(napi_env env, double v) {
+    napi_value r;
+    napi_create_double(env, v, &r);
+    return r;
+}
+
+static napi_value mk_undefined(napi_env env) {
+    napi_value r;
+    napi_get_undefined(env, &r);
+    return r;
+}
+
+static napi_value mk_external(napi_env env, void *p) {
+    napi_value r;
+    napi_create_external(env, p, NULL, NULL, &r);
+    return r;
+}
+
+/* status -> thrown Error("libsplat_hip <code>: <message>") */
+static napi_value check(napi_env env, splat_ctx *ctx, int rc, napi_value ok) {
+    if (rc == SPLAT_OK) return ok;
+    char msg[600];
+    const char *m = splat_last_error(ctx);
+    strcpy(msg, "libsplat_hip ");
+    char num[16];
+    int n = rc, k = 0;
+    if (n < 0) { msg[strlen(msg) + 1] = 0; msg[strlen(msg)] = '-'; n = -n; }
+    do { num[k++] = (char)('0' + n % 10); n /= 10; } while (n);
+    while (k) { size_t l = strlen(msg); msg[l] = num[--k]; msg[l + 1] = 0; }
+    strcat(msg, ": ");
+    strncat(msg, m ? m : "", sizeof msg - strlen(msg) - 1);
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+}
+
+#define FN(name) static napi_value name(napi_env env, napi_callback_info info)
+#define ARGS(n) call_t c; if (!get_args(env, info, &c, n)) return NULL
+#define BAIL if (c.failed) return NULL
+
+FN(abi_version) { (void)info; return mk_number(env, splat_abi_version()); }
+
+FN(ctx_create) {
+    ARGS(1);
+    int dev = (int)arg_number(&c, 0); BAIL;
+    splat_ctx *ctx = NULL;
+    int rc = splat_ctx_create(dev, &ctx);
+    return check(env, NULL, rc, rc == SPLAT_OK ? mk_external(env, ctx) : NULL);
+}
+FN(ctx_destroy) { ARGS(1); splat_ctx_destroy((splat_ctx *)arg_external(&c, 0)); return mk_undefined(env); }
+FN(sync) { ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL; return check(env, x, splat_sync(x), mk_undefined(env)); }
+FN(set_timing) { ARGS(2); splat_ctx *x = arg_external(&c, 0); int e = (int)arg_number(&c, 1); BAIL; return check(env, x, splat_set_timing(x, e), mk_undefined(env)); }
+FN(stage_time_ms) {
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); int st = (int)arg_number(&c, 1); BAIL;
+    float ms = 0; int rc = splat_stage_time_ms(x, st, &ms);
+    return check(env, x, rc, mk_number(env, ms));
+}
+FN(buf_alloc) {
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); size_t b = (size_t)arg_number(&c, 1); BAIL;
+    void *p = NULL; int rc = splat_buf_alloc(x, b, &p);
+    return check(env, x, rc, mk_number(env, (double)(uintptr_t)p));
+}
+FN(buf_free) { ARGS(2); splat_ctx *x = arg_external(&c, 0); void *p = arg_dptr(&c, 1); BAIL; return check(env, x, splat_buf_free(x, p), mk_undefined(env)); }
+FN(buf_zero) { ARGS(3); splat_ctx *x = arg_external(&c, 0); void *p = arg_dptr(&c, 1); size_t b = (size_t)arg_number(&c, 2); BAIL; return check(env, x, splat_buf_zero(x, p, b), mk_undefined(env)); }
+FN(buf_upload) { /* (ctx, dptr, hostTypedArray) */
+    ARGS(3); splat_ctx *x = arg_external(&c, 0); void *p = arg_dptr(&c, 1); size_t n = 0; void *h = arg_hostbuf(&c, 2, &n); BAIL;
+    return check(env, x, splat_buf_upload(x, p, h, n), mk_undefined(env));
+}
+FN(buf_download) { /* (ctx, hostTypedArray, dptr) fills the whole array */
+    ARGS(3); splat_ctx *x = arg_external(&c, 0); size_t n = 0; void *h = arg_hostbuf(&c, 1, &n); void *p = arg_dptr(&c, 2); BAIL;
+    return check(env, x, splat_buf_download(x, h, p, n), mk_undefined(env));
+}
+FN(update_props) {
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); void *pos = arg_dptr(&c, 1), *cur = arg_dptr(&c, 2);
+    uint32_t n = (uint32_t)arg_number(&c, 3); void *props = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_update_props(x, pos, cur, n, props), mk_undefined(env));
+}
+FN(project) { /* (ctx, Float32Array(22), posRadius, strideVec4, n, projected, keys|null, payload|null, nPadded) */
+    ARGS(9); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
+    void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3), n = (uint32_t)arg_number(&c, 4);
+    void *proj = arg_dptr(&c, 5), *keys = arg_dptr(&c, 6), *pay = arg_dptr(&c, 7); uint32_t np = (uint32_t)arg_number(&c, 8); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_project(x, u, pr, st, n, proj, keys, pay, np), mk_undefined(env));
+}
+FN(extract_keys) {
+    ARGS(6); splat_ctx *x = arg_external(&c, 0); void *proj = arg_dptr(&c, 1); uint32_t n = (uint32_t)arg_number(&c, 2), np = (uint32_t)arg_number(&c, 3);
+    void *k = arg_dptr(&c, 4), *p = arg_dptr(&c, 5); BAIL;
+    return check(env, x, splat_extract_keys(x, proj, n, np, k, p), mk_undefined(env));
+}
+FN(sort_create) {
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); uint32_t cap = (uint32_t)arg_number(&c, 1); BAIL;
+    splat_sorter *s = NULL; int rc = splat_sort_create(x, cap, &s);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_external(env, s) : NULL);
+}
+FN(sort_destroy) { ARGS(1); splat_sort_destroy(arg_external(&c, 0)); return mk_undefined(env); }
+FN(sort_capacity) { ARGS(1); return mk_number(env, splat_sort_capacity(arg_external(&c, 0))); }
+FN(sort_keys) { ARGS(1); return mk_number(env, (double)(uintptr_t)splat_sort_keys(arg_external(&c, 0))); }
+FN(sort_payload) { ARGS(1); return mk_number(env, (double)(uintptr_t)splat_sort_payload(arg_external(&c, 0))); }
+FN(sort_sorted_payload) { ARGS(1); return mk_number(env, (double)(uintptr_t)splat_sort_sorted_payload(arg_external(&c, 0))); }
+FN(sort_sorted_keys) { ARGS(1); return mk_number(env, (double)(uintptr_t)splat_sort_sorted_keys(arg_external(&c, 0))); }
+FN(sort_run) { /* (ctx, sorter, n, bitBegin, bitEnd) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1);
+    uint32_t n = (uint32_t)arg_number(&c, 2), b0 = (uint32_t)arg_number(&c, 3), b1 = (uint32_t)arg_number(&c, 4); BAIL;
+    return check(env, x, splat_sort_run(s, n, b0, b1), mk_undefined(env));
+}
+FN(sort_set_mode) { ARGS(3); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); int m = (int)arg_number(&c, 2); BAIL; return check(env, x, splat_sort_set_mode(s, m), mk_undefined(env)); }
+FN(scan_u32) {
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); void *in = arg_dptr(&c, 1), *out = arg_dptr(&c, 2); uint32_t n = (uint32_t)arg_number(&c, 3);
+    void *tot = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_scan_u32(x, in, out, n, tot), mk_undefined(env));
+}
+FN(bin_create) {
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); uint32_t t = (uint32_t)arg_number(&c, 1); BAIL;
+    splat_binner *b = NULL; int rc = splat_bin_create(x, t, &b);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_external(env, b) : NULL);
+}
+FN(bin_destroy) { ARGS(1); splat_bin_destroy(arg_external(&c, 0)); return mk_undefined(env); }
+FN(bin_run) { /* (ctx, binner, projected, nSplats, sorted, nSorted, W, H, row0, row1) */
+    ARGS(10); splat_ctx *x = arg_external(&c, 0); splat_binner *b = arg_external(&c, 1); void *proj = arg_dptr(&c, 2);
+    uint32_t ns = (uint32_t)arg_number(&c, 3); void *sorted = arg_dptr(&c, 4); uint32_t nso = (uint32_t)arg_number(&c, 5);
+    uint32_t w = (uint32_t)arg_number(&c, 6), h = (uint32_t)arg_number(&c, 7), r0 = (uint32_t)arg_number(&c, 8), r1 = (uint32_t)arg_number(&c, 9); BAIL;
+    return check(env, x, splat_bin_run(b, proj, ns, sorted, nso, w, h, r0, r1), mk_undefined(env));
+}
+#define BIN_GETTER(jsname, cfn)                                                                        \
+    FN(jsname) {                                                                                       \
+        ARGS(2); splat_ctx *x = arg_external(&c, 0); splat_binner *b = arg_external(&c, 1); BAIL;      \
+        void *p = NULL; int rc = cfn(b, &p);                                                           \
+        return check(env, x, rc, mk_number(env, (double)(uintptr_t)p));                                \
+    }
+BIN_GETTER(bin_counts, splat_bin_counts)
+BIN_GETTER(bin_offsets, splat_bin_offsets)
+BIN_GETTER(bin_indices, splat_bin_indices)
+FN(bin_total) {
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); splat_binner *b = arg_external(&c, 1); BAIL;
+    uint64_t t = 0; int rc = splat_bin_total(b, &t);
+    return check(env, x, rc, mk_number(env, (double)t));
+}
+static void fill_cfg(call_t *c, size_t i, splat_composite_cfg *cfg) { /* [mode, earlyOut, tile, row0, row1] */
+    memset(cfg, 0, sizeof *cfg);
+    uint32_t v[5] = {0, 1, 16, 0, 0xffffffffu};
+    bool is = false;
+    napi_is_array(c->env, c->argv[i], &is);
+    if (is)
+        for (uint32_t k = 0; k < 5; ++k) {
+            napi_value e;
+            double d;
+            if (napi_get_element(c->env, c->argv[i], k, &e) == napi_ok && napi_get_value_double(c->env, e, &d) == napi_ok) v[k] = (uint32_t)d;
+        }
+    cfg->mode = v[0]; cfg->early_out = v[1]; cfg->tile_size = v[2]; cfg->tile_row0 = v[3]; cfg->tile_row1 = v[4];
+}
+FN(composite) { /* (ctx, cfg[5], color, cStride, normals, nStride, projected, indices, counts, offsets, W, H, out8|null, outF|null) */
+    ARGS(14); splat_ctx *x = arg_external(&c, 0); splat_composite_cfg cfg; fill_cfg(&c, 1, &cfg);
+    void *col = arg_dptr(&c, 2); uint32_t cs = (uint32_t)arg_number(&c, 3); void *nrm = arg_dptr(&c, 4); uint32_t ns = (uint32_t)arg_number(&c, 5);
+    void *proj = arg_dptr(&c, 6), *idx = arg_dptr(&c, 7), *cnt = arg_dptr(&c, 8), *off = arg_dptr(&c, 9);
+    uint32_t w = (uint32_t)arg_number(&c, 10), h = (uint32_t)arg_number(&c, 11); void *o8 = arg_dptr(&c, 12), *of = arg_dptr(&c, 13); BAIL;
+    return check(env, x, splat_composite(x, &cfg, col, cs, nrm, ns, proj, idx, cnt, off, w, h, o8, of, NULL), mk_undefined(env));
+}
+FN(render_frame) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), props, normals, n, W, H, projected, out8|null, outF|null) */
+    ARGS(13); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); splat_binner *b = arg_external(&c, 2);
+    splat_composite_cfg cfg; fill_cfg(&c, 3, &cfg); size_t ub = 0; float *u = arg_hostbuf(&c, 4, &ub);
+    void *props = arg_dptr(&c, 5), *nrm = arg_dptr(&c, 6); uint32_t n = (uint32_t)arg_number(&c, 7), w = (uint32_t)arg_number(&c, 8), h = (uint32_t)arg_number(&c, 9);
+    void *proj = arg_dptr(&c, 10), *o8 = arg_dptr(&c, 11), *of = arg_dptr(&c, 12); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_render_frame(x, s, b, &cfg, u, props, nrm, n, w, h, proj, o8, of), mk_undefined(env));
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+#define EXPORT(name) { #name, NULL, name, NULL, NULL, NULL, napi_enumerable, NULL }
+    napi_property_descriptor d[] = {
+        EXPORT(abi_version), EXPORT(ctx_create), EXPORT(ctx_destroy), EXPORT(sync), EXPORT(set_timing), EXPORT(stage_time_ms),
+        EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props),
+        EXPORT(project), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
+        EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
+        EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
+        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(composite), EXPORT(render_frame),
+    };
+    napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

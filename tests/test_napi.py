@@ -1,0 +1,89 @@
+"""The reference's own host language: JS classes over the N-API shim (splat_renderer_amd/napi).
+
+CPU part: the addon loads under Node, exports one function per ABI verb it wraps, throws a JS
+Error (never falls back) without a GPU, and its Camera matches the oracle bit for bit.
+GPU part: a whole frame driven stage by stage from JS equals the oracle's.
+"""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import make_case, oracle_pipeline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAPI = os.path.join(ROOT, "splat_renderer_amd", "napi")
+NODE = shutil.which("node")
+
+pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"),
+                                reason="node / N-API headers not present")
+
+
+def ensure_built():
+    if not os.path.exists(os.path.join(NAPI, "splat_napi.node")):
+        import __graft_entry__ as g
+        g.build()
+
+
+def node(script, *args):
+    return subprocess.run([NODE, "-e", script, *args], cwd=NAPI, capture_output=True, text=True, timeout=120)
+
+
+def test_addon_loads_and_exports():
+    ensure_built()
+    r = node("const a=require('./splat_napi.node');console.log(JSON.stringify({abi:a.abi_version(),names:Object.keys(a)}))")
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["abi"] == 1
+    for name in ("ctx_create", "project", "extract_keys", "sort_run", "scan_u32", "bin_run", "composite", "render_frame",
+                 "update_props", "buf_upload", "buf_download"):
+        assert name in d["names"]
+
+
+def test_js_camera_matches_oracle():
+    ensure_built()
+    r = node("const sr=require('./index.js');const c=new sr.Camera();c.setAspect(16/9);"
+             "console.log(JSON.stringify(Array.from(c.uniforms(1920,1080))))")
+    assert r.returncode == 0, r.stderr
+    u = np.array(json.loads(r.stdout), np.float32)
+    vp, eye = O.camera(aspect=16 / 9)
+    assert np.array_equal(u[:16].view(np.uint32), vp.view(np.uint32)) and np.array_equal(u[16:19], eye)
+    assert u[20] == 1920 and u[21] == 1080
+
+
+def test_js_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ensure_built()
+    r = node("const sr=require('./index.js');try{new sr.Device(0);console.log('NO THROW')}catch(e){console.log('threw '+e.message)}")
+    assert r.returncode == 0 and r.stdout.startswith("threw libsplat_hip -6"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_js_frame_matches_oracle(tmp_path):
+    ensure_built()
+    n, w, h = 4000, 208, 120
+    props, normals, u = make_case(n, w, h, 23, 1.5)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    _, want8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
+                              ref["offsets"], w, h)
+    props.tofile(tmp_path / "props.f32")
+    normals.tofile(tmp_path / "normals.f32")
+    r = subprocess.run([NODE, "render_frame.js", str(tmp_path / "props.f32"), str(tmp_path / "normals.f32"), str(n), str(w),
+                        str(h), str(tmp_path / "out.rgba8"), str(tmp_path / "order.u32"), str(tmp_path / "counts.u32"),
+                        str(tmp_path / "indices.u32")], cwd=NAPI, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert np.array_equal(np.array(info["uniforms"], np.float32).view(np.uint32), u.view(np.uint32))
+    assert info["pairs"] == ref["indices"].shape[0]
+    assert np.array_equal(np.fromfile(tmp_path / "order.u32", np.uint32), ref["order"])
+    assert np.array_equal(np.fromfile(tmp_path / "counts.u32", np.uint32), ref["counts"])
+    assert np.array_equal(np.fromfile(tmp_path / "indices.u32", np.uint32), ref["indices"])
+    got8 = np.fromfile(tmp_path / "out.rgba8", np.uint8).reshape(h, w, 4)
+    assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 3
+    assert (np.abs(got8.astype(int) - want8.astype(int)).max(axis=2) > 1).mean() <= 2e-3
