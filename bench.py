@@ -118,10 +118,17 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     def frame():
         r.render(u, pbuf, nbuf, None, width, height)
 
+    def stage_avg(sid):
+        cnt, tot = C.c_uint32(), C.c_double()
+        _lib.check(lib.splat_stage_time_stats(ctx, sid, C.byref(cnt), C.byref(tot)), ctx)
+        return tot.value / max(cnt.value, 1)
+
     for _ in range(args.warmup):
         frame()
     dev.sync()
-    # timed region: exactly K frames, HIP-event stage timing on (a few us per stage)
+    # timed region: exactly K frames; HIP events bracket ONLY the roofline kernel (k_composite) on
+    # the ctx stream, because every recorded stage costs ~10 us of stream idle per frame
+    _lib.check(lib.splat_set_timing_stages(ctx, 1 << _lib.STAGE_COMPOSITE), ctx)
     dev.setTiming(True)
     dev.sync()
     t0 = time.perf_counter()
@@ -129,15 +136,19 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
         frame()
     dev.sync()
     dt = time.perf_counter() - t0
-    stage_ms = {}
-    for sid, sname in enumerate(_lib.STAGE_NAMES[:4]):
-        cnt, tot = C.c_uint32(), C.c_double()
-        _lib.check(lib.splat_stage_time_stats(ctx, sid, C.byref(cnt), C.byref(tot)), ctx)
-        stage_ms[sname] = tot.value / max(cnt.value, 1)
+    composite_ms = stage_avg(_lib.STAGE_COMPOSITE)
     consumed = C.c_uint64()
     _lib.check(lib.splat_timing_consumed(ctx, C.byref(consumed)), ctx)
-    dev.setTiming(False)
     p_used = consumed.value / args.steps
+    # per-stage breakdown from a separate short loop with every stage's events on (not part of `value`)
+    _lib.check(lib.splat_set_timing_stages(ctx, 0xFFFFFFFF), ctx)
+    dev.setTiming(True)
+    for _ in range(min(args.steps, 10)):
+        frame()
+    dev.sync()
+    stage_ms = {sname: stage_avg(sid) for sid, sname in enumerate(_lib.STAGE_NAMES[:4])}
+    stage_ms["composite"] = composite_ms
+    dev.setTiming(False)
     pairs = r.binner.getTotalIndices()
 
     comp_bytes = composite_alg_bytes(p_used, width, height)

@@ -72,6 +72,10 @@ int splat_sync(splat_ctx *ctx);
 int splat_abi_version(void);
 /* Enable per-stage hipEvent timing (off by default: events cost a few us per stage). */
 int splat_set_timing(splat_ctx *ctx, int enabled);
+/* Restrict event recording to the stages whose bit (1 << stage id) is set (default: all).  Each
+ * recorded stage costs ~10 us of stream idle per frame, so a throughput measurement that only needs
+ * one kernel's duration enables only that stage. */
+int splat_set_timing_stages(splat_ctx *ctx, uint32_t stage_mask);
 /* Duration of the most recent run of `stage`; synchronises on that stage's end event. */
 int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);
 /* Every timed run of `stage` since timing was last enabled: number of samples and their summed

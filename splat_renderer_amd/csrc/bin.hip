@@ -18,55 +18,127 @@
 #include "common.h"
 #include "tile_range.h"
 
-struct splat_binner {
-    splat_ctx *ctx = nullptr;
-    uint32_t tile = 16;
-    uint32_t ntx = 0, nty = 0;
-    uint32_t tiles_cap = 0, splats_cap = 0;
-    uint32_t *counts = nullptr, *offsets = nullptr; // per tile
-    uint32_t *hits = nullptr;                       // per sorted position: #tiles, then exclusive pair offset
-    uint2 *ranges = nullptr;                        // per sorted position: packed clamped tile range
-    uint32_t *d_total = nullptr;
-    splat_sorter pairs;                             // (tileId, splatIdx) ping-pong buffers
-    uint64_t total = 0;
-    bool ran = false;
-};
+constexpr uint32_t BIN_THREADS = 256;
+constexpr uint32_t BIN_PER_THREAD = 2;
+constexpr uint32_t BIN_BLOCK = BIN_THREADS * BIN_PER_THREAD; // sorted positions per workgroup
+constexpr uint32_t BIN_STAGE_PAIRS = 4096;                   // pairs staged in LDS for coalesced stores (32 KB)
 
-__global__ __launch_bounds__(256) void k_bin_count(const float4 *__restrict__ projected, uint32_t n_splats,
-                                                   const uint32_t *__restrict__ sorted, uint32_t n_sorted, uint32_t width,
-                                                   uint32_t height, uint32_t tile, uint32_t ntx, uint32_t nty, uint32_t row0,
-                                                   uint32_t row1, uint32_t *__restrict__ hits, uint2 *__restrict__ ranges) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_sorted) return;
-    uint32_t s = sorted[i];
-    uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0, h = 0;
-    if (s < n_splats) { // 0xFFFFFFFF padding bins nowhere
-        float4 b = projected[(size_t)s * 2];
-        if (tile_range(b, width, height, tile, ntx, nty, row0, row1, tx0, tx1, ty0, ty1)) {
-            h = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-        }
-    }
-    hits[i] = h;
-    ranges[i] = make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
+__device__ __forceinline__ uint32_t range_hits(uint2 r) {
+    const uint32_t tx0 = r.x & 0xffffu, tx1 = r.x >> 16, ty0 = r.y & 0xffffu, ty1 = r.y >> 16;
+    return (tx0 > tx1 || ty0 > ty1) ? 0u : (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
 }
 
-__global__ __launch_bounds__(256) void k_bin_expand(const uint32_t *__restrict__ sorted, uint32_t n_sorted,
-                                                    const uint32_t *__restrict__ pair_off, const uint2 *__restrict__ ranges,
-                                                    uint32_t ntx, uint32_t *__restrict__ pair_tile,
-                                                    uint32_t *__restrict__ pair_splat) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_sorted) return;
-    uint2 r = ranges[i];
-    uint32_t tx0 = r.x & 0xffffu, tx1 = r.x >> 16, ty0 = r.y & 0xffffu, ty1 = r.y >> 16;
-    if (tx0 > tx1 || ty0 > ty1) return;
-    uint32_t s = sorted[i];
-    uint32_t o = pair_off[i];
-    for (uint32_t ty = ty0; ty <= ty1; ++ty)
-        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-            pair_tile[o] = ty * ntx + tx;
-            pair_splat[o] = s;
-            ++o;
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *wsum) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// count: every sorted position gets its clamped tile range (gathered per splat: 16 B of bounds, or
+// the 4 B range32 the projector wrote on the frame path) and every 512-position block its pair count.
+template <bool FROM_RANGE32>
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const float4 *__restrict__ projected,
+                                                           const uint32_t *__restrict__ range32, uint32_t n_splats,
+                                                           const uint32_t *__restrict__ sorted, uint32_t n_sorted, BinParams bp,
+                                                           uint2 *__restrict__ ranges, uint32_t *__restrict__ blocksums) {
+    __shared__ uint32_t wsum[4];
+    uint32_t local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * BIN_BLOCK + k * BIN_THREADS + threadIdx.x;
+        if (i < n_sorted) {
+            const uint32_t s = sorted[i];
+            uint32_t tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
+            if (s < n_splats) { // 0xFFFFFFFF padding bins nowhere
+                if (FROM_RANGE32) {
+                    const uint32_t r = range32[s];
+                    tx0 = r & 0xffu; tx1 = (r >> 8) & 0xffu; ty0 = (r >> 16) & 0xffu; ty1 = r >> 24;
+                } else {
+                    const float4 b = projected[(size_t)s * 2];
+                    if (!tile_range(b, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1)) {
+                        tx0 = 1; tx1 = 0; ty0 = 1; ty1 = 0;
+                    }
+                }
+            }
+            const uint2 r = make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
+            ranges[i] = r;
+            local += range_hits(r);
         }
+    }
+    const uint32_t total = block_sum(local, wsum);
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
+}
+
+// expand: the (tile id, splat idx) pairs of a block land in [block_base, block_base + block_total) in
+// sorted order: position-major (k * 256 + thread), then row-major over the splat's tile rectangle.
+// Small blocks are staged in LDS so that the global stores are contiguous runs.
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__restrict__ sorted, uint32_t n_sorted,
+                                                            const uint2 *__restrict__ ranges,
+                                                            const uint32_t *__restrict__ block_base, uint32_t ntx,
+                                                            uint32_t *__restrict__ pair_tile, uint32_t *__restrict__ pair_splat) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint2 stage[BIN_STAGE_PAIRS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint2 r[BIN_PER_THREAD];
+    uint32_t s[BIN_PER_THREAD], h[BIN_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * BIN_BLOCK + k * BIN_THREADS + tid;
+        r[k] = make_uint2(1u, 1u); // empty
+        s[k] = 0;
+        if (i < n_sorted) {
+            r[k] = ranges[i];
+            s[k] = sorted[i];
+        }
+        h[k] = range_hits(r[k]);
+    }
+    // exclusive offsets inside the block, position-major: all k = 0 positions, then all k = 1 ...
+    uint32_t off[BIN_PER_THREAD];
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_PER_THREAD; ++k) {
+        uint32_t incl = h[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
+        __syncthreads();
+        off[k] = carry + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - h[k];
+        carry += s0 + s1 + s2 + s3;
+    }
+    const uint32_t total = carry, base = block_base[blockIdx.x];
+    if (total == 0) return;
+    const bool staged = total <= BIN_STAGE_PAIRS;
+#pragma unroll
+    for (uint32_t k = 0; k < BIN_PER_THREAD; ++k) {
+        if (h[k] == 0) continue;
+        const uint32_t tx0 = r[k].x & 0xffffu, tx1 = r[k].x >> 16, ty0 = r[k].y & 0xffffu, ty1 = r[k].y >> 16;
+        uint32_t o = off[k];
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                if (staged) {
+                    stage[o] = make_uint2(ty * ntx + tx, s[k]);
+                } else {
+                    pair_tile[base + o] = ty * ntx + tx;
+                    pair_splat[base + o] = s[k];
+                }
+                ++o;
+            }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t o = tid; o < total; o += BIN_THREADS) {
+            const uint2 p = stage[o];
+            pair_tile[base + o] = p.x;
+            pair_splat[base + o] = p.y;
+        }
+    }
 }
 
 // Tile offsets from the tile-sorted pair keys: the thread at the first pair of tile t writes
@@ -95,9 +167,9 @@ __global__ __launch_bounds__(256) void k_tile_counts(const uint32_t *__restrict_
 static void binner_free(splat_binner *b) {
     if (b->counts) (void)hipFree(b->counts);
     if (b->offsets) (void)hipFree(b->offsets);
-    if (b->hits) (void)hipFree(b->hits);
+    if (b->blocksums) (void)hipFree(b->blocksums);
     if (b->ranges) (void)hipFree(b->ranges);
-    b->counts = b->offsets = b->hits = nullptr;
+    b->counts = b->offsets = b->blocksums = nullptr;
     b->ranges = nullptr;
     b->tiles_cap = b->splats_cap = 0;
 }
@@ -110,6 +182,109 @@ static void sorter_free_members(splat_sorter *s) {
     if (s->hist) (void)hipFree(s->hist);
     s->keys = s->keys_b = s->payload = s->payload_b = s->hist = nullptr;
     s->capacity = 0;
+}
+
+int binner_reserve_range32(splat_binner *b, uint32_t n_splats) {
+    splat_ctx *ctx = b->ctx;
+    if (n_splats <= b->range32_cap) return SPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->range32) (void)hipFree(b->range32);
+    b->range32 = nullptr;
+    b->range32_cap = 0;
+    if (hipMalloc((void **)&b->range32, (size_t)n_splats * 4 + 16) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
+    b->range32_cap = n_splats;
+    return SPLAT_OK;
+}
+
+// binSplats.  range32 (optional): per splat index, the packed range the projector computed with the
+// same BinParams (frame path); otherwise ranges are derived from the projected bounds here.
+int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
+               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32) {
+    splat_ctx *ctx = b->ctx;
+    ARG_CHECK(ctx, width >= 1 && height >= 1);
+    ARG_CHECK(ctx, n_sorted == 0 || (projected && sorted));
+    const uint32_t ntx = div_up(width, b->tile), nty = div_up(height, b->tile); // GPUTileBinner.ts:198-200
+    ARG_CHECK(ctx, ntx <= 65535 && nty <= 65535 && (uint64_t)ntx * nty <= (1u << 24));
+    const uint32_t tiles = ntx * nty;
+    if (tile_row1 > nty) tile_row1 = nty;
+    if (tile_row0 > tile_row1) tile_row0 = tile_row1;
+    const uint32_t blocks = div_up(n_sorted, BIN_BLOCK);
+
+    if (tiles > b->tiles_cap || n_sorted > b->splats_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t tc = tiles > b->tiles_cap ? tiles : b->tiles_cap;
+        uint32_t sc = n_sorted > b->splats_cap ? n_sorted : b->splats_cap;
+        binner_free(b);
+        if (hipMalloc((void **)&b->counts, (size_t)tc * 4 + 16) != hipSuccess ||
+            hipMalloc((void **)&b->offsets, (size_t)tc * 4 + 16) != hipSuccess ||
+            hipMalloc((void **)&b->blocksums, (size_t)div_up(sc, BIN_BLOCK) * 4 + 16) != hipSuccess ||
+            hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess) {
+            binner_free(b);
+            return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
+        }
+        b->tiles_cap = tc;
+        b->splats_cap = sc;
+    }
+    b->ntx = ntx;
+    b->nty = nty;
+    b->ran = false;
+    const BinParams bp = {width, height, b->tile, ntx, nty, tile_row0, tile_row1};
+
+    stage_begin(ctx, SPLAT_STAGE_BIN);
+    uint32_t total32 = 0;
+    int rc = SPLAT_OK;
+    if (n_sorted > 0) {
+        if (range32)
+            hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
+                               n_splats, (const uint32_t *)sorted, n_sorted, bp, b->ranges, b->blocksums);
+        else
+            hipLaunchKernelGGL(k_bin_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected,
+                               nullptr, n_splats, (const uint32_t *)sorted, n_sorted, bp, b->ranges, b->blocksums);
+        LAUNCH_CHECK(ctx, "k_bin_count");
+        rc = scan_exclusive_u32(ctx, b->blocksums, b->blocksums, blocks, b->d_total); // PrefixSumScanner.scan :296-303
+        if (rc != SPLAT_OK) return rc;
+        // the one host round trip of the frame: the pair total sizes the fill (the reference reads
+        // back all T counts here: GPUTileBinner.ts:244-263)
+        rc = ctx_ensure_pinned(ctx, 16);
+        if (rc != SPLAT_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, b->d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        total32 = *(volatile uint32_t *)ctx->pinned;
+    }
+    b->total = total32;
+    if (total32 > 0) {
+        if (total32 > b->pairs.capacity) {
+            uint64_t want = (uint64_t)total32 + total32 / 4 + 4096;
+            if (want > 0x3ffff000ull) want = 0x3ffff000ull;
+            if (total32 > want) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "binSplats: more than 2^30 tile-splat pairs");
+            rc = sorter_reserve(&b->pairs, (uint32_t)want);
+            if (rc != SPLAT_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
+                           b->ranges, b->blocksums, ntx, b->pairs.keys, b->pairs.payload);
+        LAUNCH_CHECK(ctx, "k_bin_expand");
+        uint32_t bits = 1;
+        while ((1u << bits) < tiles) ++bits;
+        rc = radix_sort_pairs(ctx, b->pairs.keys, b->pairs.payload, b->pairs.keys_b, b->pairs.payload_b, b->pairs.hist,
+                              total32, 0, bits, &b->pairs.result_in_primary);
+        if (rc != SPLAT_OK) return rc;
+        const uint32_t *sorted_tiles = b->pairs.result_in_primary ? b->pairs.keys : b->pairs.keys_b;
+        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(total32, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, tiles,
+                           b->offsets);
+        LAUNCH_CHECK(ctx, "k_tile_offsets");
+        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts);
+        LAUNCH_CHECK(ctx, "k_tile_counts");
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(b->counts, 0, (size_t)tiles * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(b->offsets, 0, (size_t)(tiles + 1) * 4, ctx->stream));
+        if (b->pairs.capacity == 0) {
+            rc = sorter_reserve(&b->pairs, 1); // so getTileIndicesBuffer() has something to return ("at least 4 bytes" :288)
+            if (rc != SPLAT_OK) return rc;
+        }
+    }
+    stage_end(ctx, SPLAT_STAGE_BIN);
+    b->ran = true;
+    return SPLAT_OK;
 }
 
 extern "C" {
@@ -137,93 +312,14 @@ void splat_bin_destroy(splat_binner *b) {
     binner_free(b);
     sorter_free_members(&b->pairs);
     if (b->d_total) (void)hipFree(b->d_total);
+    if (b->range32) (void)hipFree(b->range32);
     delete b;
 }
 
 int splat_bin_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted,
                   uint32_t width, uint32_t height, uint32_t tile_row0, uint32_t tile_row1) {
     if (!b) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner is NULL");
-    splat_ctx *ctx = b->ctx;
-    ARG_CHECK(ctx, width >= 1 && height >= 1);
-    ARG_CHECK(ctx, n_sorted == 0 || (projected && sorted));
-    const uint32_t ntx = div_up(width, b->tile), nty = div_up(height, b->tile); // GPUTileBinner.ts:198-200
-    ARG_CHECK(ctx, ntx <= 65535 && nty <= 65535 && (uint64_t)ntx * nty <= (1u << 24));
-    const uint32_t tiles = ntx * nty;
-    if (tile_row1 > nty) tile_row1 = nty;
-    if (tile_row0 > tile_row1) tile_row0 = tile_row1;
-
-    if (tiles > b->tiles_cap || n_sorted > b->splats_cap) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        uint32_t tc = tiles > b->tiles_cap ? tiles : b->tiles_cap;
-        uint32_t sc = n_sorted > b->splats_cap ? n_sorted : b->splats_cap;
-        binner_free(b);
-        if (hipMalloc((void **)&b->counts, (size_t)tc * 4 + 16) != hipSuccess ||
-            hipMalloc((void **)&b->offsets, (size_t)tc * 4 + 16) != hipSuccess ||
-            hipMalloc((void **)&b->hits, (size_t)sc * 4 + 16) != hipSuccess ||
-            hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess) {
-            binner_free(b);
-            return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
-        }
-        b->tiles_cap = tc;
-        b->splats_cap = sc;
-    }
-    b->ntx = ntx;
-    b->nty = nty;
-    b->ran = false;
-
-    stage_begin(ctx, SPLAT_STAGE_BIN);
-    uint32_t total32 = 0;
-    if (n_sorted > 0) {
-        hipLaunchKernelGGL(k_bin_count, dim3(div_up(n_sorted, 256)), dim3(256), 0, ctx->stream, (const float4 *)projected,
-                           n_splats, (const uint32_t *)sorted, n_sorted, width, height, b->tile, ntx, nty, tile_row0,
-                           tile_row1, b->hits, b->ranges);
-        LAUNCH_CHECK(ctx, "k_bin_count");
-        int rc = scan_exclusive_u32(ctx, b->hits, b->hits, n_sorted, b->d_total);
-        if (rc != SPLAT_OK) return rc;
-    }
-    int rc = SPLAT_OK;
-    if (n_sorted > 0) {
-        // the one host round trip of the frame: the pair total sizes the fill (the reference reads
-        // back all T counts here: GPUTileBinner.ts:244-263)
-        rc = ctx_ensure_pinned(ctx, 16);
-        if (rc != SPLAT_OK) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, b->d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        total32 = *(volatile uint32_t *)ctx->pinned;
-    }
-    b->total = total32;
-    if (total32 > 0) {
-        if (total32 > b->pairs.capacity) {
-            uint64_t want = (uint64_t)total32 + total32 / 4 + 4096;
-            if (want > 0xfffff000ull) want = 0xfffff000ull;
-            rc = sorter_reserve(&b->pairs, (uint32_t)want);
-            if (rc != SPLAT_OK) return rc;
-        }
-        hipLaunchKernelGGL(k_bin_expand, dim3(div_up(n_sorted, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)sorted,
-                           n_sorted, b->hits, b->ranges, ntx, b->pairs.keys, b->pairs.payload);
-        LAUNCH_CHECK(ctx, "k_bin_expand");
-        uint32_t bits = 1;
-        while ((1u << bits) < tiles) ++bits;
-        rc = radix_sort_pairs(ctx, b->pairs.keys, b->pairs.payload, b->pairs.keys_b, b->pairs.payload_b, b->pairs.hist,
-                              total32, 0, bits, &b->pairs.result_in_primary);
-        if (rc != SPLAT_OK) return rc;
-        const uint32_t *sorted_tiles = b->pairs.result_in_primary ? b->pairs.keys : b->pairs.keys_b;
-        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(total32, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, tiles,
-                           b->offsets);
-        LAUNCH_CHECK(ctx, "k_tile_offsets");
-        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts);
-        LAUNCH_CHECK(ctx, "k_tile_counts");
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(b->counts, 0, (size_t)tiles * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(b->offsets, 0, (size_t)(tiles + 1) * 4, ctx->stream));
-        if (b->pairs.capacity == 0) {
-            rc = sorter_reserve(&b->pairs, 1); // so getTileIndicesBuffer() has something to return ("at least 4 bytes" :288)
-            if (rc != SPLAT_OK) return rc;
-        }
-    }
-    stage_end(ctx, SPLAT_STAGE_BIN);
-    b->ran = true;
-    return SPLAT_OK;
+    return binner_run(b, projected, n_splats, sorted, n_sorted, width, height, tile_row0, tile_row1, nullptr);
 }
 
 uint32_t splat_bin_tile_size(const splat_binner *b) { return b ? b->tile : 0; }

@@ -23,6 +23,7 @@ struct splat_ctx {
     bool own_stream = false;
     std::string err;
     bool timing = false;
+    uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars
     void *scan_ws = nullptr;
@@ -84,3 +85,32 @@ struct splat_sorter {
 
 // grows the sorter's buffers (contents are NOT preserved)
 int sorter_reserve(splat_sorter *s, uint32_t capacity);
+
+struct splat_binner {
+    splat_ctx *ctx = nullptr;
+    uint32_t tile = 16;
+    uint32_t ntx = 0, nty = 0;
+    uint32_t tiles_cap = 0, splats_cap = 0, range32_cap = 0;
+    uint32_t *counts = nullptr, *offsets = nullptr; // per tile
+    uint32_t *blocksums = nullptr;                  // pairs per 512-position block, then their exclusive scan
+    uint2 *ranges = nullptr;                        // per sorted position: packed clamped tile range
+    uint32_t *range32 = nullptr;                    // per splat INDEX: 8-bit packed range written by the projector (frame path)
+    uint32_t *d_total = nullptr;
+    splat_sorter pairs;                             // (tileId, splatIdx) ping-pong buffers
+    uint64_t total = 0;
+    bool ran = false;
+};
+
+// Tile-range parameters handed to the projector so that it can emit range32[] (frame path)
+struct BinParams {
+    uint32_t width, height, tile, ntx, nty, row0, row1;
+};
+
+// bin.hip internals used by frame.hip
+int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
+int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
+               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32);
+// project.hip internal: the projector with the optional per-index tile range output
+int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
+                   uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
+                   const BinParams *bp);

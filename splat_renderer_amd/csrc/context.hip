@@ -48,7 +48,7 @@ int ctx_ensure_pinned(splat_ctx *ctx, size_t bytes) {
 }
 
 void stage_begin(splat_ctx *ctx, int stage) {
-    if (!ctx->timing) return;
+    if (!ctx->timing || !((ctx->timing_mask >> stage) & 1u)) return;
     StageTimer &t = ctx->timers[stage];
     if (t.used == t.beg.size()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -61,7 +61,7 @@ void stage_begin(splat_ctx *ctx, int stage) {
 }
 
 void stage_end(splat_ctx *ctx, int stage) {
-    if (!ctx->timing) return;
+    if (!ctx->timing || !((ctx->timing_mask >> stage) & 1u)) return;
     StageTimer &t = ctx->timers[stage];
     if (t.used >= t.beg.size()) return;
     (void)hipEventRecord(t.end[t.used], ctx->stream);
@@ -145,6 +145,12 @@ int splat_set_timing(splat_ctx *ctx, int enabled) {
             return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counter hipMalloc");
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, 16, ctx->stream));
     }
+    return SPLAT_OK;
+}
+
+int splat_set_timing_stages(splat_ctx *ctx, uint32_t stage_mask) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ctx->timing_mask = stage_mask;
     return SPLAT_OK;
 }
 

@@ -77,12 +77,29 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
     ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && normals && projected);
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner));
     if (n > splat_sort_capacity(sorter)) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_render_frame: n exceeds the sorter's capacity");
-    // SplatProjector.project + DepthKeyExtractor.extract fused; props is the interleaved buffer
-    int rc = splat_project(ctx, uniforms, props, 2, n, projected, splat_sort_keys(sorter), splat_sort_payload(sorter), n);
+    ARG_CHECK(ctx, width >= 1 && height >= 1);
+    // SplatProjector.project + DepthKeyExtractor.extract fused; props is the interleaved buffer.
+    // When tile coordinates fit 8 bits the projector also emits each splat's clamped tile range,
+    // which turns the binner's 16-byte bounds gather (in sorted order) into a 4-byte one.
+    const uint32_t tile = splat_bin_tile_size(binner);
+    const uint32_t ntx = div_up(width, tile), nty = div_up(height, tile);
+    uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
+    if (row0 > row1) row0 = row1;
+    const bool fast = ntx <= 256 && nty <= 256 && n > 0;
+    int rc = SPLAT_OK;
+    uint32_t *range32 = nullptr;
+    const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
+    if (fast) {
+        rc = binner_reserve_range32(binner, n);
+        if (rc != SPLAT_OK) return rc;
+        range32 = binner->range32;
+    }
+    ARG_CHECK(ctx, (((uintptr_t)props | (uintptr_t)projected) & 15) == 0);
+    rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), splat_sort_payload(sorter), n, range32, &bp);
     if (rc != SPLAT_OK) return rc;
     rc = splat_sort_run(sorter, n, 0, 32); // RadixSorter.sort()
     if (rc != SPLAT_OK) return rc;
-    rc = splat_bin_run(binner, projected, n, splat_sort_sorted_payload(sorter), n, width, height, cfg->tile_row0, cfg->tile_row1);
+    rc = binner_run(binner, projected, n, splat_sort_sorted_payload(sorter), n, width, height, row0, row1, range32);
     if (rc != SPLAT_OK) return rc;
     void *counts, *offsets, *indices;
     if ((rc = splat_bin_counts(binner, &counts)) != SPLAT_OK) return rc;

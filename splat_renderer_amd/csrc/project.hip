@@ -10,6 +10,7 @@
 // This file is compiled with -ffp-contract=off: every float op below is one IEEE binary32 op in
 // the order written, identical to oracle/oracle.c, so records and keys are bit-exact.
 #include "common.h"
+#include "tile_range.h"
 
 struct FrameUniforms {
     float m[16];   // VP, column-major
@@ -33,11 +34,11 @@ __device__ __forceinline__ uint32_t depth_key(float depth) {
     return bits ^ mask;
 }
 
-template <bool WITH_KEYS>
+template <bool WITH_KEYS, bool WITH_RANGE>
 __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
                                                  uint32_t stride_vec4, uint32_t n, uint32_t n_padded, uint32_t index_base,
                                                  float4 *__restrict__ projected, uint32_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ payload) {
+                                                 uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, BinParams bp) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) {
         if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
@@ -72,6 +73,12 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
         keys[i] = depth_key(depth);
         payload[i] = index_base + i;
     }
+    if (WITH_RANGE) { // the binner's clamped tile range while the bounds are still in registers:
+        // after the sort it is then a 4-byte gather instead of a 16-byte one
+        uint32_t tx0, tx1, ty0, ty1;
+        const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
+        range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_extract_keys(const float4 *__restrict__ projected, uint32_t n, uint32_t n_padded,
@@ -97,6 +104,33 @@ __global__ __launch_bounds__(256) void k_update_props(const float4 *__restrict__
     props[(size_t)i * 2 + 1] = make_float4(fabsf(c.x) * 0.8f + 0.2f, fabsf(c.y) * 0.8f + 0.2f, fabsf(c.z) * 0.8f + 0.2f, 1.0f); // :97-101
 }
 
+int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
+                   uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
+                   const BinParams *bp) {
+    FrameUniforms u;
+    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
+    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
+    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
+    const uint32_t work = keys ? n_padded : n;
+    if (work == 0) return SPLAT_OK;
+    BinParams none = {0, 0, 1, 0, 0, 0, 0};
+    const float4 *src = (const float4 *)pos_radius + (size_t)index_base * pr_stride_vec4;
+    stage_begin(ctx, SPLAT_STAGE_PROJECT);
+    dim3 grid(div_up(work, 256)), block(256);
+    if (keys && range32)
+        hipLaunchKernelGGL((k_project<true, true>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, index_base,
+                           (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, range32, *bp);
+    else if (keys)
+        hipLaunchKernelGGL((k_project<true, false>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, index_base,
+                           (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, nullptr, none);
+    else
+        hipLaunchKernelGGL((k_project<false, false>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n, index_base,
+                           (float4 *)projected, nullptr, nullptr, nullptr, none);
+    LAUNCH_CHECK(ctx, "k_project");
+    stage_end(ctx, SPLAT_STAGE_PROJECT);
+    return SPLAT_OK;
+}
+
 extern "C" {
 
 int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
@@ -107,23 +141,7 @@ int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
     ARG_CHECK(ctx, (keys == nullptr) == (payload == nullptr));
     ARG_CHECK(ctx, keys == nullptr || n_padded >= n);
     ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected) & 15) == 0);
-    FrameUniforms u;
-    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
-    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
-    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
-    uint32_t work = keys ? n_padded : n;
-    if (work == 0) return SPLAT_OK;
-    stage_begin(ctx, SPLAT_STAGE_PROJECT);
-    dim3 grid(div_up(work, 256)), block(256);
-    if (keys)
-        hipLaunchKernelGGL(k_project<true>, grid, block, 0, ctx->stream, u, (const float4 *)pos_radius, pr_stride_vec4, n,
-                           n_padded, 0u, (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload);
-    else
-        hipLaunchKernelGGL(k_project<false>, grid, block, 0, ctx->stream, u, (const float4 *)pos_radius, pr_stride_vec4, n,
-                           n, 0u, (float4 *)projected, nullptr, nullptr);
-    LAUNCH_CHECK(ctx, "k_project");
-    stage_end(ctx, SPLAT_STAGE_PROJECT);
-    return SPLAT_OK;
+    return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, n, 0, projected, keys, payload, n_padded, nullptr, nullptr);
 }
 
 int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t first,
@@ -131,18 +149,8 @@ int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_r
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, uniforms && (count == 0 || (pos_radius && projected_slice)) && pr_stride_vec4 >= 1);
     ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected_slice) & 15) == 0);
-    if (count == 0) return SPLAT_OK;
-    FrameUniforms u;
-    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
-    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
-    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
-    stage_begin(ctx, SPLAT_STAGE_PROJECT);
-    const float4 *src = (const float4 *)pos_radius + (size_t)first * pr_stride_vec4;
-    hipLaunchKernelGGL(k_project<false>, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream, u, src, pr_stride_vec4, count,
-                       count, first, (float4 *)projected_slice, nullptr, nullptr);
-    LAUNCH_CHECK(ctx, "k_project(slice)");
-    stage_end(ctx, SPLAT_STAGE_PROJECT);
-    return SPLAT_OK;
+    return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, count, first, projected_slice, nullptr, nullptr, 0, nullptr,
+                          nullptr);
 }
 
 int splat_extract_keys(splat_ctx *ctx, const void *projected, uint32_t n, uint32_t n_padded, void *keys, void *payload) {

@@ -36,3 +36,9 @@ __device__ __forceinline__ bool tile_range(float4 bounds, uint32_t width, uint32
     return ty0 <= ty1;
 }
 
+
+// 8-bit packed tile range (frame path, ntx and nty <= 256): tx0 | tx1<<8 | ty0<<16 | ty1<<24.
+// An empty range is encoded with tx0 = 1 > tx1 = 0.
+__device__ __forceinline__ uint32_t pack_range32(bool ok, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1) {
+    return ok ? (tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24)) : 1u;
+}
