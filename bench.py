@@ -100,7 +100,7 @@ def main():
     u = cam.uniforms(width, height)
     workload = f"{name}: {n} synthetic Gaussians @{width}x{height}, {tile}x{tile} tiles"
 
-    if world == 1:
+    if world == 1 and "RANK" not in os.environ:
         result = run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload)
     else:
         result = run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world)
@@ -191,7 +191,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     import torch
     import torch.distributed as td
     torch.cuda.set_device(local_rank)
-    td.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if not td.is_initialized():
+        td.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     per = dist.shard_size(n, world)
     stages = dist.HipStages(torch, local_rank, per * world, width, height, tile)
     pt = torch.from_numpy(props).cuda()
@@ -201,8 +202,15 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     def frame():
         br.render(u, pt.data_ptr(), nt.data_ptr())
 
-    for _ in range(args.warmup):
+    # warm-up: the first frame also calibrates the bands (equal pairs per band instead of equal rows:
+    # the centre rows of this scene are denser)
+    frame()
+    torch.cuda.synchronize()
+    rows_hist = br.rebalance(lambda t: td.all_reduce(t, op=td.ReduceOp.SUM))
+    for _ in range(max(args.warmup - 1, 1)):
         frame()
+    stages.consumed = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
     torch.cuda.synchronize()
     td.barrier()
     torch.cuda.synchronize()
@@ -216,19 +224,34 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     td.all_reduce(tmax, op=td.ReduceOp.MAX)
     dt = float(tmax.item())
-    kept = torch.tensor([stages.kept], dtype=torch.int64, device="cuda")
-    kept_all = [torch.zeros_like(kept) for _ in range(world)]
-    td.all_gather(kept_all, kept)
+    comp_ms = stages.stage_avg_ms(_lib.STAGE_COMPOSITE)
+    p_used = int(stages.consumed[0].item()) / args.steps
+    stages.set_timing(False)
+    r0, r1 = br.pixel_rows()
+    info = torch.tensor([stages.kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6)], dtype=torch.int64, device="cuda")
+    infos = [torch.zeros_like(info) for _ in range(world)]
+    td.all_gather(infos, info)
+    infos = [[int(v) for v in t.tolist()] for t in infos]
+    # roofline of the dominant kernel on the slowest rank's composite (per launch = per band)
+    slow = max(range(world), key=lambda k: infos[k][4])
+    rows_px = min(infos[slow][2] * tile, height) - infos[slow][1] * tile
+    comp_bytes = composite_alg_bytes(infos[slow][3], width, rows_px)
+    achieved = comp_bytes / (infos[slow][4] / 1e9) / 1e9 if infos[slow][4] else 0.0
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
         "frames_per_s": args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
-                   "parallelism": f"tile-row bands x{world} + 1 RCCL all-gather of {per * 32} B shards per frame",
-                   "splats_kept_per_rank": [int(k.item()) for k in kept_all],
+                   "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * 32} B "
+                                  f"shards per frame",
+                   "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
+                                 "composite_ms": i[4] / 1e6} for i in infos],
                    "composite": "front-to-back, early-out at alpha>=0.99"},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": comp_bytes,
+                     "avg_launch_ms": infos[slow][4] / 1e6, "rank": slow},
+        "cpu_baseline": None,  # reported at N=1 only
     }
     td.barrier()
     stages.destroy()

@@ -44,6 +44,30 @@ def band_rows(nty, rank, world):
     return nty * rank // world, nty * (rank + 1) // world
 
 
+def balanced_rows(row_weights, world):
+    """Band boundaries [r0, r1) per rank so that every band carries about the same weight (e.g. the
+    tile-splat pairs of its rows) — the uniform-cube scene is denser in the centre rows.  Every rank
+    computes this from the same all-reduced histogram, so all ranks agree; every band gets at least
+    one row while rows remain.  Returns a list of (r0, r1)."""
+    w = np.asarray(row_weights, dtype=np.float64)
+    nty = w.shape[0]
+    if world >= nty:
+        return [(min(r, nty), min(r + 1, nty)) for r in range(world)]
+    cum = np.concatenate([[0.0], np.cumsum(w + 1e-9)])  # strictly increasing
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(cum, total * r / world, side="left"))
+        # nearest boundary to the ideal cut, keeping at least one row per band on both sides
+        if c > 0 and abs(cum[c - 1] - total * r / world) < abs(cum[c] - total * r / world):
+            c -= 1
+        c = max(c, cuts[-1] + 1)
+        c = min(c, nty - (world - r))
+        cuts.append(c)
+    cuts.append(nty)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 class HipStages:
     """Device work of one rank through the C ABI.  Tensors are torch CUDA tensors; the splat ctx
     is created on torch's current stream so that RCCL's stream dependencies order the exchange."""
@@ -67,6 +91,25 @@ class HipStages:
         self.mode, self.early_out = mode, early_out
         self.kept = 0
         self.pairs = 0
+        self.consumed = None  # optional torch int64[1]: list entries staged by the composite
+
+    def set_timing(self, enabled, stage_mask=0xFFFFFFFF):
+        check(self.lib.splat_set_timing_stages(self.ctx, stage_mask), self.ctx)
+        check(self.lib.splat_set_timing(self.ctx, int(enabled)), self.ctx)
+
+    def stage_avg_ms(self, stage):
+        cnt, tot = C.c_uint32(), C.c_double()
+        check(self.lib.splat_stage_time_stats(self.ctx, stage, C.byref(cnt), C.byref(tot)), self.ctx)
+        return tot.value / max(cnt.value, 1)
+
+    def row_pairs(self):
+        """Tile-splat pairs per tile row of the last band_frame (zeros outside the band)."""
+        ntx, nty = -(-self.width // self.tile), -(-self.height // self.tile)
+        counts = C.c_void_p()
+        check(self.lib.splat_bin_counts(self.binner, C.byref(counts)), self.ctx)
+        host = np.empty(ntx * nty, np.uint32)
+        check(self.lib.splat_buf_download(self.ctx, host.ctypes.data, counts, host.nbytes), self.ctx)
+        return host.reshape(nty, ntx).sum(axis=1).astype(np.int64)
 
     def new_records(self, count, fill_nan=False):
         t = self.torch.empty((count, REC_FLOATS), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
@@ -97,7 +140,8 @@ class HipStages:
         check(lib.splat_bin_indices(self.binner, C.byref(indices)), ctx)
         cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1)
         check(lib.splat_composite(ctx, C.byref(cfg), props_ptr + 16, 2, normals_ptr, 1, records.data_ptr(), indices, counts,
-                                  offsets, self.width, self.height, out_image.data_ptr(), None, None), ctx)
+                                  offsets, self.width, self.height, out_image.data_ptr(), None,
+                                  self.consumed.data_ptr() if self.consumed is not None else None), ctx)
 
     def destroy(self):
         self.lib.splat_bin_destroy(self.binner)
@@ -129,6 +173,18 @@ class BandRenderer:
             self.all_gather(self.gathered, self.shard)
         st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image)
         return self.image
+
+    def rebalance(self, all_reduce_sum):
+        """Re-cut the bands from the pairs-per-row histogram of the frame just rendered.
+        all_reduce_sum(tensor) sums an int64 tensor over ranks in place (torch.distributed.all_reduce)."""
+        rows = self.stages.row_pairs()
+        t = self.stages.torch.from_numpy(rows)
+        if self.world > 1:
+            t = t.to(self.gathered.device)
+            all_reduce_sum(t)
+            rows = t.cpu().numpy()
+        self.row0, self.row1 = balanced_rows(rows, self.world)[self.rank]
+        return rows
 
     def pixel_rows(self):
         return self.row0 * self.tile, min(self.row1 * self.tile, self.height)

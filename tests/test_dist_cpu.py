@@ -136,3 +136,19 @@ def test_slice_and_band_partition_properties():
             rows = [dist.band_rows(nty, r, world) for r in range(world)]
             assert rows[0][0] == 0 and rows[-1][1] == nty
             assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+
+
+def test_balanced_rows():
+    w = np.array([1, 1, 10, 30, 30, 10, 1, 1], np.int64)
+    for world in (1, 2, 3, 4, 8, 12):
+        bands = dist.balanced_rows(w, world)
+        assert len(bands) == world and bands[0][0] == 0 and bands[-1][1] == 8 or world > 8
+        flat = [r for a, b in bands for r in range(a, b)]
+        assert flat == sorted(set(flat)) and set(flat) == set(range(8))  # a partition of the rows
+        if world <= 8:
+            assert all(b > a for a, b in bands)  # nobody idles while rows remain
+    two = dist.balanced_rows(w, 2)
+    assert two == [(0, 4), (4, 8)]
+    sums = [w[a:b].sum() for a, b in dist.balanced_rows(w, 4)]
+    assert max(sums) <= 42  # equal rows would give 2/40/40/2; the balanced cut does much better
+    assert dist.balanced_rows(np.zeros(5), 2) in ([(0, 2), (2, 5)], [(0, 3), (3, 5)])
