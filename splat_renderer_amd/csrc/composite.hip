@@ -146,36 +146,65 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
         const uint32_t batch_n = (count - base < CBATCH) ? (count - base) : CBATCH;
         for (uint32_t c0 = 0; c0 < batch_n && uniform64(live) != 0; c0 += 64) {
             const uint2 mm = s_mask[w][c0 + lane];
-            unsigned long long hits = uniform64(__ballot((mm.x | mm.y) != 0u));
+            // entries of this chunk that cover at least one pixel still accumulating
+            const unsigned long long lv0 = uniform64(live);
+            unsigned long long hits = uniform64(__ballot(((mm.x & (uint32_t)lv0) | (mm.y & (uint32_t)(lv0 >> 32))) != 0u));
+            // two entries per trip: both parameter reads are in flight together, both Gaussians are
+            // independent work, and the loop/branch overhead is paid once per pair; the second
+            // entry's coverage is re-masked with the pixels the first one has just saturated, so the
+            // per-pixel stop is exactly sequential
             while (hits) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(hits);
+                const uint32_t j0 = (uint32_t)__builtin_ctzll(hits);
                 hits &= hits - 1;
+                const bool two = hits != 0;
+                const uint32_t j1 = two ? (uint32_t)__builtin_ctzll(hits) : j0;
+                hits &= hits - 1; // (0 & anything stays 0)
                 // (readlane returns int: go through uint32_t or the low word sign-extends into the high one)
-                const unsigned long long cover = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j) << 32) |
-                                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j);
-                const unsigned long long lv = uniform64(live); // pinned at the use: see uniform64()
-                const unsigned long long active = cover & lv;
-                if (active == 0) continue; // every pixel it covers has already saturated
-                const float4 G = s_geo[c0 + j]; // wave-uniform address: LDS broadcast
-                const float2 C = s_col[c0 + j];
-                const float dx = pxf - G.x, dy = pyf - G.y;
-                float g = __builtin_amdgcn_exp2f((dx * dx + dy * dy) * G.z);
-                g = __builtin_amdgcn_inverse_ballot_w64(active) ? g : 0.0f;
+                const unsigned long long cover0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j0) << 32) |
+                                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j0);
+                unsigned long long cover1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j1) << 32) |
+                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j1);
+                if (!two) cover1 = 0;
+                const float4 G0 = s_geo[c0 + j0], G1 = s_geo[c0 + j1]; // wave-uniform addresses: LDS broadcasts
+                const float2 C0 = s_col[c0 + j0], C1 = s_col[c0 + j1];
+                const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
+                float g0 = __builtin_amdgcn_exp2f((dx0 * dx0 + dy0 * dy0) * G0.z);
+                float g1 = __builtin_amdgcn_exp2f((dx1 * dx1 + dy1 * dy1) * G1.z);
+                unsigned long long lv = uniform64(live); // pinned at the use: see uniform64()
+                g0 = __builtin_amdgcn_inverse_ballot_w64(cover0 & lv) ? g0 : 0.0f;
                 if (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) { // :183-185 as written
-                    const float om = 1.0f - g;
-                    cr = cr * om + C.x * g;
-                    cg = cg * om + C.y * g;
-                    cb = cb * om + G.w * g;
-                    acc = acc * om + g;
-                    if (EARLY_OUT) live = lv & ~__ballot(acc >= 0.99f); // :187-190
+                    const float om = 1.0f - g0;
+                    cr = cr * om + C0.x * g0;
+                    cg = cg * om + C0.y * g0;
+                    cb = cb * om + G0.w * g0;
+                    acc = acc * om + g0;
+                    if (EARLY_OUT) lv &= ~__ballot(acc >= 0.99f); // :187-190
                 } else { // SURVEY §8a contract 3: nearest on top
-                    const float wgt = acc * g;
-                    cr += C.x * wgt;
-                    cg += C.y * wgt;
-                    cb += G.w * wgt;
-                    acc = acc * (1.0f - g);
-                    if (EARLY_OUT) live = lv & ~__ballot((1.0f - acc) >= 0.99f);
+                    const float wgt = acc * g0;
+                    cr += C0.x * wgt;
+                    cg += C0.y * wgt;
+                    cb += G0.w * wgt;
+                    acc = acc * (1.0f - g0);
+                    if (EARLY_OUT) lv &= ~__ballot((1.0f - acc) >= 0.99f);
                 }
+                lv = uniform64(lv);
+                g1 = __builtin_amdgcn_inverse_ballot_w64(cover1 & lv) ? g1 : 0.0f;
+                if (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) {
+                    const float om = 1.0f - g1;
+                    cr = cr * om + C1.x * g1;
+                    cg = cg * om + C1.y * g1;
+                    cb = cb * om + G1.w * g1;
+                    acc = acc * om + g1;
+                    if (EARLY_OUT) lv &= ~__ballot(acc >= 0.99f);
+                } else {
+                    const float wgt = acc * g1;
+                    cr += C1.x * wgt;
+                    cg += C1.y * wgt;
+                    cb += G1.w * wgt;
+                    acc = acc * (1.0f - g1);
+                    if (EARLY_OUT) lv &= ~__ballot((1.0f - acc) >= 0.99f);
+                }
+                live = lv;
                 if (EARLY_OUT && uniform64(live) == 0) break;
             }
         }
