@@ -224,6 +224,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     td.all_reduce(tmax, op=td.ReduceOp.MAX)
     dt = float(tmax.item())
+    br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # outside the timed region: proves no sync-free frame overflowed
+    assert stages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
     comp_ms = stages.stage_avg_ms(_lib.STAGE_COMPOSITE)
     p_used = int(stages.consumed[0].item()) / args.steps
     stages.set_timing(False)

@@ -147,7 +147,14 @@ int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out);
 void splat_bin_destroy(splat_binner *b);
 /* binSplats(): sorted = n_sorted u32 splat indices (entries >= n_splats are padding and are
  * skipped).  Only tile rows [tile_row0, tile_row1) are binned (0, UINT32_MAX = all rows) —
- * the multi-GPU band.  Makes one 4-byte device->host read of the pair total. */
+ * the multi-GPU band.
+ * Host round trips: the FIRST run (and any run whose pair buffers must grow) reads the 4-byte pair
+ * total back to size the fill.  After that, while the previous run's total leaves 50 % headroom,
+ * runs are sync-free: the total is read on the device, grids are sized from the previous total, and
+ * it returns through an async copy examined by the next splat_bin_* call on this binner.  If a
+ * frame's pairs outgrew that limit (more than 1.5x the previous frame's), its lists are incomplete
+ * and that next call returns SPLAT_ERR_CAPACITY after raising the capacity: render the frame
+ * again.  The getters below wait for the async copy. */
 int splat_bin_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted,
                   uint32_t n_sorted, uint32_t width, uint32_t height, uint32_t tile_row0,
                   uint32_t tile_row1);
@@ -197,6 +204,17 @@ int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_r
 int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected, uint32_t n,
                     uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_row0,
                     uint32_t tile_row1, uint32_t *n_kept_host);
+
+/* One rank's frame after the exchange, without a host round trip: band filter (the kept count stays
+ * on the device) -> depth sort -> bin -> composite of tile rows [cfg->tile_row0, cfg->tile_row1).
+ * records: n_records ProjectedSplat records whose originalIndex is the global splat index (the
+ * all-gathered shards); props/normals: the full scene in the reference's layouts. */
+int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
+                     const splat_composite_cfg *cfg, const void *props, const void *normals,
+                     const void *records, uint32_t n_records, uint32_t width, uint32_t height,
+                     void *out_rgba8, void *out_rgba32f, void *consumed_dptr);
+/* Number of splats the last splat_band_frame / splat_band_keys kept (synchronises). */
+int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,8 @@
 #include "common.h"
 #include "tile_range.h"
 
+#include <cstdlib>
+
 constexpr uint32_t BIN_THREADS = 256;
 constexpr uint32_t BIN_PER_THREAD = 2;
 constexpr uint32_t BIN_BLOCK = BIN_THREADS * BIN_PER_THREAD; // sorted positions per workgroup
@@ -41,10 +43,15 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *wsum) {
 template <bool FROM_RANGE32>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const float4 *__restrict__ projected,
                                                            const uint32_t *__restrict__ range32, uint32_t n_splats,
-                                                           const uint32_t *__restrict__ sorted, uint32_t n_sorted, BinParams bp,
-                                                           uint2 *__restrict__ ranges, uint32_t *__restrict__ blocksums) {
+                                                           const uint32_t *__restrict__ sorted, uint32_t n_sorted_host,
+                                                           const uint32_t *__restrict__ n_sorted_dev, BinParams bp,
+                                                           uint2 *__restrict__ ranges, uint32_t *__restrict__ blocksums,
+                                                           uint32_t *__restrict__ overflow_flag) {
     __shared__ uint32_t wsum[4];
     uint32_t local = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow_flag = 0; // set by k_bin_expand of this frame if it clips
+    uint32_t n_sorted = n_sorted_host;
+    if (n_sorted_dev) n_sorted = min(*n_sorted_dev, n_sorted_host); // sync-free callers: count on the device
 #pragma unroll
     for (uint32_t k = 0; k < BIN_PER_THREAD; ++k) {
         const uint32_t i = blockIdx.x * BIN_BLOCK + k * BIN_THREADS + threadIdx.x;
@@ -65,6 +72,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const float4 *__restr
             const uint2 r = make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
             ranges[i] = r;
             local += range_hits(r);
+        } else if (i < n_sorted_host) {
+            ranges[i] = make_uint2(1u, 1u); // past the device-side count: empty
         }
     }
     const uint32_t total = block_sum(local, wsum);
@@ -77,6 +86,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const float4 *__restr
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__restrict__ sorted, uint32_t n_sorted,
                                                             const uint2 *__restrict__ ranges,
                                                             const uint32_t *__restrict__ block_base, uint32_t ntx,
+                                                            uint32_t pair_limit, uint32_t *__restrict__ overflow,
                                                             uint32_t *__restrict__ pair_tile, uint32_t *__restrict__ pair_splat) {
     __shared__ uint32_t wsum[4];
     __shared__ uint2 stage[BIN_STAGE_PAIRS];
@@ -114,6 +124,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
     }
     const uint32_t total = carry, base = block_base[blockIdx.x];
     if (total == 0) return;
+    // sync-free frames: pairs at or past the limit are dropped (and flagged).  Everything below the
+    // limit is still written, so the pair buffers never hold stale tile ids / splat indices that a
+    // later kernel could index with.
+    const bool clipped = base + total > pair_limit || base + total < base;
+    if (clipped && tid == 0) atomicOr(overflow, 1u);
+    if (base >= pair_limit) return;
     const bool staged = total <= BIN_STAGE_PAIRS;
 #pragma unroll
     for (uint32_t k = 0; k < BIN_PER_THREAD; ++k) {
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 if (staged) {
                     stage[o] = make_uint2(ty * ntx + tx, s[k]);
-                } else {
+                } else if (!clipped || base + o < pair_limit) {
                     pair_tile[base + o] = ty * ntx + tx;
                     pair_splat[base + o] = s[k];
                 }
@@ -133,7 +149,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
     }
     if (staged) {
         __syncthreads();
-        for (uint32_t o = tid; o < total; o += BIN_THREADS) {
+        const uint32_t keep = clipped ? pair_limit - base : total;
+        for (uint32_t o = tid; o < keep && o < total; o += BIN_THREADS) {
             const uint2 p = stage[o];
             pair_tile[base + o] = p.x;
             pair_splat[base + o] = p.y;
@@ -146,12 +163,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
 // the thread at the last pair closes the tail with offsets[u] = P.  offsets has T+1 entries.
 // Same values as the exclusive scan of the counts (TileBinner.ts:452-459), with no atomics:
 // 11M global atomic increments cost 1.03 ms at C2, this costs a few microseconds.
-__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ sorted_tiles, uint32_t pairs,
-                                                      uint32_t tiles, uint32_t *__restrict__ offsets) {
+__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ sorted_tiles, uint32_t pairs_host,
+                                                      const uint32_t *__restrict__ pairs_dev, uint32_t tiles,
+                                                      uint32_t *__restrict__ offsets) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t pairs = pairs_dev ? min(*pairs_dev, pairs_host) : pairs_host;
+    if (pairs == 0) { // (only possible with a device-side count) every list is empty
+        if (blockIdx.x == 0)
+            for (uint32_t u = threadIdx.x; u <= tiles; u += 256u) offsets[u] = 0;
+        return;
+    }
     if (i >= pairs) return;
-    const uint32_t t = sorted_tiles[i];
-    const int64_t prev = (i == 0) ? -1 : (int64_t)sorted_tiles[i - 1];
+    const uint32_t t = min(sorted_tiles[i], tiles - 1);
+    const int64_t prev = (i == 0) ? -1 : (int64_t)min(sorted_tiles[i - 1], tiles - 1);
     if ((int64_t)t != prev)
         for (int64_t u = prev + 1; u <= (int64_t)t; ++u) offsets[u] = i;
     if (i == pairs - 1)
@@ -180,7 +204,8 @@ static void sorter_free_members(splat_sorter *s) {
     if (s->payload) (void)hipFree(s->payload);
     if (s->payload_b) (void)hipFree(s->payload_b);
     if (s->hist) (void)hipFree(s->hist);
-    s->keys = s->keys_b = s->payload = s->payload_b = s->hist = nullptr;
+    if (s->d_count) (void)hipFree(s->d_count);
+    s->keys = s->keys_b = s->payload = s->payload_b = s->hist = s->d_count = nullptr;
     s->capacity = 0;
 }
 
@@ -199,7 +224,7 @@ int binner_reserve_range32(splat_binner *b, uint32_t n_splats) {
 // binSplats.  range32 (optional): per splat index, the packed range the projector computed with the
 // same BinParams (frame path); otherwise ranges are derived from the projected bounds here.
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
-               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32) {
+               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32, const uint32_t *n_sorted_dev) {
     splat_ctx *ctx = b->ctx;
     ARG_CHECK(ctx, width >= 1 && height >= 1);
     ARG_CHECK(ctx, n_sorted == 0 || (projected && sorted));
@@ -230,50 +255,68 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     b->ran = false;
     const BinParams bp = {width, height, b->tile, ntx, nty, tile_row0, tile_row1};
 
+    // the previous frame's async readback (if any): learn its pair total, detect overflow
+    int rc = binner_settle(b);
+    if (rc != SPLAT_OK) return rc;
+
     stage_begin(ctx, SPLAT_STAGE_BIN);
     uint32_t total32 = 0;
-    int rc = SPLAT_OK;
+    bool async = false;
     if (n_sorted > 0) {
         if (range32)
             hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
-                               n_splats, (const uint32_t *)sorted, n_sorted, bp, b->ranges, b->blocksums);
+                               n_splats, (const uint32_t *)sorted, n_sorted, n_sorted_dev, bp, b->ranges, b->blocksums, b->d_total + 1);
         else
             hipLaunchKernelGGL(k_bin_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected,
-                               nullptr, n_splats, (const uint32_t *)sorted, n_sorted, bp, b->ranges, b->blocksums);
+                               nullptr, n_splats, (const uint32_t *)sorted, n_sorted, n_sorted_dev, bp, b->ranges, b->blocksums, b->d_total + 1);
         LAUNCH_CHECK(ctx, "k_bin_count");
         rc = scan_exclusive_u32(ctx, b->blocksums, b->blocksums, blocks, b->d_total); // PrefixSumScanner.scan :296-303
         if (rc != SPLAT_OK) return rc;
-        // the one host round trip of the frame: the pair total sizes the fill (the reference reads
-        // back all T counts here: GPUTileBinner.ts:244-263)
-        rc = ctx_ensure_pinned(ctx, 16);
-        if (rc != SPLAT_OK) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, b->d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        total32 = *(volatile uint32_t *)ctx->pinned;
-    }
-    b->total = total32;
-    if (total32 > 0) {
-        if (total32 > b->pairs.capacity) {
-            uint64_t want = (uint64_t)total32 + total32 / 4 + 4096;
-            if (want > 0x3ffff000ull) want = 0x3ffff000ull;
-            if (total32 > want) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "binSplats: more than 2^30 tile-splat pairs");
-            rc = sorter_reserve(&b->pairs, (uint32_t)want);
-            if (rc != SPLAT_OK) return rc;
+        const uint64_t want_async = (uint64_t)b->last_total + b->last_total / 8 + 4096; // 12.5 % frame-to-frame growth
+        async = b->allow_async && b->have_last && b->last_total > 0 && want_async <= b->pairs.capacity;
+        if (async) {
+            b->pair_limit = (uint32_t)want_async;
+            total32 = b->pair_limit; // grid bound; the real count is read on the device
+        } else {
+            // the one host round trip of a (first / growing) frame: the pair total sizes the fill
+            // (the reference reads back all T counts here: GPUTileBinner.ts:244-263)
+            HIP_TRY(ctx, hipMemcpyAsync(b->pinned, b->d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            total32 = *(volatile uint32_t *)b->pinned;
+            b->last_total = total32;
+            b->have_last = true;
+            if (total32 > b->pairs.capacity) {
+                uint64_t want = (uint64_t)total32 + total32 / 2 + 8192; // headroom for sync-free frames to come
+                if (want > 0x3ffff000ull) want = 0x3ffff000ull;
+                if (total32 > want) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "binSplats: more than 2^30 tile-splat pairs");
+                rc = sorter_reserve(&b->pairs, (uint32_t)want);
+                if (rc != SPLAT_OK) return rc;
+            }
+            b->pair_limit = total32;
         }
+    }
+    b->total = async ? b->last_total : total32;
+    if (total32 > 0) {
         hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
-                           b->ranges, b->blocksums, ntx, b->pairs.keys, b->pairs.payload);
+                           b->ranges, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys, b->pairs.payload);
         LAUNCH_CHECK(ctx, "k_bin_expand");
         uint32_t bits = 1;
         while ((1u << bits) < tiles) ++bits;
+        const uint32_t *p_dev = async ? b->d_total : nullptr;
         rc = radix_sort_pairs(ctx, b->pairs.keys, b->pairs.payload, b->pairs.keys_b, b->pairs.payload_b, b->pairs.hist,
-                              total32, 0, bits, &b->pairs.result_in_primary);
+                              total32, 0, bits, &b->pairs.result_in_primary, -1, p_dev);
         if (rc != SPLAT_OK) return rc;
         const uint32_t *sorted_tiles = b->pairs.result_in_primary ? b->pairs.keys : b->pairs.keys_b;
-        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(total32, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, tiles,
-                           b->offsets);
+        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(total32, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
+                           tiles, b->offsets);
         LAUNCH_CHECK(ctx, "k_tile_offsets");
         hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts);
         LAUNCH_CHECK(ctx, "k_tile_counts");
+        if (async) { // {total, overflow} come back without stalling the stream; examined at the next call
+            HIP_TRY(ctx, hipMemcpyAsync(b->pinned, b->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(b->readback_done, ctx->stream));
+            b->pending = true;
+        }
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->counts, 0, (size_t)tiles * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(b->offsets, 0, (size_t)(tiles + 1) * 4, ctx->stream));
@@ -284,6 +327,29 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     }
     stage_end(ctx, SPLAT_STAGE_BIN);
     b->ran = true;
+    return SPLAT_OK;
+}
+
+int binner_settle(splat_binner *b) {
+    if (!b->pending) return SPLAT_OK;
+    splat_ctx *ctx = b->ctx;
+    b->pending = false;
+    HIP_TRY(ctx, hipEventSynchronize(b->readback_done));
+    const uint32_t total = ((volatile uint32_t *)b->pinned)[0], overflow = ((volatile uint32_t *)b->pinned)[1];
+    b->last_total = total;
+    b->have_last = true;
+    b->total = total;
+    if (overflow || total > b->pair_limit) {
+        // that frame's lists (and anything composited from them) are incomplete: make room, tell the caller
+        uint64_t want = (uint64_t)total + total / 2 + 8192;
+        if (want > 0x3ffff000ull) want = 0x3ffff000ull;
+        b->ran = false;
+        int rc = sorter_reserve(&b->pairs, (uint32_t)want);
+        if (rc != SPLAT_OK) return rc;
+        return ctx_fail(ctx, SPLAT_ERR_CAPACITY,
+                        "the previous frame produced more tile-splat pairs than its sync-free limit (sized from the frame "
+                        "before it): its tile lists are incomplete; capacity has been raised, render that frame again");
+    }
     return SPLAT_OK;
 }
 
@@ -298,10 +364,14 @@ int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out) {
     b->ctx = ctx;
     b->tile = tile_size;
     b->pairs.ctx = ctx;
-    if (hipMalloc((void **)&b->d_total, 16) != hipSuccess) {
+    if (hipMalloc((void **)&b->d_total, 16) != hipSuccess || hipHostMalloc((void **)&b->pinned, 16, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&b->readback_done, hipEventDisableTiming) != hipSuccess) {
+        if (b->d_total) (void)hipFree(b->d_total);
+        if (b->pinned) (void)hipHostFree(b->pinned);
         delete b;
-        return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
+        return ctx_fail(ctx, SPLAT_ERR_OOM, "binner allocation");
     }
+    if (const char *e = getenv("SPLAT_BIN_SYNC")) b->allow_async = !(e[0] == '1');
     *out = b;
     return SPLAT_OK;
 }
@@ -313,6 +383,8 @@ void splat_bin_destroy(splat_binner *b) {
     sorter_free_members(&b->pairs);
     if (b->d_total) (void)hipFree(b->d_total);
     if (b->range32) (void)hipFree(b->range32);
+    if (b->pinned) (void)hipHostFree(b->pinned);
+    if (b->readback_done) (void)hipEventDestroy(b->readback_done);
     delete b;
 }
 
@@ -326,6 +398,7 @@ uint32_t splat_bin_tile_size(const splat_binner *b) { return b ? b->tile : 0; }
 
 int splat_bin_counts(splat_binner *b, void **dptr) {
     if (!b || !dptr) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner/dptr is NULL");
+    if (int rc = binner_settle(b)) return rc;
     if (!b->ran) return ctx_fail(b->ctx, SPLAT_ERR_STATE, "Tile counts buffer not initialized"); // GPUTileBinner.ts:354-359
     *dptr = b->counts;
     return SPLAT_OK;
@@ -333,6 +406,7 @@ int splat_bin_counts(splat_binner *b, void **dptr) {
 
 int splat_bin_offsets(splat_binner *b, void **dptr) {
     if (!b || !dptr) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner/dptr is NULL");
+    if (int rc = binner_settle(b)) return rc;
     if (!b->ran) return ctx_fail(b->ctx, SPLAT_ERR_STATE, "Tile offsets buffer not initialized"); // :340-345
     *dptr = b->offsets;
     return SPLAT_OK;
@@ -340,6 +414,7 @@ int splat_bin_offsets(splat_binner *b, void **dptr) {
 
 int splat_bin_indices(splat_binner *b, void **dptr) {
     if (!b || !dptr) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner/dptr is NULL");
+    if (int rc = binner_settle(b)) return rc;
     if (!b->ran) return ctx_fail(b->ctx, SPLAT_ERR_STATE, "Tile indices buffer not initialized"); // :347-352
     *dptr = b->pairs.result_in_primary ? b->pairs.payload : b->pairs.payload_b;
     return SPLAT_OK;
@@ -347,6 +422,7 @@ int splat_bin_indices(splat_binner *b, void **dptr) {
 
 int splat_bin_total(splat_binner *b, uint64_t *total_pairs) {
     if (!b || !total_pairs) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner/total is NULL");
+    if (int rc = binner_settle(b)) return rc;
     if (!b->ran) return ctx_fail(b->ctx, SPLAT_ERR_STATE, "binSplats has not run");
     *total_pairs = b->total;
     return SPLAT_OK;

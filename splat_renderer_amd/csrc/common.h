@@ -65,11 +65,12 @@ static inline uint64_t div_up64(uint64_t a, uint64_t b) { return (a + b - 1) / b
 int scan_exclusive_u32(splat_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);
 // radix_sort.hip: sorts n pairs from (k0,p0) using (k1,p1) as the ping-pong partner; returns in
 // *result_in_primary whether the result ended in (k0,p0). hist is a workspace of
-// 256 * div_up(n, RADIX_PART) + 256 u32.
+// 256 * div_up(n, RADIX_PART) + 256 u32.  n_dev (optional, rowscan mode): the number of pairs is
+// min(*n_dev, n) read on the device, n only sizes the grid — no host round trip to learn it.
 constexpr uint32_t RADIX_PART = 4096; // keys per workgroup partition
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1,
                      uint32_t *hist, uint32_t n, uint32_t bit_begin, uint32_t bit_end,
-                     bool *result_in_primary, int mode = -1);
+                     bool *result_in_primary, int mode = -1, const uint32_t *n_dev = nullptr);
 
 int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);
 
@@ -78,6 +79,7 @@ struct splat_sorter {
     uint32_t capacity = 0;
     uint32_t *keys = nullptr, *keys_b = nullptr, *payload = nullptr, *payload_b = nullptr;
     uint32_t *hist = nullptr;
+    uint32_t *d_count = nullptr; // device-side element count for sync-free callers (splat_band_keys)
     bool result_in_primary = true;
     bool ran = false;
     int mode = -1; // -1 = library default, 0 = upsweep/rowscan/downsweep, 1 = onesweep (chained scan)
@@ -95,10 +97,22 @@ struct splat_binner {
     uint32_t *blocksums = nullptr;                  // pairs per 512-position block, then their exclusive scan
     uint2 *ranges = nullptr;                        // per sorted position: packed clamped tile range
     uint32_t *range32 = nullptr;                    // per splat INDEX: 8-bit packed range written by the projector (frame path)
-    uint32_t *d_total = nullptr;
+    uint32_t *d_total = nullptr;                    // [0] pair total of the last run, [1] overflow flag
     splat_sorter pairs;                             // (tileId, splatIdx) ping-pong buffers
     uint64_t total = 0;
     bool ran = false;
+    // sync-free operation: when the previous frame's pair total is known and 1.125x of it fits the
+    // pair buffers, the next frame does not wait for its own total: kernels read it on the device,
+    // grids are sized for `pair_limit` = 1.125x the previous total, and the total comes back through an
+    // async copy that is examined at the next call.  A frame that outgrew its limit is reported then
+    // (SPLAT_ERR_CAPACITY).
+    bool allow_async = true;
+    bool pending = false;      // an async {total, overflow} readback is in flight
+    bool have_last = false;
+    uint32_t last_total = 0;
+    uint32_t pair_limit = 0;   // pairs this frame's grids / stores are bounded by
+    uint32_t *pinned = nullptr; // 4 u32, host-pinned
+    hipEvent_t readback_done = nullptr;
 };
 
 // Tile-range parameters handed to the projector so that it can emit range32[] (frame path)
@@ -109,7 +123,9 @@ struct BinParams {
 // bin.hip internals used by frame.hip
 int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
-               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32);
+               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32,
+               const uint32_t *n_sorted_dev = nullptr);
+int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_ERR_CAPACITY if that frame overflowed
 // project.hip internal: the projector with the optional per-index tile range output
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,

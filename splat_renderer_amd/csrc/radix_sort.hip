@@ -28,25 +28,19 @@ constexpr uint32_t RS_ITEMS = RADIX_PART / RS_THREADS; // 16 keys per thread
 constexpr uint32_t RS_WAVES = RS_THREADS / 64;
 
 // ---------------------------------------------------------------------------------------------
-// Partitioning.  A partition is items*256 keys; the downsweep is instantiated for several sizes
-// (SPLAT_RADIX_ITEMS selects one for tuning runs).
+// Partition = 16 keys/thread x 256 threads = 4096 keys.  Measured on MI355X (tools/sort_bench.py, 5M
+// keys x 4 passes): 4 items 346 us, 6 -> 266, 8 -> 228, 12 -> 193, 14 -> 184, 16 -> 176, 20 -> 174,
+// 24 -> 190, 32 -> 177.  Bigger partitions win until ~16 (longer digit runs = better store coalescing,
+// fixed per-partition work amortised), then the occupancy loss cancels the gain.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t RS_MIN_ITEMS = 4;
-static const uint32_t kItemChoices[] = {4, 6, 8, 12, 14, 16, 20, 24, 32};
+constexpr uint32_t RS_PART_KEYS = RS_ITEMS * RS_THREADS;
 
-static uint32_t g_force_items = 0; // tuning hook: SPLAT_RADIX_ITEMS env var (read once)
-
-static uint32_t wg_per_cu_for(uint32_t items) { // mirrors downsweep_wg_per_cu (defined with the kernel below)
-    return items <= 6 ? 8 : items <= 12 ? 5 : items <= 16 ? 4 : items <= 20 ? 3 : 2;
-}
-
-// Measured on MI355X (tools/sort_bench.py, 5M and 11.3M pairs): 4 items 346 us, 6 -> 266, 8 -> 228,
-// 12 -> 193, 14 -> 184, 16 -> 176, 20 -> 174, 24 -> 190, 32 -> 177 (4-pass 5M-key sort).  Bigger
-// partitions win until ~16 (longer digit runs = better store coalescing, fixed per-partition work
-// amortised) and then occupancy loss cancels the gain, so 16 is the default at every size tried.
-static uint32_t choose_items(uint32_t n) {
-    (void)n;
-    return RS_ITEMS;
+// Number of keys to sort: a host value, or (sync-free callers) a device word clamped to the host
+// bound the grid was sized for.  Workgroups past the end exit at once.
+__device__ __forceinline__ uint32_t sort_count(uint32_t n_host, const uint32_t *n_dev) {
+    if (!n_dev) return n_host;
+    const uint32_t v = *n_dev;
+    return v < n_host ? v : n_host;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -66,13 +60,19 @@ __device__ __forceinline__ void hist_add4(uint32_t *h, uint4 v, uint32_t shift, 
     }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__restrict__ keys, uint32_t n,
-                                                              uint32_t shift, uint32_t mask, uint32_t num_parts,
-                                                              uint32_t part_keys, uint32_t *__restrict__ hist) {
+__global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__restrict__ keys, uint32_t n_host,
+                                                              const uint32_t *__restrict__ n_dev, uint32_t shift,
+                                                              uint32_t mask, uint32_t num_parts, uint32_t part_keys,
+                                                              uint32_t *__restrict__ hist) {
     __shared__ uint32_t lh[RS_WAVES][256]; // one private histogram per wave: fewer same-bank collisions
     const uint32_t tid = threadIdx.x, w = tid >> 6;
-    for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
+    const uint32_t n = sort_count(n_host, n_dev);
     const uint32_t base = blockIdx.x * part_keys; // multiple of 256 keys = 1 KiB: uint4 loads stay aligned
+    if (base >= n) { // partition past the end (device-side n): an all-zero column
+        hist[(size_t)tid * num_parts + blockIdx.x] = 0;
+        return;
+    }
+    for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
     if (base + part_keys <= n) {
         const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
         const uint32_t vecs = part_keys / 4; // multiple of 64
@@ -314,25 +314,19 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
 
 // resident workgroups per CU for a given ITEMS: LDS-bound (160 KiB per CU), capped at 8 (32 waves)
 constexpr uint32_t downsweep_lds_bytes(uint32_t items) { return items * RS_THREADS * 8 + (uint32_t)sizeof(DownsweepShared); }
-// ... and register-bound: ~6.5 VGPRs per item + ~20, so the LDS count is lowered where asking for it
-// would make the compiler spill
-constexpr uint32_t downsweep_wg_per_cu(uint32_t items) {
-    return items <= 6 ? 8 : items <= 12 ? 5 : items <= 16 ? 4 : items <= 20 ? 3 : 2;
-}
-static_assert(downsweep_wg_per_cu(16) * downsweep_lds_bytes(16) <= 160u * 1024u, "LDS budget");
-static_assert(downsweep_wg_per_cu(20) * downsweep_lds_bytes(20) <= 160u * 1024u, "LDS budget");
-static_assert(downsweep_wg_per_cu(32) * downsweep_lds_bytes(32) <= 160u * 1024u, "LDS budget");
-static_assert(downsweep_wg_per_cu(12) * downsweep_lds_bytes(12) <= 160u * 1024u, "LDS budget");
-static_assert(downsweep_wg_per_cu(8) * downsweep_lds_bytes(8) <= 160u * 1024u, "LDS budget");
-static_assert(downsweep_wg_per_cu(6) * downsweep_lds_bytes(6) <= 160u * 1024u, "LDS budget");
+// ... and register-bound (~6.5 VGPRs per item + ~20): 4 workgroups per CU for 16 items
+constexpr uint32_t downsweep_wg_per_cu(uint32_t items) { return items <= 6 ? 8 : items <= 12 ? 5 : items <= 16 ? 4 : 2; }
+static_assert(downsweep_wg_per_cu(RS_ITEMS) * downsweep_lds_bytes(RS_ITEMS) <= 160u * 1024u, "LDS budget");
 
 template <uint32_t ITEMS>
 __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ pay_out, uint32_t n, uint32_t shift, uint32_t mask, uint32_t num_parts,
-    const uint32_t *__restrict__ scanned_hist, const uint32_t *__restrict__ totals) {
+    uint32_t *__restrict__ pay_out, uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t shift, uint32_t mask,
+    uint32_t num_parts, const uint32_t *__restrict__ scanned_hist, const uint32_t *__restrict__ totals) {
     __shared__ DownsweepShared sh;
     __shared__ uint2 s_kp[ITEMS * RS_THREADS]; // (key, payload) reordered by digit
+    const uint32_t n = sort_count(n_host, n_dev);
+    if (blockIdx.x * ITEMS * RS_THREADS >= n) return; // partition past the end (device-side n)
     // every partition but (possibly) the last is full: it takes the path with no per-key bounds checks
     if ((blockIdx.x + 1) * ITEMS * RS_THREADS <= n)
         downsweep_body<ITEMS, true, false>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
@@ -340,13 +334,6 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radi
     else
         downsweep_body<ITEMS, false, false>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                             scanned_hist, totals, nullptr, nullptr);
-}
-
-template <uint32_t ITEMS>
-static void launch_downsweep(splat_ctx *ctx, uint32_t parts, const uint32_t *ki, const uint32_t *pi, uint32_t *ko, uint32_t *po,
-                             uint32_t n, uint32_t shift, uint32_t mask, const uint32_t *hist, const uint32_t *totals) {
-    hipLaunchKernelGGL(k_radix_downsweep<ITEMS>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pi, ko, po, n, shift, mask,
-                       parts, hist, totals);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,32 +415,21 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(OS_ITEMS)) void k_r
 static int g_radix_mode = -1;
 
 static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
-                              uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
-    const uint32_t items = g_force_items ? g_force_items : choose_items(n);
-    const uint32_t part_keys = items * RS_THREADS;
-    const uint32_t parts = div_up(n, part_keys); // <= div_up(n, RS_MIN_ITEMS*256): the hist workspace is sized for that
+                              const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
+    const uint32_t parts = div_up(n, RS_PART_KEYS);
     uint32_t *ki = k0, *pi = p0, *ko = k1, *po = p1;
     bool primary = true;
     for (uint32_t shift = bit_begin; shift < bit_end; shift += 8) {
         uint32_t bits = bit_end - shift < 8 ? bit_end - shift : 8;
         uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_radix_upsweep, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, mask, parts, part_keys,
-                           hist);
+        hipLaunchKernelGGL(k_radix_upsweep, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
+                           RS_PART_KEYS, hist);
         LAUNCH_CHECK(ctx, "k_radix_upsweep");
         uint32_t *totals = hist + (size_t)256 * parts;
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals);
         LAUNCH_CHECK(ctx, "k_radix_rowscan");
-        switch (items) {
-        case 4: launch_downsweep<4>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 6: launch_downsweep<6>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 8: launch_downsweep<8>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 12: launch_downsweep<12>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 14: launch_downsweep<14>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 20: launch_downsweep<20>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 24: launch_downsweep<24>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        case 32: launch_downsweep<32>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        default: launch_downsweep<16>(ctx, parts, ki, pi, ko, po, n, shift, mask, hist, totals); break;
-        }
+        hipLaunchKernelGGL(k_radix_downsweep<RS_ITEMS>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pi, ko, po, n, n_dev,
+                           shift, mask, parts, hist, totals);
         LAUNCH_CHECK(ctx, "k_radix_downsweep");
         uint32_t *t = ki; ki = ko; ko = t;
         t = pi; pi = po; po = t;
@@ -491,22 +467,18 @@ static int radix_sort_onesweep(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint3
 }
 
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
-                     uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode) {
+                     uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode, const uint32_t *n_dev) {
     if (g_radix_mode < 0) {
         g_radix_mode = 0;
         if (const char *e = getenv("SPLAT_RADIX_MODE")) g_radix_mode = (e[0] == 'o' || e[0] == '1') ? 1 : 0;
-        if (const char *e = getenv("SPLAT_RADIX_ITEMS")) {
-            uint32_t v = (uint32_t)atoi(e);
-            for (uint32_t c : kItemChoices)
-                if (c == v) g_force_items = v;
-        }
     }
     *result_in_primary = true;
     if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
     if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
     if (mode < 0) mode = g_radix_mode;
+    if (n_dev) mode = 0; // a device-side count is only supported by the rowscan kernels
     if (mode == 1) return radix_sort_onesweep(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
-    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
+    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary);
 }
 
 // the look-back's timeout word (workspace word 1028): non-zero after a sort = a chained scan gave up
@@ -525,7 +497,8 @@ static void sorter_free(splat_sorter *s) {
     if (s->payload) (void)hipFree(s->payload);
     if (s->payload_b) (void)hipFree(s->payload_b);
     if (s->hist) (void)hipFree(s->hist);
-    s->keys = s->keys_b = s->payload = s->payload_b = s->hist = nullptr;
+    if (s->d_count) (void)hipFree(s->d_count);
+    s->keys = s->keys_b = s->payload = s->payload_b = s->hist = s->d_count = nullptr;
     s->capacity = 0;
 }
 
@@ -537,14 +510,14 @@ int sorter_reserve(splat_sorter *s, uint32_t capacity) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     sorter_free(s);
     size_t bytes = (size_t)padded * 4;
-    // rowscan mode: rows for the smallest partition size + the 256 row totals; onesweep mode:
+    // rowscan mode: 256 rows of one count per partition + the 256 row totals; onesweep mode:
     // 1280 header words + status words of 4 passes
-    size_t hist_a = ((size_t)256 * div_up((uint32_t)padded, RS_MIN_ITEMS * RS_THREADS) + 256) * 4;
+    size_t hist_a = ((size_t)256 * div_up((uint32_t)padded, RS_PART_KEYS) + 256) * 4;
     size_t hist_b = ((size_t)1280 + (size_t)4 * div_up((uint32_t)padded, OS_ITEMS * RS_THREADS) * 256) * 4;
     size_t hist_bytes = hist_a > hist_b ? hist_a : hist_b;
     if (hipMalloc((void **)&s->keys, bytes) != hipSuccess || hipMalloc((void **)&s->keys_b, bytes) != hipSuccess ||
         hipMalloc((void **)&s->payload, bytes) != hipSuccess || hipMalloc((void **)&s->payload_b, bytes) != hipSuccess ||
-        hipMalloc((void **)&s->hist, hist_bytes) != hipSuccess) {
+        hipMalloc((void **)&s->hist, hist_bytes) != hipSuccess || hipMalloc((void **)&s->d_count, 16) != hipSuccess) {
         sorter_free(s);
         return ctx_fail(ctx, SPLAT_ERR_OOM, "sorter hipMalloc");
     }

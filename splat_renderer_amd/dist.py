@@ -89,8 +89,8 @@ class HipStages:
         self.binner = b
         self.width, self.height, self.tile = width, height, tile
         self.mode, self.early_out = mode, early_out
-        self.kept = 0
         self.pairs = 0
+        self.overflows = 0
         self.consumed = None  # optional torch int64[1]: list entries staged by the composite
 
     def set_timing(self, enabled, stage_mask=0xFFFFFFFF):
@@ -125,23 +125,35 @@ class HipStages:
         check(self.lib.splat_project_slice(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
                                            out_records.data_ptr()), self.ctx)
 
-    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image):
-        lib, ctx = self.lib, self.ctx
-        kept = C.c_uint32()
-        check(lib.splat_band_keys(ctx, self.sorter, records.data_ptr(), n_records, self.width, self.height, self.tile,
-                                  row0, row1, C.byref(kept)), ctx)
-        self.kept = kept.value
-        check(lib.splat_sort_run(self.sorter, kept.value, 0, 32), ctx)
-        check(lib.splat_bin_run(self.binner, records.data_ptr(), n_records, lib.splat_sort_sorted_payload(self.sorter),
-                                kept.value, self.width, self.height, row0, row1), ctx)
-        counts, offsets, indices = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        check(lib.splat_bin_counts(self.binner, C.byref(counts)), ctx)
-        check(lib.splat_bin_offsets(self.binner, C.byref(offsets)), ctx)
-        check(lib.splat_bin_indices(self.binner, C.byref(indices)), ctx)
+    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False):
+        """settle=False (frame loops): sync-free; a frame whose pairs outgrew 1.5x the previous frame's
+        is only noticed at the next call (which then has room).  settle=True: wait for this frame's pair
+        total and render it again if it overflowed — results are final on return."""
         cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1)
-        check(lib.splat_composite(ctx, C.byref(cfg), props_ptr + 16, 2, normals_ptr, 1, records.data_ptr(), indices, counts,
-                                  offsets, self.width, self.height, out_image.data_ptr(), None,
-                                  self.consumed.data_ptr() if self.consumed is not None else None), ctx)
+        args = (self.ctx, self.sorter, self.binner, C.byref(cfg), props_ptr, normals_ptr, records.data_ptr(), n_records,
+                self.width, self.height, out_image.data_ptr(), None,
+                self.consumed.data_ptr() if self.consumed is not None else None)
+        rc = self.lib.splat_band_frame(*args)
+        if rc == -4:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
+            self.overflows += 1
+            rc = self.lib.splat_band_frame(*args)
+        check(rc, self.ctx)
+        if settle:
+            t = C.c_uint64()
+            rc = self.lib.splat_bin_total(self.binner, C.byref(t))
+            if rc == -4:
+                self.overflows += 1
+                check(self.lib.splat_band_frame(*args), self.ctx)
+                rc = self.lib.splat_bin_total(self.binner, C.byref(t))
+            check(rc, self.ctx)
+            self.pairs = int(t.value)
+
+    @property
+    def kept(self):
+        """Splats the last band_frame kept (synchronises)."""
+        k = C.c_uint32()
+        check(self.lib.splat_band_kept(self.ctx, self.sorter, C.byref(k)), self.ctx)
+        return k.value
 
     def destroy(self):
         self.lib.splat_bin_destroy(self.binner)
@@ -166,12 +178,15 @@ class BandRenderer:
         self.gathered = stages.new_records(self.per * world) if world > 1 else self.shard
         self.image = stages.new_image()
 
-    def render(self, uniforms, props_ptr, normals_ptr):
+    def render(self, uniforms, props_ptr, normals_ptr, settle=False):
         st = self.stages
         st.project_slice(uniforms, props_ptr, self.first, self.count, self.shard)
         if self.world > 1:
             self.all_gather(self.gathered, self.shard)
-        st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image)
+        if settle:
+            st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image, True)
+        else:
+            st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image)
         return self.image
 
     def rebalance(self, all_reduce_sum):

@@ -484,6 +484,8 @@ class Renderer:
         self.output = None
         self.outputFloat = None
         self._wh = (0, 0)
+        self._last = None
+        self.previousFrameOverflowed = False
 
     def render(self, uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height, tileRows=(0, U32_MAX),
                wantFloat=False):
@@ -502,18 +504,39 @@ class Renderer:
         if wantFloat and self.outputFloat is None:
             self.outputFloat = d.createBuffer(width * height * 16)
         cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1])
-        check(d.lib.splat_render_frame(d.ctx, self.sorter._s, self.binner._b, C.byref(cfg),
-                                       u.ctypes.data_as(C.POINTER(C.c_float)), propertyBuffer.ptr, normalsBuffer.ptr,
-                                       self.numPoints, width, height, self.projector.getProjectedBuffer().ptr,
-                                       self.output.ptr, self.outputFloat.ptr if wantFloat else None), d.ctx)
+        args = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)), propertyBuffer.ptr,
+                normalsBuffer.ptr, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
+                self.outputFloat.ptr if wantFloat else None)
+        self._last = (args, u, cfg)  # keeps u/cfg alive; finish() may have to render this frame again
+        rc = d.lib.splat_render_frame(*args)
+        if rc == -4:  # SPLAT_ERR_CAPACITY: the PREVIOUS (sync-free) frame outgrew its pair limit; room was made
+            self.previousFrameOverflowed = True
+            rc = d.lib.splat_render_frame(*args)
+        check(rc, d.ctx)
         self.binner._tiles = -(-width // self.tileSize) * -(-height // self.tileSize)
         return self.output
 
+    def finish(self):
+        """Settles a sync-free frame: waits for its pair total and, if the frame outgrew the limit
+        sized from the frame before it, renders it again (now with room).  Called before results
+        are read."""
+        d = self.device
+        t = C.c_uint64()
+        rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
+        if rc == -4 and self._last is not None:
+            self.previousFrameOverflowed = True
+            check(d.lib.splat_render_frame(*self._last[0]), d.ctx)
+            rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
+        check(rc, d.ctx)
+        return int(t.value)
+
     def readPixels(self):
+        self.finish()
         w, h = self._wh
         return self.output.read(np.uint8).reshape(h, w, 4)
 
     def readPixelsFloat(self):
+        self.finish()
         w, h = self._wh
         return self.outputFloat.read(np.float32).reshape(h, w, 4)
 

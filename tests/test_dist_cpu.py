@@ -40,7 +40,7 @@ class OracleStages:
         rec[:, 6] = np.arange(first, first + count, dtype=np.uint32).view(np.float32)  # global originalIndex
         out_records[:count] = torch.from_numpy(rec)
 
-    def band_frame(self, records, n_records, props, normals, row0, row1, out_image):
+    def band_frame(self, records, n_records, props, normals, row0, row1, out_image, settle=False):
         rec = records.numpy()
         ntx, nty = -(-self.width // self.tile), -(-self.height // self.tile)
         # splat_band_keys: keep splats whose clamped tile rows meet [row0,row1), ascending index

@@ -353,7 +353,7 @@ def test_virtual_ranks_band_frame_matches_single_gpu(device, world):
     got = np.zeros_like(want)
     kept = []
     for br in renderers:  # phase 2: every rank renders its band from the gathered records
-        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image)
+        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=True)
         torch.cuda.synchronize()
         r0, r1 = br.pixel_rows()
         got[r0:r1] = br.image.cpu().numpy()[r0:r1]
@@ -458,3 +458,63 @@ def test_full_size_C2_properties(device):
     r.destroy()
     pbuf.destroy()
     nbuf.destroy()
+
+
+def test_sync_free_frames_repeat_bit_exactly(device):
+    """After the first frame the binner stops waiting for its pair total (device-side count, async
+    readback).  Frames 2..5 of a static scene must reproduce frame 1 bit for bit."""
+    n, w, h = 40000, 480, 270
+    props, normals, u = make_case(n, w, h, 51, 1.5)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    first = r.readPixelsFloat().copy()
+    for _ in range(4):
+        r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    assert not r.previousFrameOverflowed
+    assert np.array_equal(r.readPixelsFloat().view(np.uint32), first.view(np.uint32))
+    assert r.binner.getTotalIndices() == ref["indices"].shape[0]
+    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    r.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
+
+
+def test_sync_free_overflow_is_detected_and_recovered(device):
+    """A frame whose pairs exceed 1.5x the previous frame's cannot fit its sync-free limit: the
+    library reports it at the next call and the host facade renders it again; the final lists and
+    image are the oracle's."""
+    n, w, h = 20000, 320, 200
+    small, normals, u = make_case(n, w, h, 61, 0.5)
+    big = small.copy()
+    big[:, 3] *= 6.0  # ~20x the pairs
+    ref = oracle_pipeline(big, normals, u, w, h)
+    assert ref["indices"].shape[0] > 3 * oracle_pipeline(small, normals, u, w, h)["indices"].shape[0]
+    want, _, _ = O.composite(O.MODE_FRONT_TO_BACK, True, big[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
+                             ref["offsets"], w, h)
+    sbuf, bbuf, nbuf = device.createBufferFrom(small), device.createBufferFrom(big), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r.render(u, sbuf, nbuf, None, w, h, wantFloat=True)   # sync frame: learns P_small
+    r.render(u, sbuf, nbuf, None, w, h, wantFloat=True)   # sync-free
+    r.render(u, bbuf, nbuf, None, w, h, wantFloat=True)   # sync-free, overflows its limit
+    got = r.readPixelsFloat()                              # finish(): detects, re-renders
+    assert r.previousFrameOverflowed
+    assert r.binner.getTotalIndices() == ref["indices"].shape[0]
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    err = np.abs(got - want)
+    assert err.max() <= TOL_EARLY_OUT_BOUND and (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
+    # and the low-level contract: the raw ABI call after an overflowed frame returns CAPACITY once
+    r2 = sr.Renderer(device, None, "rgba8unorm", n)
+    r2.render(u, sbuf, nbuf, None, w, h)
+    r2.render(u, sbuf, nbuf, None, w, h)
+    r2.render(u, bbuf, nbuf, None, w, h)
+    with pytest.raises(sr.SplatError) as ei:
+        r2.binner.getTotalIndices()
+    assert ei.value.code == -4 and "render that frame again" in str(ei.value)
+    r2.render(u, bbuf, nbuf, None, w, h)
+    assert r2.finish() == ref["indices"].shape[0]
+    for o in (r, r2, sbuf, bbuf, nbuf):
+        o.destroy()
