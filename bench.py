@@ -53,11 +53,21 @@ def cpu_baseline(name, props, normals, u, width, height):
     t0 = time.perf_counter()
     rn = O.frame(u, props, normals, width, height, threads=cores, want_f32=False)
     tn = time.perf_counter() - t0
+    # model B = the CPU restatement of SequentialRenderer.ts (one oriented quad per splat, back to front):
+    # the renderer BASELINE.json names; it reuses model A's sort (reverse order), so only its raster is timed
+    proj = O.project(u, props)
+    keys, pay = O.extract_keys(proj)
+    _, order = O.sort_pairs(keys, pay)
+    t0 = time.perf_counter()
+    O.sequential(u, props, normals, order[::-1].copy(), width, height)
+    tb = time.perf_counter() - t0
     return {"value": n / t1 / 1e6, "unit": "Msplats/s", "cores": 1, "kind": "port",
             "sample": f"1 full frame of {name} (N={n}, {width}x{height}), oracle/oracle.c model A, 1 thread",
             "seconds": round(t1, 3), "stage_ms": [round(x, 1) for x in r1["stage_ms"]],
             "all_cores": {"value": n / tn / 1e6, "cores": cores, "seconds": round(tn, 3),
                           "note": "projector + composite banded over pthreads; sort and binning stay serial"},
+            "model_b_sequential_raster": {"seconds": round(tb, 3), "cores": 1,
+                                          "note": "oracle restatement of SequentialRenderer.ts raster only (sorted order given)"},
             "frame_u8": rn["out_u8"]}
 
 

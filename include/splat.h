@@ -160,10 +160,19 @@ int splat_bin_run(splat_binner *b, const void *projected, uint32_t n_splats, con
                   uint32_t tile_row1);
 uint32_t splat_bin_tile_size(const splat_binner *b);        /* getTileSize() */
 int splat_bin_counts(splat_binner *b, void **dptr);          /* getTileCountsBuffer()  u32[numTiles] */
-int splat_bin_offsets(splat_binner *b, void **dptr);         /* getTileOffsetsBuffer() u32[numTiles] */
+int splat_bin_offsets(splat_binner *b, void **dptr);         /* getTileOffsetsBuffer() u32[numTiles] (+1: [numTiles] = total) */
 int splat_bin_indices(splat_binner *b, void **dptr);         /* getTileIndicesBuffer() u32[total]    */
 int splat_bin_total(splat_binner *b, uint64_t *total_pairs); /* sum of counts of the last run */
 int splat_bin_dims(splat_binner *b, uint32_t *ntx, uint32_t *nty);
+
+/* ---- PerTileSorter.sort  (src/PerTileSorter.ts:66-122,174-213) --------------------------------- */
+/* The reference re-sorts every tile's list by depth in LDS (racy, capped at 2048: SURVEY I3).  The
+ * binner here emits every list already in (depth key, index) order, so the stage is a CHECK: counts
+ * adjacent pairs of one tile that are not strictly increasing in (depth key, splat index).
+ * tile_offsets must have num_tiles + 1 entries (as splat_bin_offsets returns).  Synchronises. */
+int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void *tile_offsets,
+                              uint32_t num_tiles, const void *tile_indices, uint64_t total_pairs,
+                              uint64_t *violations_host);
 
 /* ---- ComputeShaderRenderer.render / TileRenderer.render  (src/ComputeShaderRenderer.ts:97-198,362-422) */
 #define SPLAT_COMPOSITE_FRONT_TO_BACK 0     /* SURVEY §8a contract 3: nearest on top (default) */

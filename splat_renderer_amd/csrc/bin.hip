@@ -188,6 +188,29 @@ __global__ __launch_bounds__(256) void k_tile_counts(const uint32_t *__restrict_
     if (t < tiles) counts[t] = offsets[t + 1] - offsets[t];
 }
 
+// PerTileSorter's job, as a check instead of a sort (src/PerTileSorter.ts:66-122 re-sorts every tile's
+// list by depth; here the lists leave the binner already in (depth key, index) order): pair i and
+// its successor, when they belong to the same tile, must be strictly increasing in (key, index).
+__global__ __launch_bounds__(256) void k_validate_tile_order(const float4 *__restrict__ projected,
+                                                             const uint32_t *__restrict__ offsets, uint32_t tiles,
+                                                             const uint32_t *__restrict__ indices, uint32_t pairs,
+                                                             unsigned long long *__restrict__ violations) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i + 1 >= pairs) return;
+    // tile of pair i: the last t with offsets[t] <= i (empty tiles share an offset with their successor)
+    uint32_t lo = 0, hi = tiles; // offsets[tiles] = pairs > i
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    if (i + 1 >= offsets[lo + 1]) return; // i is the last entry of its tile
+    const uint32_t a = indices[i], b = indices[i + 1];
+    const uint32_t ka = __float_as_uint(reinterpret_cast<const float *>(projected)[(size_t)a * 8 + 4]);
+    const uint32_t kb = __float_as_uint(reinterpret_cast<const float *>(projected)[(size_t)b * 8 + 4]);
+    const uint32_t sa = ka ^ (((ka >> 31) == 1u) ? 0xffffffffu : 0x80000000u), sb = kb ^ (((kb >> 31) == 1u) ? 0xffffffffu : 0x80000000u);
+    if (sa > sb || (sa == sb && a >= b)) atomicAdd(violations, 1ull);
+}
+
 static void binner_free(splat_binner *b) {
     if (b->counts) (void)hipFree(b->counts);
     if (b->offsets) (void)hipFree(b->offsets);
@@ -425,6 +448,28 @@ int splat_bin_total(splat_binner *b, uint64_t *total_pairs) {
     if (int rc = binner_settle(b)) return rc;
     if (!b->ran) return ctx_fail(b->ctx, SPLAT_ERR_STATE, "binSplats has not run");
     *total_pairs = b->total;
+    return SPLAT_OK;
+}
+
+int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void *tile_offsets, uint32_t num_tiles,
+                              const void *tile_indices, uint64_t total_pairs, uint64_t *violations_host) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, violations_host && (total_pairs == 0 || (projected && tile_offsets && tile_indices)) && num_tiles >= 1);
+    ARG_CHECK(ctx, total_pairs < (1ull << 32));
+    *violations_host = 0;
+    if (total_pairs < 2) return SPLAT_OK;
+    int rc = ctx_ensure_scan_ws(ctx, 256);
+    if (rc != SPLAT_OK) return rc;
+    unsigned long long *d = (unsigned long long *)ctx->scan_ws;
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_validate_tile_order, dim3(div_up((uint32_t)total_pairs, 256)), dim3(256), 0, ctx->stream,
+                       (const float4 *)projected, (const uint32_t *)tile_offsets, num_tiles, (const uint32_t *)tile_indices,
+                       (uint32_t)total_pairs, d);
+    LAUNCH_CHECK(ctx, "k_validate_tile_order");
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *violations_host = v;
     return SPLAT_OK;
 }
 

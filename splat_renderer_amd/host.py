@@ -370,15 +370,26 @@ class GPUTileBinner:
 
 class PerTileSorter:
     """src/PerTileSorter.ts:6-223.  The reference's per-tile LDS sort is racy and capped at 2048
-    entries; GPUTileBinner here already emits every list in sorted order, so sort()
-    has nothing to reorder and is a no-op kept for call-site compatibility."""
+    entries; GPUTileBinner here already emits every list in (depth key, index) order, so
+    sort() has nothing to reorder.  It keeps the reference's argument list and, with validate=True,
+    runs the order CHECK on the device and returns the number of out-of-order neighbours (0)."""
 
-    def __init__(self, device):
-        self.device = device
+    def __init__(self, device, validate=False):
+        self.device, self.validate = device, validate
+        self.violations = 0
 
     def sort(self, commandEncoder, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, splatIndicesBuffer, numTiles,
-             maxSplatsPerTile):  # :174-213
-        return None
+             maxSplatsPerTile, totalPairs=None):  # :174-213
+        if not self.validate:
+            return None
+        d = self.device
+        if totalPairs is None:
+            totalPairs = splatIndicesBuffer.size // 4
+        v = C.c_uint64()
+        check(d.lib.splat_validate_tile_order(d.ctx, projectedBuffer.ptr, tileOffsetsBuffer.ptr, numTiles,
+                                              splatIndicesBuffer.ptr, totalPairs, C.byref(v)), d.ctx)
+        self.violations = int(v.value)
+        return self.violations
 
     def cleanupTempBuffers(self):
         pass
@@ -467,6 +478,45 @@ class TileRenderer(ComputeShaderRenderer):
         return ComputeShaderRenderer.render(self, uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer,
                                             self._projected, self._counts, self._offsets, tileSize, numTilesX, width, height,
                                             wantFloat)
+
+
+class SequentialRenderer:
+    """src/SequentialRenderer.ts:5-321 — the ordering-exact path: one draw per splat in the order of a
+    caller-supplied sorted index buffer (:268-307).  The reference does this with the hardware
+    rasteriser and an oriented-quad footprint ("model B"), which only the CPU oracle
+    restates.  This class keeps the name, constructor and render() arguments and honours the
+    caller's order exactly — it bins the given order and composites it with the HIP kernel — but
+    with the ComputeShaderRenderer footprint (model A), nearest-first: pass near-to-far indices
+    (RadixSorter's order), not the reversed order the reference's blend state needs."""
+
+    def __init__(self, device, context=None, presentationFormat="rgba8unorm", numSplats=0, tileSize=16):
+        self.device, self.numSplats, self.tileSize = device, numSplats, tileSize
+        self.projector = SplatProjector(device, numSplats)
+        self.binner = GPUTileBinner(device, tileSize)
+        self.compositor = ComputeShaderRenderer(device, context, presentationFormat)
+
+    def render(self, uniformData, splatPropertyBuffer, sortedIndexBuffer, curvatureBuffer, width, height,
+               wantFloat=False):  # :233-314
+        u = _uniform_floats(uniformData).copy()
+        if u.shape[0] < 22:
+            u = np.concatenate([u[:20], np.array([width, height], np.float32)])
+        self.projector.project(None, u, splatPropertyBuffer)
+        self.binner.binSplats(None, self.projector.getProjectedBuffer(), sortedIndexBuffer, self.numSplats, width, height)
+        self.compositor.render(u, splatPropertyBuffer, self.binner.getTileIndicesBuffer(), curvatureBuffer,
+                               self.projector.getProjectedBuffer(), self.binner.getTileCountsBuffer(),
+                               self.binner.getTileOffsetsBuffer(), self.tileSize, -(-width // self.tileSize), width, height,
+                               wantFloat)
+
+    def readPixels(self):
+        return self.compositor.readPixels()
+
+    def readPixelsFloat(self):
+        return self.compositor.readPixelsFloat()
+
+    def destroy(self):  # :316-320
+        self.projector.destroy()
+        self.binner.destroy()
+        self.compositor.destroy()
 
 
 class Renderer:

@@ -518,3 +518,47 @@ def test_sync_free_overflow_is_detected_and_recovered(device):
     assert r2.finish() == ref["indices"].shape[0]
     for o in (r, r2, sbuf, bbuf, nbuf):
         o.destroy()
+
+
+def test_per_tile_sorter_validates_order(device):
+    """PerTileSorter keeps its call site; as a validator it finds 0 out-of-order neighbours in the
+    binner's lists and > 0 once two entries of a list are swapped."""
+    n, w, h = 20000, 320, 200
+    props, normals, u = make_case(n, w, h, 71, 1.5)
+    g = run_gpu_pipeline(device, props, normals, u, n, w, h)
+    b = g["binner"]
+    total = b.getTotalIndices()
+    pts = sr.PerTileSorter(device, validate=True)
+    assert pts.sort(None, g["proj"].getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer(),
+                    b.getTileIndicesBuffer(), 20 * 13, 4096, total) == 0
+    counts = b.getTileCountsBuffer().read(np.uint32)
+    offsets = b.getTileOffsetsBuffer().read(np.uint32)
+    t = int(np.argmax(counts))
+    idx = b.getTileIndicesBuffer().read(np.uint32, total)
+    o = int(offsets[t])
+    idx[o], idx[o + 5] = idx[o + 5], idx[o]
+    b.getTileIndicesBuffer().write(idx)
+    assert pts.sort(None, g["proj"].getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer(),
+                    b.getTileIndicesBuffer(), 20 * 13, 4096, total) > 0
+    assert sr.PerTileSorter(device).sort(None, None, None, None, None, 0, 0) is None  # reference call shape, no-op
+    destroy_all(g)
+
+
+def test_sequential_renderer_honours_given_order(device):
+    """SequentialRenderer.render(uniforms, props, sortedIdx, curvature, W, H): the image is the
+    composite of exactly the given order (here: a deliberately NON-depth order, index order)."""
+    n, w, h = 3000, 160, 96
+    props, normals, u = make_case(n, w, h, 81, 2.0)
+    order = np.arange(n, dtype=np.uint32)
+    proj = O.project(u, props)
+    counts, offsets, idx = O.bin_sorted(proj, order, w, h)
+    want, _, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, proj, idx, counts, offsets, w, h)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf, obuf = device.createBufferFrom(normals), device.createBufferFrom(order)
+    r = sr.SequentialRenderer(device, None, "rgba8unorm", n)
+    r.render(u[:20], pm.getPropertyBuffer(), obuf, nbuf, w, h, wantFloat=True)  # 20-float block: W,H appended
+    err = np.abs(r.readPixelsFloat() - want)
+    assert err.max() <= TOL_EARLY_OUT_BOUND and (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
+    for o in (r, pm, nbuf, obuf):
+        o.destroy()
