@@ -146,10 +146,15 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
         range32 = binner->range32;
     }
     ARG_CHECK(ctx, (((uintptr_t)props | (uintptr_t)projected) & 15) == 0);
-    rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), splat_sort_payload(sorter), n, range32, &bp);
+    // (the payload array is not written: payload = splat index, synthesised by the sort's first pass)
+    rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp);
     if (rc != SPLAT_OK) return rc;
-    rc = splat_sort_run(sorter, n, 0, 32); // RadixSorter.sort()
+    stage_begin(ctx, SPLAT_STAGE_SORT);
+    rc = radix_sort_pairs(ctx, sorter->keys, sorter->payload, sorter->keys_b, sorter->payload_b, sorter->hist, n, 0, 32,
+                          &sorter->result_in_primary, 0, nullptr, true); // RadixSorter.sort()
+    stage_end(ctx, SPLAT_STAGE_SORT);
     if (rc != SPLAT_OK) return rc;
+    sorter->ran = true;
     rc = binner_run(binner, projected, n, splat_sort_sorted_payload(sorter), n, width, height, row0, row1, range32);
     if (rc != SPLAT_OK) return rc;
     // (fields, not the public getters: those wait for a sync-free frame's pair total to come back)

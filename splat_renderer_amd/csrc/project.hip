@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
     if (i >= n) {
         if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
             keys[i] = 0xffffffffu;
-            payload[i] = 0xffffffffu;
+            if (payload) payload[i] = 0xffffffffu;
         }
         return;
     }
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
     projected[(size_t)i * 2 + 1] = b;
     if (WITH_KEYS) {
         keys[i] = depth_key(depth);
-        payload[i] = index_base + i;
+        if (payload) payload[i] = index_base + i; // (frame path: the sort's first pass synthesises it)
     }
     if (WITH_RANGE) { // the binner's clamped tile range while the bounds are still in registers:
         // after the sort it is then a 4-byte gather instead of a 16-byte one

@@ -222,7 +222,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
         const uint32_t p = wbase + i * 64;
         const uint32_t q = FULL ? p : ((p < valid) ? p : (valid - 1));
         key[i] = keys_in[base + q];
-        pay[i] = pay_in[base + q];
+        pay[i] = pay_in ? pay_in[base + q] : (base + q); // no payload array: the payload is the element's index
     }
     if (!ONESWEEP) __syncthreads(); // wave_hist zeroed
 
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(OS_ITEMS)) void k_r
 static int g_radix_mode = -1;
 
 static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
-                              const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
+                              const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary,
+                              bool iota_payload) {
     const uint32_t parts = div_up(n, RS_PART_KEYS);
     uint32_t *ki = k0, *pi = p0, *ko = k1, *po = p1;
     bool primary = true;
@@ -428,7 +429,10 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
         uint32_t *totals = hist + (size_t)256 * parts;
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals);
         LAUNCH_CHECK(ctx, "k_radix_rowscan");
-        hipLaunchKernelGGL(k_radix_downsweep<RS_ITEMS>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pi, ko, po, n, n_dev,
+        // iota_payload: the input payload is 0,1,2,... (fresh from the projector): the first pass
+        // synthesises it instead of reading 4 B per key that the projector would have had to write
+        const uint32_t *pin = (iota_payload && shift == bit_begin) ? nullptr : pi;
+        hipLaunchKernelGGL(k_radix_downsweep<RS_ITEMS>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n, n_dev,
                            shift, mask, parts, hist, totals);
         LAUNCH_CHECK(ctx, "k_radix_downsweep");
         uint32_t *t = ki; ki = ko; ko = t;
@@ -467,7 +471,8 @@ static int radix_sort_onesweep(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint3
 }
 
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
-                     uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode, const uint32_t *n_dev) {
+                     uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode, const uint32_t *n_dev,
+                     bool iota_payload) {
     if (g_radix_mode < 0) {
         g_radix_mode = 0;
         if (const char *e = getenv("SPLAT_RADIX_MODE")) g_radix_mode = (e[0] == 'o' || e[0] == '1') ? 1 : 0;
@@ -476,9 +481,9 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
     if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
     if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
     if (mode < 0) mode = g_radix_mode;
-    if (n_dev) mode = 0; // a device-side count is only supported by the rowscan kernels
+    if (n_dev || iota_payload) mode = 0; // device-side counts / implicit payloads: rowscan kernels only
     if (mode == 1) return radix_sort_onesweep(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
-    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary);
+    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary, iota_payload);
 }
 
 // the look-back's timeout word (workspace word 1028): non-zero after a sort = a chained scan gave up
