@@ -222,6 +222,13 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                      const splat_composite_cfg *cfg, const void *props, const void *normals,
                      const void *records, uint32_t n_records, uint32_t width, uint32_t height,
                      void *out_rgba8, void *out_rgba32f, void *consumed_dptr);
+/* After the first frame splat_band_frame sizes its sort/bin grids from the PREVIOUS frame's kept count
+ * and pair total (x1.125) and learns its own asynchronously; a frame that outgrew those bounds is
+ * reported by the next splat_band_frame / splat_band_settle call with SPLAT_ERR_CAPACITY (render it
+ * again; the bounds have been raised).  splat_band_settle waits for the last frame's readbacks, so
+ * on SPLAT_OK that frame's image is final; it returns its kept count and pair total. */
+int splat_band_settle(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, uint32_t *n_kept_host,
+                      uint64_t *pairs_host);
 /* Number of splats the last splat_band_frame / splat_band_keys kept (synchronises). */
 int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host);
 

@@ -80,6 +80,7 @@ SIGNATURES = {
                                 _u32, _vp, _vp, _vp]),
     "splat_project_slice": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
     "splat_band_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "splat_band_settle": (_i, [_vp, _vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "splat_band_kept": (_i, [_vp, _vp, C.POINTER(_u32)]),
     "splat_band_keys": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
 }

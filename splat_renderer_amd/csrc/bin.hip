@@ -158,34 +158,29 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
     }
 }
 
-// Tile offsets from the tile-sorted pair keys: the thread at the first pair of tile t writes
-// offsets[u] = i for every u in (previous tile, t] (empty tiles in between start where t starts),
-// the thread at the last pair closes the tail with offsets[u] = P.  offsets has T+1 entries.
-// Same values as the exclusive scan of the counts (TileBinner.ts:452-459), with no atomics:
-// 11M global atomic increments cost 1.03 ms at C2, this costs a few microseconds.
-__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ sorted_tiles, uint32_t pairs_host,
-                                                      const uint32_t *__restrict__ pairs_dev, uint32_t tiles,
-                                                      uint32_t *__restrict__ offsets) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t pairs = pairs_dev ? min(*pairs_dev, pairs_host) : pairs_host;
-    if (pairs == 0) { // (only possible with a device-side count) every list is empty
-        if (blockIdx.x == 0)
-            for (uint32_t u = threadIdx.x; u <= tiles; u += 256u) offsets[u] = 0;
-        return;
+// Tile offsets and counts from the tile-sorted pair keys: thread t finds the first pair whose tile
+// id is >= t and the first whose id is >= t + 1 by binary search (the same values as the exclusive
+// scan of the counts, TileBinner.ts:452-459).  No atomics (the first version's 11M global atomic
+// increments cost 1.03 ms at C2) and no serial gap filling (a band of a multi-GPU frame has thousands
+// of empty tiles before its first pair): T threads x ~2 x 24 loads, a few microseconds.
+__device__ __forceinline__ uint32_t lower_bound_tile(const uint32_t *__restrict__ sorted_tiles, uint32_t pairs, uint32_t t) {
+    uint32_t lo = 0, hi = pairs;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (sorted_tiles[mid] < t) lo = mid + 1; else hi = mid;
     }
-    if (i >= pairs) return;
-    const uint32_t t = min(sorted_tiles[i], tiles - 1);
-    const int64_t prev = (i == 0) ? -1 : (int64_t)min(sorted_tiles[i - 1], tiles - 1);
-    if ((int64_t)t != prev)
-        for (int64_t u = prev + 1; u <= (int64_t)t; ++u) offsets[u] = i;
-    if (i == pairs - 1)
-        for (uint32_t u = t + 1; u <= tiles; ++u) offsets[u] = pairs;
+    return lo;
 }
 
-__global__ __launch_bounds__(256) void k_tile_counts(const uint32_t *__restrict__ offsets, uint32_t tiles,
-                                                     uint32_t *__restrict__ counts) {
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t < tiles) counts[t] = offsets[t + 1] - offsets[t];
+__global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ sorted_tiles, uint32_t pairs_host,
+                                                      const uint32_t *__restrict__ pairs_dev, uint32_t tiles,
+                                                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ counts) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t > tiles) return;
+    const uint32_t pairs = pairs_dev ? min(*pairs_dev, pairs_host) : pairs_host;
+    const uint32_t lo = lower_bound_tile(sorted_tiles, pairs, t);
+    offsets[t] = lo; // offsets[tiles] = pairs
+    if (t < tiles) counts[t] = lower_bound_tile(sorted_tiles, pairs, t + 1) - lo;
 }
 
 // PerTileSorter's job, as a check instead of a sort (src/PerTileSorter.ts:66-122 re-sorts every tile's
@@ -343,11 +338,9 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         }
         if (rc != SPLAT_OK) return rc;
         const uint32_t *sorted_tiles = b->pairs.result_in_primary ? b->pairs.keys : b->pairs.keys_b;
-        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(total32, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
-                           tiles, b->offsets);
+        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
+                           tiles, b->offsets, b->counts);
         LAUNCH_CHECK(ctx, "k_tile_offsets");
-        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts);
-        LAUNCH_CHECK(ctx, "k_tile_counts");
         if (async) { // {total, overflow} come back without stalling the stream; examined at the next call
             HIP_TRY(ctx, hipMemcpyAsync(b->pinned, b->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipEventRecord(b->readback_done, ctx->stream));

@@ -81,6 +81,12 @@ struct splat_sorter {
     uint32_t *keys = nullptr, *keys_b = nullptr, *payload = nullptr, *payload_b = nullptr;
     uint32_t *hist = nullptr;
     uint32_t *d_count = nullptr; // device-side element count for sync-free callers (splat_band_keys)
+    // splat_band_frame: the kept count of the previous frame bounds this frame's sort/bin grids
+    // (1.125x), its own count comes back asynchronously and is examined at the next call
+    bool count_pending = false, have_last_count = false;
+    uint32_t last_count = 0, count_bound = 0;
+    uint32_t *pinned_count = nullptr; // 4 u32 host-pinned
+    hipEvent_t count_event = nullptr;
     bool result_in_primary = true;
     bool ran = false;
     int mode = -1; // -1 = library default, 0 = upsweep/rowscan/downsweep, 1 = onesweep (chained scan)

@@ -36,6 +36,80 @@ __global__ __launch_bounds__(256) void k_band_scatter(const float4 *__restrict__
     payload[s] = i;
 }
 
+// ---- fused band filter for splat_band_frame (tile coordinates fit 8 bits) -------------------------
+// prepare: one coalesced pass over the gathered 32-byte records: per record the depth key and the
+// band-clamped tile range (in index order), per 512-record block the number kept.
+constexpr uint32_t BAND_THREADS = 256, BAND_PER_THREAD = 2, BAND_BLOCK = BAND_THREADS * BAND_PER_THREAD;
+
+__global__ __launch_bounds__(BAND_THREADS) void k_band_prepare(const float4 *__restrict__ records, uint32_t n, BinParams bp,
+                                                               uint32_t *__restrict__ keys_by_idx,
+                                                               uint32_t *__restrict__ range32, uint32_t *__restrict__ blocksums) {
+    __shared__ uint32_t wsum[4];
+    uint32_t kept = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BAND_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * BAND_BLOCK + k * BAND_THREADS + threadIdx.x;
+        if (i < n) {
+            const float4 a = records[(size_t)i * 2], b = records[(size_t)i * 2 + 1];
+            uint32_t tx0, tx1, ty0, ty1;
+            const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
+            range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
+            keys_by_idx[i] = depth_key_of(b.x);
+            kept += ok ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// compact: the kept (key, global index) pairs of block b go to [base[b], ...) in ascending index order
+__global__ __launch_bounds__(BAND_THREADS) void k_band_compact(const uint32_t *__restrict__ keys_by_idx,
+                                                               const uint32_t *__restrict__ range32, uint32_t n,
+                                                               const uint32_t *__restrict__ block_base,
+                                                               uint32_t *__restrict__ keys, uint32_t *__restrict__ payload) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t carry = block_base[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < BAND_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * BAND_BLOCK + k * BAND_THREADS + tid;
+        const bool keep = (i < n) && ((range32[i] & 0xffu) <= ((range32[i] >> 8) & 0xffu)); // tx0 <= tx1: not the empty code
+        const unsigned long long m = __ballot(keep);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
+        __syncthreads();
+        if (keep) {
+            const uint32_t o = carry + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + below;
+            keys[o] = keys_by_idx[i];
+            payload[o] = i;
+        }
+        carry += s0 + s1 + s2 + s3;
+    }
+}
+
+// Resolves the previous splat_band_frame's kept-count readback.  If that frame kept more splats than
+// the bound its grids were sized for, it was rendered from a truncated set: say so (once).
+static int band_settle_count(splat_ctx *ctx, splat_sorter *sorter) {
+    if (!sorter->count_pending) return SPLAT_OK;
+    sorter->count_pending = false;
+    HIP_TRY(ctx, hipEventSynchronize(sorter->count_event));
+    const uint32_t kept = *(volatile uint32_t *)sorter->pinned_count;
+    sorter->last_count = kept;
+    sorter->have_last_count = true;
+    if (kept > sorter->count_bound) {
+        sorter->have_last_count = false; // next frame: full-size grids, then learn again
+        return ctx_fail(ctx, SPLAT_ERR_CAPACITY,
+                        "the previous band frame kept more splats than its sync-free bound (1.125x the frame before it): it "
+                        "was rendered from a truncated set; render that frame again");
+    }
+    return SPLAT_OK;
+}
+
 // band filter, count left on the device in sorter->d_count (no host round trip)
 static int band_keys_device(splat_ctx *ctx, splat_sorter *sorter, const void *projected, uint32_t n, uint32_t width,
                             uint32_t height, uint32_t tile_size, uint32_t tile_row0, uint32_t tile_row1) {
@@ -88,18 +162,62 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (row0 > row1) row0 = row1;
     // keep -> sort -> bin with the kept count living on the device: no host round trip in here
-    int rc = SPLAT_OK;
+    int rc = band_settle_count(ctx, sorter); // the previous frame's kept count (async readback)
+    if (rc != SPLAT_OK) {
+        binner->have_last = false; // its pair total came from the truncated set: do not size the next frame from it
+        return rc;
+    }
+    const uint32_t ntx = div_up(width, tile);
+    const bool fast = ntx <= 256 && nty <= 256 && n_records > 0;
+    uint32_t *range32 = nullptr;
+    // grids of the sort and of the binner's count/expand are sized for `bound` kept splats: all
+    // records on a first frame, 1.125x the previous frame's kept count afterwards
+    uint32_t bound = n_records;
+    if (sorter->have_last_count) {
+        const uint64_t b = (uint64_t)sorter->last_count + sorter->last_count / 8 + 4096;
+        if (b < bound) bound = (uint32_t)b;
+    }
     if (n_records > 0) {
-        rc = band_keys_device(ctx, sorter, records, n_records, width, height, tile, row0, row1);
-        if (rc != SPLAT_OK) return rc;
+        if (n_records > sorter->capacity) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_band_frame: n_records exceeds the sorter's capacity");
+        if (fast) {
+            rc = binner_reserve_range32(binner, n_records);
+            if (rc != SPLAT_OK) return rc;
+            range32 = binner->range32;
+            const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
+            const uint32_t blocks = div_up(n_records, BAND_BLOCK);
+            uint32_t *keys_by_idx = sorter->keys_b, *blocksums = sorter->hist; // both free until the sort starts
+            stage_begin(ctx, SPLAT_STAGE_PROJECT);
+            hipLaunchKernelGGL(k_band_prepare, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records,
+                               bp, keys_by_idx, range32, blocksums);
+            LAUNCH_CHECK(ctx, "k_band_prepare");
+            rc = scan_exclusive_u32(ctx, blocksums, blocksums, blocks, sorter->d_count);
+            if (rc != SPLAT_OK) return rc;
+            hipLaunchKernelGGL(k_band_compact, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, keys_by_idx, range32, n_records,
+                               blocksums, sorter->keys, sorter->payload);
+            LAUNCH_CHECK(ctx, "k_band_compact");
+            stage_end(ctx, SPLAT_STAGE_PROJECT);
+        } else {
+            rc = band_keys_device(ctx, sorter, records, n_records, width, height, tile, row0, row1);
+            if (rc != SPLAT_OK) return rc;
+        }
+        // kept count -> host, without stalling the stream
+        if (!sorter->pinned_count) {
+            if (hipHostMalloc((void **)&sorter->pinned_count, 16, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&sorter->count_event, hipEventDisableTiming) != hipSuccess)
+                return ctx_fail(ctx, SPLAT_ERR_OOM, "band frame readback allocation");
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(sorter->pinned_count, sorter->d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(sorter->count_event, ctx->stream));
+        sorter->count_pending = true;
+        sorter->count_bound = bound;
         stage_begin(ctx, SPLAT_STAGE_SORT);
-        rc = radix_sort_pairs(ctx, sorter->keys, sorter->payload, sorter->keys_b, sorter->payload_b, sorter->hist, n_records, 0, 32,
+        rc = radix_sort_pairs(ctx, sorter->keys, sorter->payload, sorter->keys_b, sorter->payload_b, sorter->hist, bound, 0, 32,
                               &sorter->result_in_primary, 0, sorter->d_count);
         stage_end(ctx, SPLAT_STAGE_SORT);
         if (rc != SPLAT_OK) return rc;
         sorter->ran = true;
     }
-    rc = binner_run(binner, records, n_records, splat_sort_sorted_payload(sorter), n_records, width, height, row0, row1, nullptr,
+    rc = binner_run(binner, records, n_records, splat_sort_sorted_payload(sorter), bound, width, height, row0, row1, range32,
                     n_records ? sorter->d_count : nullptr);
     if (rc != SPLAT_OK) return rc;
     void *indices = binner->pairs.result_in_primary ? binner->pairs.payload : binner->pairs.payload_b;
@@ -108,6 +226,22 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     c2.tile_row1 = row1;
     return splat_composite(ctx, &c2, (const char *)props + 16, 2, normals, 1, records, indices, binner->counts, binner->offsets, width,
                            height, out_rgba8, out_rgba32f, consumed_dptr);
+}
+
+int splat_band_settle(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, uint32_t *n_kept_host, uint64_t *pairs_host) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, sorter && binner);
+    int rc = band_settle_count(ctx, sorter);
+    if (rc != SPLAT_OK) {
+        binner->have_last = false;
+        (void)binner_settle(binner); // drop that frame's pair readback as well
+        return rc;
+    }
+    rc = binner_settle(binner);
+    if (rc != SPLAT_OK) return rc;
+    if (n_kept_host) *n_kept_host = sorter->last_count;
+    if (pairs_host) *pairs_host = binner->total;
+    return SPLAT_OK;
 }
 
 int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host) {

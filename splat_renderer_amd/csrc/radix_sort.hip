@@ -556,6 +556,8 @@ int splat_sort_create(splat_ctx *ctx, uint32_t capacity, splat_sorter **out) {
 void splat_sort_destroy(splat_sorter *s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->pinned_count) (void)hipHostFree(s->pinned_count);
+    if (s->count_event) (void)hipEventDestroy(s->count_event);
     sorter_free(s);
     delete s;
 }

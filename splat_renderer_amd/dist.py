@@ -139,12 +139,13 @@ class HipStages:
             rc = self.lib.splat_band_frame(*args)
         check(rc, self.ctx)
         if settle:
-            t = C.c_uint64()
-            rc = self.lib.splat_bin_total(self.binner, C.byref(t))
-            if rc == -4:
+            t, k = C.c_uint64(), C.c_uint32()
+            for _ in range(4):  # kept-count overflow, then pair overflow, at worst
+                rc = self.lib.splat_band_settle(self.ctx, self.sorter, self.binner, C.byref(k), C.byref(t))
+                if rc != -4:
+                    break
                 self.overflows += 1
                 check(self.lib.splat_band_frame(*args), self.ctx)
-                rc = self.lib.splat_bin_total(self.binner, C.byref(t))
             check(rc, self.ctx)
             self.pairs = int(t.value)
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-rank device time of the multi-GPU frame, measured on ONE GPU with virtual ranks (the
+all-gather is a pre-built concat and is NOT included): python tools/band_bench.py [C2] [G ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import splat_renderer_amd as sr
+from splat_renderer_amd import dist
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C2"
+worlds = [int(a) for a in sys.argv[2:]] or [1, 2, 4, 8]
+n, w, h = sr.scene.CONFIGS[name]
+props, normals = sr.scene.make_scene(n)
+cam = sr.Camera()
+cam.setAspect(w / h)
+u = cam.uniforms(w, h)
+pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+for world in worlds:
+    per = dist.shard_size(n, world)
+    st = dist.HipStages(torch, 0, per * world, w, h)
+    brs = [dist.BandRenderer(st, n, w, h, r, world, None) for r in range(world)]
+    for br in brs:
+        st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+    gathered = torch.cat([br.shard for br in brs], dim=0).contiguous()
+    # balance bands by pairs per row from one calibration pass over all rows
+    full = dist.BandRenderer(st, n, w, h, 0, 1, None)
+    st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), 0, full.nty, full.image, settle=True)
+    rows = st.row_pairs()
+    bands = dist.balanced_rows(rows, world)
+    out = []
+    for r, br in enumerate(brs):
+        r0, r1 = bands[r]
+        for _ in range(3):
+            st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+            st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), r0, r1, br.image, settle=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 20
+        for _ in range(K):
+            st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+            st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), r0, r1, br.image)
+        torch.cuda.synchronize()
+        out.append(((time.perf_counter() - t0) / K * 1e3, r1 - r0, st.kept))
+    print(f"{name} G={world}: per-rank ms (rows, kept): " + "  ".join(f"{t:.3f} ({rr},{k})" for t, rr, k in out)
+          + f"   max {max(t for t, _, _ in out):.3f} ms  [+ all-gather of {per * 32 / 1e6:.0f} MB shards]")
+    st.destroy()
