@@ -100,6 +100,18 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     const float inv_sqrt3 = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
     uint32_t staged = 0;
 
+    // ---- list-entry fetch, split from its use (issue early / write LDS late).  Almost every tile
+    // saturates inside its first batch, but tiles on a silhouette keep some pixel open and walk
+    // their whole list (thousands of entries): from their second batch on, the NEXT batch's gathers
+    // are issued before the current batch is consumed, so the ~3 us dependent-load chain (index, then
+    // record / colour / normal) overlaps the arithmetic instead of preceding it.
+    uint32_t f_idx = 0xffffffffu;              // splat index of the entry this thread stages
+    float4 f_b = make_float4(0, 0, 0, 0), f_c = f_b, f_n = f_b;
+    float f_r = 0.0f;
+    bool f_ready = false;                      // f_* already hold this thread's entry of the batch about to be staged
+    uint32_t n_idx = 0xffffffffu;              // index of this thread's entry one batch further on (the gathers depend on it)
+    bool n_idx_valid = false;
+
     for (uint32_t base = 0; base < count; base += CBATCH) {
         __syncthreads(); // previous batch fully consumed (and s_wave_done visible)
         if (EARLY_OUT) {
@@ -113,13 +125,21 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float2 col = make_float2(0.0f, 0.0f);
             uint32_t xm = 0, ym = 0;
-            if (e < count) {
-                const uint32_t s = p.indices[off + e];
-                const float4 b = p.projected[(size_t)s * 2];
-                const float r = reinterpret_cast<const float *>(p.projected)[(size_t)s * 8 + 5];
+            if (!f_ready) { // the first three batches of a tile: fetch now
+                f_idx = (e < count) ? p.indices[off + e] : 0xffffffffu;
+                if (f_idx != 0xffffffffu) {
+                    f_b = p.projected[(size_t)f_idx * 2];
+                    f_r = reinterpret_cast<const float *>(p.projected)[(size_t)f_idx * 8 + 5];
+                    f_c = p.color[(size_t)f_idx * p.color_stride];
+                    f_n = p.normals[(size_t)f_idx * p.normal_stride];
+                }
+            }
+            if (f_idx != 0xffffffffu) {
+                const float4 b = f_b;
+                const float r = f_r;
                 if (!(r < 0.5f)) { // :127-129 "too small"
-                    const float4 c = p.color[(size_t)s * p.color_stride];
-                    const float4 nrm = p.normals[(size_t)s * p.normal_stride];
+                    const float4 c = f_c;
+                    const float4 nrm = f_n;
                     const float ndl = (nrm.x * inv_sqrt3 + nrm.y * inv_sqrt3) + nrm.z * inv_sqrt3;
                     const float kd = 0.85f + 0.15f * fmaxf(ndl, 0.0f); // :144-145
                     col = make_float2(c.x * kd, c.y * kd);
@@ -135,6 +155,23 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             s_mask[1][tid] = quadrant_mask(xm >> 8, ym & 0xffu);
             s_mask[2][tid] = quadrant_mask(xm & 0xffu, ym >> 8);
             s_mask[3][tid] = quadrant_mask(xm >> 8, ym >> 8);
+            // issue the fetches for later batches; nothing below waits for them until the next stage
+            f_ready = false;
+            if (base >= CBATCH) { // a tile that needed a second batch usually needs more
+                if (n_idx_valid) { // index of batch k+1 arrived a batch ago: its gathers go out now
+                    f_idx = n_idx;
+                    if (f_idx != 0xffffffffu) {
+                        f_b = p.projected[(size_t)f_idx * 2];
+                        f_r = reinterpret_cast<const float *>(p.projected)[(size_t)f_idx * 8 + 5];
+                        f_c = p.color[(size_t)f_idx * p.color_stride];
+                        f_n = p.normals[(size_t)f_idx * p.normal_stride];
+                    }
+                    f_ready = true;
+                }
+                const uint32_t e2 = e + 2 * CBATCH; // batch k+2
+                n_idx = (e2 < count) ? p.indices[off + e2] : 0xffffffffu;
+                n_idx_valid = true;
+            }
         }
         staged = (count - base < CBATCH) ? count : base + CBATCH;
         __syncthreads();
