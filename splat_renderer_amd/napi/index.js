@@ -139,10 +139,17 @@ class GPUTileBinner {
   destroy() { if (this.handle) native.bin_destroy(this.handle); this.handle = null; }
 }
 
-/** src/PerTileSorter.ts:6-223 — lists leave GPUTileBinner already sorted; kept for call-site compatibility */
+/** src/PerTileSorter.ts:6-223 — lists leave GPUTileBinner already in (depth key, index) order, so sort()
+ * reorders nothing; with validate=true it runs the order check on the device and returns the number
+ * of out-of-order neighbours (0). */
 class PerTileSorter {
-  constructor(device) { this.device = device; }
-  sort() {}
+  constructor(device, validate = false) { this.device = device; this.validate = validate; this.violations = 0; }
+  sort(commandEncoder, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, splatIndicesBuffer, numTiles, maxSplatsPerTile, totalPairs) { // :174-213
+    if (!this.validate) return undefined;
+    const total = totalPairs === undefined ? splatIndicesBuffer.size / 4 : totalPairs;
+    this.violations = native.validate_tile_order(this.device.ctx, projectedBuffer.ptr, tileOffsetsBuffer.ptr, numTiles, splatIndicesBuffer.ptr, total);
+    return this.violations;
+  }
   cleanupTempBuffers() {}
   destroy() {}
 }
@@ -176,6 +183,28 @@ class TileRenderer extends ComputeShaderRenderer {
     if (!this.bound) throw new Error('TileRenderer.render: call bindTileData(projected, counts, offsets) first');
     super.render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, this.bound[0], this.bound[1], this.bound[2], tileSize, numTilesX, width, height);
   }
+}
+
+/** src/SequentialRenderer.ts:5-321 — ordering-exact path: composites exactly the order of the caller's
+ * sorted index buffer (near-to-far), with the ComputeShaderRenderer footprint; the reference's
+ * oriented-quad hardware raster (model B) exists only in the CPU oracle. */
+class SequentialRenderer {
+  constructor(device, context = null, presentationFormat = 'rgba8unorm', numSplats = 0, tileSize = 16) {
+    this.device = device; this.numSplats = numSplats; this.tileSize = tileSize;
+    this.projector = new SplatProjector(device, numSplats); this.binner = new GPUTileBinner(device, tileSize);
+    this.compositor = new ComputeShaderRenderer(device, context, presentationFormat);
+  }
+  render(uniformData, splatPropertyBuffer, sortedIndexBuffer, curvatureBuffer, width, height) { // :233-314
+    let u = uniformFloats(uniformData);
+    if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
+    this.projector.project(null, u, splatPropertyBuffer);
+    native.bin_run(this.device.ctx, this.binner.handle, this.projector.getProjectedBuffer().ptr, this.numSplats, sortedIndexBuffer.ptr, this.numSplats, width, height, 0, U32_MAX);
+    this.binner.numTiles = Math.ceil(width / this.tileSize) * Math.ceil(height / this.tileSize);
+    this.compositor.render(u, splatPropertyBuffer, this.binner.getTileIndicesBuffer(), curvatureBuffer, this.projector.getProjectedBuffer(),
+      this.binner.getTileCountsBuffer(), this.binner.getTileOffsetsBuffer(), this.tileSize, Math.ceil(width / this.tileSize), width, height);
+  }
+  readPixels() { return this.compositor.readPixels(); }
+  destroy() { this.projector.destroy(); this.binner.destroy(); this.compositor.destroy(); } // :316-320
 }
 
 /** src/Renderer.ts:13,250,311 — name kept as the whole-frame facade (project -> keys -> sort -> bin -> composite) */
@@ -237,4 +266,4 @@ class Camera {
 }
 
 module.exports = { native, Device, Buffer: Buffer_, Camera, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
-  GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL };
+  GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, SequentialRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL };

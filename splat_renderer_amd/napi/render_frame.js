@@ -23,6 +23,10 @@ if (!threw) throw new Error('getter before binSplats did not throw');
   extractor.extract(enc, projector.getProjectedBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), n, sorter.paddedSize);
   sorter.sort();
   await binner.binSplats(enc, projector.getProjectedBuffer(), sorter.getSortedIndicesBuffer(), n, W, H);
+  const checker = new sr.PerTileSorter(device, true);
+  const bad = checker.sort(enc, projector.getProjectedBuffer(), binner.getTileCountsBuffer(), binner.getTileOffsetsBuffer(),
+    binner.getTileIndicesBuffer(), binner.numTiles, 4096, binner.getTotalIndices());
+  if (bad !== 0) throw new Error('PerTileSorter validator found ' + bad + ' out-of-order neighbours');
   renderer.render(uniforms, props.getPropertyBuffer(), binner.getTileIndicesBuffer(), normals, projector.getProjectedBuffer(),
     binner.getTileCountsBuffer(), binner.getTileOffsetsBuffer(), 16, Math.ceil(W / 16), W, H);
   fs.writeFileSync(outPath, Buffer.from(renderer.readPixels().buffer));

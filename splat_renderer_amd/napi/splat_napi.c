@@ -227,6 +227,12 @@ FN(bin_total) {
     uint64_t t = 0; int rc = splat_bin_total(b, &t);
     return check(env, x, rc, mk_number(env, (double)t));
 }
+FN(validate_tile_order) { /* (ctx, projected, offsets, numTiles, indices, totalPairs) -> violations */
+    ARGS(6); splat_ctx *x = arg_external(&c, 0); void *proj = arg_dptr(&c, 1), *off = arg_dptr(&c, 2); uint32_t nt = (uint32_t)arg_number(&c, 3);
+    void *idx = arg_dptr(&c, 4); uint64_t total = (uint64_t)arg_number(&c, 5); BAIL;
+    uint64_t v = 0; int rc = splat_validate_tile_order(x, proj, off, nt, idx, total, &v);
+    return check(env, x, rc, mk_number(env, (double)v));
+}
 static void fill_cfg(call_t *c, size_t i, splat_composite_cfg *cfg) { /* [mode, earlyOut, tile, row0, row1] */
     memset(cfg, 0, sizeof *cfg);
     uint32_t v[5] = {0, 1, 16, 0, 0xffffffffu};
@@ -264,7 +270,7 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(project), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
-        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(composite), EXPORT(render_frame),
+        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;
