@@ -127,8 +127,13 @@ int splat_sort_run(splat_sorter *s, uint32_t n, uint32_t bit_begin, uint32_t bit
 /* getSortedIndicesBuffer(): payload in sorted order (valid after splat_sort_run). */
 void *splat_sort_sorted_payload(splat_sorter *s);
 void *splat_sort_sorted_keys(splat_sorter *s);
+/* Hardware probe (diagnostic): runs ~2M wave instructions of returning LDS atomics with colliding
+ * addresses and counts those whose return values were NOT in ascending lane order.  Synchronises. */
+int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches);
 /* Sort algorithm of this sorter: 0 = per-pass histogram + row scan + scatter (default, fastest on
- * MI355X), 1 = onesweep with decoupled look-back (the reference's structure), -1 = library default. */
+ * MI355X; ranks keys with returning LDS atomics when the lane-order probe above passes, else with
+ * ballots), 1 = onesweep with decoupled look-back (the reference's structure), 2 = as 0 but always
+ * ballot ranking, -1 = library default. */
 int splat_sort_set_mode(splat_sorter *s, int mode);
 /* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
  * (the result is then invalid).  Synchronises. */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "splat_sort_run": (_i, [_vp, _u32, _u32, _u32]),
     "splat_sort_sorted_payload": (_vp, [_vp]),
     "splat_sort_sorted_keys": (_vp, [_vp]),
+    "splat_probe_lds_atomic_order": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "splat_sort_set_mode": (_i, [_vp, _i]),
     "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),
     "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),

@@ -23,6 +23,7 @@ struct splat_ctx {
     bool own_stream = false;
     std::string err;
     bool timing = false;
+    int lds_atomic_ordered = -1; // -1 unknown, else the result of radix_probe_lds_atomic_order on this device
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars
@@ -73,6 +74,7 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
                      bool *result_in_primary, int mode = -1, const uint32_t *n_dev = nullptr,
                      bool iota_payload = false);
 
+int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host);
 int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);
 
 struct splat_sorter {

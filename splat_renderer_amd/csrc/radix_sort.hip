@@ -193,7 +193,7 @@ __device__ __forceinline__ uint32_t lookback(uint32_t *status, uint32_t part, ui
     return excl;
 }
 
-template <uint32_t ITEMS, bool FULL, bool ONESWEEP>
+template <uint32_t ITEMS, bool FULL, bool ONESWEEP, bool RANK_ATOMIC>
 __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__restrict__ s_kp, uint32_t part,
                                                const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ pay_out, uint32_t n,
@@ -233,28 +233,42 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     // returning atomics of a wave execute in program order, so the value returned for item i is
     // the number of keys of that digit in items < i: a stable rank, with the LDS round trips
     // pipelined (nothing waits on them until phase B) instead of chained.
-    uint32_t rank[ITEMS], prev[ITEMS];
+    uint32_t rank[ITEMS];
+    if (RANK_ATOMIC) {
+        // Measured property of gfx950 (splat_probe_lds_atomic_order, run once per context; the ballot
+        // path below is used if it ever fails): the lanes of one returning LDS atomic that hit the same
+        // address complete in ascending lane order.  Then old = atomicAdd(&counter[digit], 1) IS the
+        // stable rank: same-digit keys of earlier items (program order) + same-digit lanes below me.
 #pragma unroll
-    for (uint32_t i = 0; i < ITEMS; ++i) {
-        uint32_t d = (key[i] >> shift) & mask;
-        if (!FULL) d = (wbase + i * 64 < valid) ? d : 255u;
-        uint32_t plo = ~0u, phi = ~0u;
-#pragma unroll
-        for (uint32_t b = 0; b < 8; ++b) {
-            const uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31); // all ones if bit b of d is set
-            const uint64_t bal = __ballot(m != 0);
-            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);        // plo & ~(bal ^ m)
-            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
+        for (uint32_t i = 0; i < ITEMS; ++i) {
+            uint32_t d = (key[i] >> shift) & mask;
+            if (!FULL) d = (wbase + i * 64 < valid) ? d : 255u;
+            rank[i] = atomicAdd(&sh.wave_hist[w][d], 1u);
         }
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0)); // same-digit lanes below me
-        const uint32_t leader = plo ? (uint32_t)__builtin_ctz(plo) : 32u + (uint32_t)__builtin_ctz(phi);
-        rank[i] = below | (leader << 8);
-        prev[i] = 0;
-        if (below == 0) prev[i] = atomicAdd(&sh.wave_hist[w][d], (uint32_t)(__popc(plo) + __popc(phi)));
-    }
-    // ---- phase B: every lane fetches its leader's result -------------------------------------------
+    } else {
+        uint32_t prev[ITEMS];
 #pragma unroll
-    for (uint32_t i = 0; i < ITEMS; ++i) rank[i] = __shfl(prev[i], rank[i] >> 8) + (rank[i] & 0xffu);
+        for (uint32_t i = 0; i < ITEMS; ++i) {
+            uint32_t d = (key[i] >> shift) & mask;
+            if (!FULL) d = (wbase + i * 64 < valid) ? d : 255u;
+            uint32_t plo = ~0u, phi = ~0u;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                const uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31); // all ones if bit b of d is set
+                const uint64_t bal = __ballot(m != 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);        // plo & ~(bal ^ m)
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
+            }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0)); // same-digit lanes below me
+            const uint32_t leader = plo ? (uint32_t)__builtin_ctz(plo) : 32u + (uint32_t)__builtin_ctz(phi);
+            rank[i] = below | (leader << 8);
+            prev[i] = 0;
+            if (below == 0) prev[i] = atomicAdd(&sh.wave_hist[w][d], (uint32_t)(__popc(plo) + __popc(phi)));
+        }
+        // ---- phase B: every lane fetches its leader's result ---------------------------------------
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i) rank[i] = __shfl(prev[i], rank[i] >> 8) + (rank[i] & 0xffu);
+    }
     __syncthreads();
 
     // thread d: exclusive prefix over waves for digit d, and the partition's count of d
@@ -318,7 +332,7 @@ constexpr uint32_t downsweep_lds_bytes(uint32_t items) { return items * RS_THREA
 constexpr uint32_t downsweep_wg_per_cu(uint32_t items) { return items <= 6 ? 8 : items <= 12 ? 5 : items <= 16 ? 4 : 2; }
 static_assert(downsweep_wg_per_cu(RS_ITEMS) * downsweep_lds_bytes(RS_ITEMS) <= 160u * 1024u, "LDS budget");
 
-template <uint32_t ITEMS>
+template <uint32_t ITEMS, bool RANK_ATOMIC>
 __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ pay_out, uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t shift, uint32_t mask,
@@ -329,10 +343,10 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radi
     if (blockIdx.x * ITEMS * RS_THREADS >= n) return; // partition past the end (device-side n)
     // every partition but (possibly) the last is full: it takes the path with no per-key bounds checks
     if ((blockIdx.x + 1) * ITEMS * RS_THREADS <= n)
-        downsweep_body<ITEMS, true, false>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+        downsweep_body<ITEMS, true, false, RANK_ATOMIC>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                            scanned_hist, totals, nullptr, nullptr);
     else
-        downsweep_body<ITEMS, false, false>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+        downsweep_body<ITEMS, false, false, RANK_ATOMIC>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                             scanned_hist, totals, nullptr, nullptr);
 }
 
@@ -399,10 +413,10 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(OS_ITEMS)) void k_r
     __syncthreads();
     const uint32_t part = s_part;
     if ((part + 1) * OS_ITEMS * RS_THREADS <= n)
-        downsweep_body<OS_ITEMS, true, true>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
+        downsweep_body<OS_ITEMS, true, true, false>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
                                              status, err);
     else
-        downsweep_body<OS_ITEMS, false, true>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
+        downsweep_body<OS_ITEMS, false, true, false>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
                                               status, err);
 }
 
@@ -416,7 +430,15 @@ static int g_radix_mode = -1;
 
 static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
                               const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary,
-                              bool iota_payload) {
+                              bool iota_payload, bool force_ballot_rank) {
+    // ranking by returning LDS atomics needs the lane-order property: probed once per context
+    if (ctx->lds_atomic_ordered < 0) {
+        uint64_t bad = 1;
+        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+        if (prc != SPLAT_OK) return prc;
+        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
+    }
+    const bool rank_atomic = ctx->lds_atomic_ordered == 1 && !force_ballot_rank;
     const uint32_t parts = div_up(n, RS_PART_KEYS);
     uint32_t *ki = k0, *pi = p0, *ko = k1, *po = p1;
     bool primary = true;
@@ -432,8 +454,12 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
         // iota_payload: the input payload is 0,1,2,... (fresh from the projector): the first pass
         // synthesises it instead of reading 4 B per key that the projector would have had to write
         const uint32_t *pin = (iota_payload && shift == bit_begin) ? nullptr : pi;
-        hipLaunchKernelGGL(k_radix_downsweep<RS_ITEMS>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n, n_dev,
-                           shift, mask, parts, hist, totals);
+        if (rank_atomic)
+            hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, true>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n,
+                               n_dev, shift, mask, parts, hist, totals);
+        else
+            hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, false>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n,
+                               n_dev, shift, mask, parts, hist, totals);
         LAUNCH_CHECK(ctx, "k_radix_downsweep");
         uint32_t *t = ki; ki = ko; ko = t;
         t = pi; pi = po; po = t;
@@ -470,6 +496,69 @@ static int radix_sort_onesweep(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint3
     return SPLAT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Probe: do returning LDS atomics of ONE wave instruction that hit the same address complete in
+// ascending lane order?  (Then `old = atomicAdd(&counter[digit], 1)` is a stable rank by itself.)
+// The ISA does not promise it, so it is measured: random and adversarial address patterns, four
+// waves per workgroup on private counters, every returned value compared with the count of lower
+// lanes holding the same address.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe_lds_atomic_order(uint32_t rounds, uint32_t seed, unsigned long long *mismatches) {
+    __shared__ uint32_t cnt[4][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t state = seed ^ (blockIdx.x * 2654435761u) ^ (tid * 40503u + 1u);
+    unsigned long long bad = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        for (uint32_t i = lane; i < 256; i += 64) cnt[w][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        // number of distinct addresses this round: 1, 2, 3, 4, 8, 16, 64, 256 (wave-uniform choice)
+        const uint32_t kinds[8] = {1, 2, 3, 4, 8, 16, 64, 256};
+        const uint32_t k = kinds[(r + blockIdx.x) & 7];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { // four dependent-free instructions back to back, like the sort's items
+            state = state * 1664525u + 1013904223u;
+            uint32_t d = (state >> 10) % k;
+            if (((r >> 3) & 3) == 1) d = (lane / (64 / (k > 64 ? 64 : k))) % k; // runs of equal addresses
+            if (((r >> 3) & 3) == 2) d = (lane * 7u) % k;                          // strided
+            d = (d * 37u) & 255u;                                                  // spread over banks
+            // reference: the set of lanes with the same address, by ballots
+            uint32_t plo = ~0u, phi = ~0u;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                const uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+                const uint64_t bal = __ballot(m != 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
+            }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0));
+            const uint32_t got = atomicAdd(&cnt[w][d], 1u);
+            // in lane order every lane of a same-address group reads (count before the instruction)
+            // + (same-address lanes below it): got - below must equal the group leader's value
+            const uint32_t base_cnt = got - below;
+            const uint32_t leader = plo ? (uint32_t)__builtin_ctz(plo) : 32u + (uint32_t)__builtin_ctz(phi);
+            if (base_cnt != (uint32_t)__shfl((int)base_cnt, (int)leader)) ++bad;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d);
+    if (lane == 0 && bad) atomicAdd(mismatches, bad);
+}
+
+int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host) {
+    int rc = ctx_ensure_scan_ws(ctx, 256);
+    if (rc != SPLAT_OK) return rc;
+    unsigned long long *d = (unsigned long long *)ctx->scan_ws;
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_probe_lds_atomic_order, dim3(2048), dim3(256), 0, ctx->stream, 256u, 12345u, d);
+    LAUNCH_CHECK(ctx, "k_probe_lds_atomic_order");
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches_host = v;
+    return SPLAT_OK;
+}
+
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
                      uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode, const uint32_t *n_dev,
                      bool iota_payload) {
@@ -483,7 +572,7 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
     if (mode < 0) mode = g_radix_mode;
     if (n_dev || iota_payload) mode = 0; // device-side counts / implicit payloads: rowscan kernels only
     if (mode == 1) return radix_sort_onesweep(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
-    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary, iota_payload);
+    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary, iota_payload, mode == 2);
 }
 
 // the look-back's timeout word (workspace word 1028): non-zero after a sort = a chained scan gave up
@@ -586,9 +675,15 @@ void *splat_sort_sorted_payload(splat_sorter *s) {
 
 int splat_sort_set_mode(splat_sorter *s, int mode) {
     if (!s) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "sorter is NULL");
-    if (mode < -1 || mode > 1) return ctx_fail(s->ctx, SPLAT_ERR_INVALID, "sort mode must be -1 (default), 0 (rowscan) or 1 (onesweep)");
+    if (mode < -1 || mode > 2)
+        return ctx_fail(s->ctx, SPLAT_ERR_INVALID, "sort mode must be -1 (default), 0 (rowscan), 1 (onesweep) or 2 (rowscan, ballot ranking)");
     s->mode = mode;
     return SPLAT_OK;
+}
+
+int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx/mismatches is NULL");
+    return radix_probe_lds_atomic_order(ctx, mismatches);
 }
 
 int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag) {

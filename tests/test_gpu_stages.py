@@ -55,7 +55,7 @@ def test_project_and_keys_bit_exact(device, n, w, h, seed):
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 1023, 4095, 4096, 4097, 8191, 12289, 100000, 1000003])
 @pytest.mark.parametrize("kind", ["random", "few_values", "all_equal", "sorted_desc"])
-@pytest.mark.parametrize("mode", [0, 1], ids=["rowscan", "onesweep"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["rowscan", "onesweep", "rowscan-ballot"])
 def test_radix_sort_stable(device, n, kind, mode):
     rng = np.random.default_rng(n * 7 + len(kind))
     if kind == "random":
@@ -97,6 +97,15 @@ def test_radix_sort_bit_ranges(device, bits_range):
     assert np.array_equal(s.getSortedIndicesBuffer().read(np.uint32, n), payload[order])
     assert np.array_equal(s.getSortedKeysBuffer().read(np.uint32, n), keys[order])
     s.destroy()
+
+
+def test_lds_atomic_order_probe(device):
+    """The fast ranking path rests on a measured hardware property; the probe must report it."""
+    import ctypes as C
+    from splat_renderer_amd import _lib
+    bad = C.c_uint64(1)
+    _lib.check(device.lib.splat_probe_lds_atomic_order(device.ctx, C.byref(bad)), device.ctx)
+    assert bad.value == 0
 
 
 def test_sort_capacity_error(device):
