@@ -217,10 +217,8 @@ static void binner_free(splat_binner *b) {
 }
 
 static void sorter_free_members(splat_sorter *s) {
-    if (s->keys) (void)hipFree(s->keys);
+    if (s->keys) (void)hipFree(s->keys); // payload / payload_b live inside the keys / keys_b allocations
     if (s->keys_b) (void)hipFree(s->keys_b);
-    if (s->payload) (void)hipFree(s->payload);
-    if (s->payload_b) (void)hipFree(s->payload_b);
     if (s->hist) (void)hipFree(s->hist);
     if (s->d_count) (void)hipFree(s->d_count);
     s->keys = s->keys_b = s->payload = s->payload_b = s->hist = s->d_count = nullptr;
@@ -323,19 +321,10 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         const uint32_t *p_dev = async ? b->d_total : nullptr;
         // tile ids up to 16 bits: two passes with the bits split evenly (13 bits -> 6 + 7) rather than
         // 8 + 5: a pass scatters in digit runs, and 64 + 128 bins give longer runs than 256 + 32
-        if (bits <= 8) {
-            rc = radix_sort_pairs(ctx, b->pairs.keys, b->pairs.payload, b->pairs.keys_b, b->pairs.payload_b, b->pairs.hist,
-                                  total32, 0, bits, &b->pairs.result_in_primary, 0, p_dev);
-        } else {
-            const uint32_t lo_bits = bits / 2; // measured at C2 (13 bits): 5+8 0.627, 6+7 0.619, 7+6 0.629, 8+5 0.649 ms/frame
-            bool dummy;
-            rc = radix_sort_pairs(ctx, b->pairs.keys, b->pairs.payload, b->pairs.keys_b, b->pairs.payload_b, b->pairs.hist,
-                                  total32, 0, lo_bits, &dummy, 0, p_dev);
-            if (rc != SPLAT_OK) return rc;
-            rc = radix_sort_pairs(ctx, b->pairs.keys_b, b->pairs.payload_b, b->pairs.keys, b->pairs.payload, b->pairs.hist,
-                                  total32, lo_bits, bits, &dummy, 0, p_dev);
-            b->pairs.result_in_primary = true;
-        }
+        // measured at C2 (13 bits): 5+8 0.627, 6+7 0.619, 7+6 0.629, 8+5 0.649 ms/frame
+        const uint32_t lo_bits = bits <= 8 ? bits : bits / 2;
+        rc = radix_sort_pairs(ctx, b->pairs.keys, b->pairs.payload, b->pairs.keys_b, b->pairs.payload_b, b->pairs.hist, total32, 0,
+                              bits, &b->pairs.result_in_primary, 0, p_dev, false, lo_bits);
         if (rc != SPLAT_OK) return rc;
         const uint32_t *sorted_tiles = b->pairs.result_in_primary ? b->pairs.keys : b->pairs.keys_b;
         hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 256)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,

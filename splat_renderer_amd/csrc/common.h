@@ -72,7 +72,7 @@ constexpr uint32_t RADIX_PART = 4096; // keys per workgroup partition
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1,
                      uint32_t *hist, uint32_t n, uint32_t bit_begin, uint32_t bit_end,
                      bool *result_in_primary, int mode = -1, const uint32_t *n_dev = nullptr,
-                     bool iota_payload = false);
+                     bool iota_payload = false, uint32_t first_bits = 8);
 
 int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host);
 int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);

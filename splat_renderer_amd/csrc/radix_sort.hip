@@ -60,6 +60,9 @@ __device__ __forceinline__ void hist_add4(uint32_t *h, uint4 v, uint32_t shift, 
     }
 }
 
+// IN_PAIRS: the input is the interleaved (key, payload) uint2 array the previous pass wrote (see
+// radix_sort_rowscan); otherwise a plain key array.
+template <bool IN_PAIRS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__restrict__ keys, uint32_t n_host,
                                                               const uint32_t *__restrict__ n_dev, uint32_t shift,
                                                               uint32_t mask, uint32_t num_parts, uint32_t part_keys,
@@ -73,23 +76,37 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__
         return;
     }
     for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
-    if (base + part_keys <= n) {
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
-        const uint32_t vecs = part_keys / 4; // multiple of 64
-        if (vecs == 4 * RS_THREADS) {        // the default 4096-key partition: all four loads in flight at once
+    if (base + part_keys <= n && part_keys == RS_ITEMS * RS_THREADS) { // full default partition: all loads in flight at once
+        if (IN_PAIRS) {
+            const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + (size_t)base * 2); // two (key, payload) pairs per uint4
+            uint4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = k4[tid + j * RS_THREADS];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t a = (v[j].x >> shift) & mask, c = (v[j].z >> shift) & mask;
+                if (a == c) {
+                    atomicAdd(&lh[w][a], 2u);
+                } else {
+                    atomicAdd(&lh[w][a], 1u);
+                    atomicAdd(&lh[w][c], 1u);
+                }
+            }
+        } else {
+            const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + base);
             const uint4 v0 = k4[tid], v1 = k4[tid + RS_THREADS], v2 = k4[tid + 2 * RS_THREADS], v3 = k4[tid + 3 * RS_THREADS];
             __syncthreads();
             hist_add4(lh[w], v0, shift, mask);
             hist_add4(lh[w], v1, shift, mask);
             hist_add4(lh[w], v2, shift, mask);
             hist_add4(lh[w], v3, shift, mask);
-        } else {
-            __syncthreads();
-            for (uint32_t j = tid; j < vecs; j += RS_THREADS) hist_add4(lh[w], k4[j], shift, mask);
         }
     } else {
         __syncthreads();
-        for (uint32_t i = base + tid; i < n; i += RS_THREADS) atomicAdd(&lh[w][(keys[i] >> shift) & mask], 1u);
+        const uint32_t end = (base + part_keys < n) ? base + part_keys : n;
+        for (uint32_t i = base + tid; i < end; i += RS_THREADS)
+            atomicAdd(&lh[w][(keys[IN_PAIRS ? (size_t)i * 2 : (size_t)i] >> shift) & mask], 1u);
     }
     __syncthreads();
     uint32_t c = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
@@ -193,7 +210,7 @@ __device__ __forceinline__ uint32_t lookback(uint32_t *status, uint32_t part, ui
     return excl;
 }
 
-template <uint32_t ITEMS, bool FULL, bool ONESWEEP, bool RANK_ATOMIC>
+template <uint32_t ITEMS, bool FULL, bool ONESWEEP, bool RANK_ATOMIC, bool IN_PAIRS = false, bool OUT_PAIRS = false>
 __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__restrict__ s_kp, uint32_t part,
                                                const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ pay_out, uint32_t n,
@@ -221,8 +238,14 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     for (uint32_t i = 0; i < ITEMS; ++i) {
         const uint32_t p = wbase + i * 64;
         const uint32_t q = FULL ? p : ((p < valid) ? p : (valid - 1));
-        key[i] = keys_in[base + q];
-        pay[i] = pay_in ? pay_in[base + q] : (base + q); // no payload array: the payload is the element's index
+        if (IN_PAIRS) { // one 8-byte load per element instead of two 4-byte ones
+            const uint2 kp = reinterpret_cast<const uint2 *>(keys_in)[base + q];
+            key[i] = kp.x;
+            pay[i] = kp.y;
+        } else {
+            key[i] = keys_in[base + q];
+            pay[i] = pay_in ? pay_in[base + q] : (base + q); // no payload array: the payload is the element's index
+        }
     }
     if (!ONESWEEP) __syncthreads(); // wave_hist zeroed
 
@@ -320,8 +343,12 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
             const uint2 kp = s_kp[pos];
             const uint32_t d = (kp.x >> shift) & mask;
             const uint32_t g = sh.global_base[d] + (pos - sh.digit_base[d]);
-            keys_out[g] = kp.x;
-            pay_out[g] = kp.y;
+            if (OUT_PAIRS) {
+                reinterpret_cast<uint2 *>(keys_out)[g] = kp; // one 8-byte store, 128-byte digit runs
+            } else {
+                keys_out[g] = kp.x;
+                pay_out[g] = kp.y;
+            }
         }
     }
 }
@@ -332,7 +359,7 @@ constexpr uint32_t downsweep_lds_bytes(uint32_t items) { return items * RS_THREA
 constexpr uint32_t downsweep_wg_per_cu(uint32_t items) { return items <= 6 ? 8 : items <= 12 ? 5 : items <= 16 ? 4 : 2; }
 static_assert(downsweep_wg_per_cu(RS_ITEMS) * downsweep_lds_bytes(RS_ITEMS) <= 160u * 1024u, "LDS budget");
 
-template <uint32_t ITEMS, bool RANK_ATOMIC>
+template <uint32_t ITEMS, bool RANK_ATOMIC, bool IN_PAIRS, bool OUT_PAIRS>
 __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ pay_out, uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t shift, uint32_t mask,
@@ -343,10 +370,10 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radi
     if (blockIdx.x * ITEMS * RS_THREADS >= n) return; // partition past the end (device-side n)
     // every partition but (possibly) the last is full: it takes the path with no per-key bounds checks
     if ((blockIdx.x + 1) * ITEMS * RS_THREADS <= n)
-        downsweep_body<ITEMS, true, false, RANK_ATOMIC>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+        downsweep_body<ITEMS, true, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                            scanned_hist, totals, nullptr, nullptr);
     else
-        downsweep_body<ITEMS, false, false, RANK_ATOMIC>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+        downsweep_body<ITEMS, false, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                             scanned_hist, totals, nullptr, nullptr);
 }
 
@@ -430,7 +457,7 @@ static int g_radix_mode = -1;
 
 static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
                               const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary,
-                              bool iota_payload, bool force_ballot_rank) {
+                              bool iota_payload, bool force_ballot_rank, uint32_t cap_stride, uint32_t first_bits) {
     // ranking by returning LDS atomics needs the lane-order property: probed once per context
     if (ctx->lds_atomic_ordered < 0) {
         uint64_t bad = 1;
@@ -440,30 +467,56 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
     }
     const bool rank_atomic = ctx->lds_atomic_ordered == 1 && !force_ballot_rank;
     const uint32_t parts = div_up(n, RS_PART_KEYS);
+    // Between passes the pairs travel INTERLEAVED: (key, payload) as one uint2 per element, laid over
+    // the destination's key+payload storage (the two arrays of a ping-pong side are one allocation:
+    // sorter_reserve / the binner's pair buffers).  The scatter is bound by the number of memory
+    // instructions and segments, not bytes: an 8-byte access per element halves both.  The first pass
+    // reads the caller's separate arrays, the last pass writes separate arrays again.
+    const bool can_pair = (p0 == k0 + cap_stride) && (p1 == k1 + cap_stride);
     uint32_t *ki = k0, *pi = p0, *ko = k1, *po = p1;
     bool primary = true;
-    for (uint32_t shift = bit_begin; shift < bit_end; shift += 8) {
-        uint32_t bits = bit_end - shift < 8 ? bit_end - shift : 8;
-        uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_radix_upsweep, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
-                           RS_PART_KEYS, hist);
+    // digit widths: first_bits for the first pass (the binner splits its tile-id bits evenly), then 8
+    uint32_t npasses = 0;
+    for (uint32_t sh = bit_begin, w = first_bits; sh < bit_end; sh += w, w = 8) ++npasses;
+    uint32_t shift = bit_begin;
+    for (uint32_t pass = 0; pass < npasses; ++pass) {
+        const uint32_t want = pass == 0 ? first_bits : 8u;
+        const uint32_t bits = bit_end - shift < want ? bit_end - shift : want;
+        const uint32_t mask = (1u << bits) - 1u;
+        const bool in_pairs = can_pair && pass > 0, out_pairs = can_pair && pass + 1 < npasses;
+        if (in_pairs)
+            hipLaunchKernelGGL(k_radix_upsweep<true>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
+                               RS_PART_KEYS, hist);
+        else
+            hipLaunchKernelGGL(k_radix_upsweep<false>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
+                               RS_PART_KEYS, hist);
         LAUNCH_CHECK(ctx, "k_radix_upsweep");
         uint32_t *totals = hist + (size_t)256 * parts;
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals);
         LAUNCH_CHECK(ctx, "k_radix_rowscan");
         // iota_payload: the input payload is 0,1,2,... (fresh from the projector): the first pass
         // synthesises it instead of reading 4 B per key that the projector would have had to write
-        const uint32_t *pin = (iota_payload && shift == bit_begin) ? nullptr : pi;
-        if (rank_atomic)
-            hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, true>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n,
-                               n_dev, shift, mask, parts, hist, totals);
-        else
-            hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, false>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n,
-                               n_dev, shift, mask, parts, hist, totals);
+        const uint32_t *pin = (iota_payload && pass == 0) ? nullptr : pi;
+#define SPLAT_DS(RA, IP, OP)                                                                                                   \
+    hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, RA, IP, OP>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n, \
+                       n_dev, shift, mask, parts, hist, totals)
+        if (rank_atomic) {
+            if (in_pairs && out_pairs) SPLAT_DS(true, true, true);
+            else if (in_pairs) SPLAT_DS(true, true, false);
+            else if (out_pairs) SPLAT_DS(true, false, true);
+            else SPLAT_DS(true, false, false);
+        } else {
+            if (in_pairs && out_pairs) SPLAT_DS(false, true, true);
+            else if (in_pairs) SPLAT_DS(false, true, false);
+            else if (out_pairs) SPLAT_DS(false, false, true);
+            else SPLAT_DS(false, false, false);
+        }
+#undef SPLAT_DS
         LAUNCH_CHECK(ctx, "k_radix_downsweep");
         uint32_t *t = ki; ki = ko; ko = t;
         t = pi; pi = po; po = t;
         primary = !primary;
+        shift += bits;
     }
     *result_in_primary = primary;
     return SPLAT_OK;
@@ -561,7 +614,7 @@ int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host) {
 
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
                      uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode, const uint32_t *n_dev,
-                     bool iota_payload) {
+                     bool iota_payload, uint32_t first_bits) {
     if (g_radix_mode < 0) {
         g_radix_mode = 0;
         if (const char *e = getenv("SPLAT_RADIX_MODE")) g_radix_mode = (e[0] == 'o' || e[0] == '1') ? 1 : 0;
@@ -570,9 +623,11 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
     if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
     if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
     if (mode < 0) mode = g_radix_mode;
-    if (n_dev || iota_payload) mode = 0; // device-side counts / implicit payloads: rowscan kernels only
+    if (first_bits < 1 || first_bits > 8) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: first_bits must be 1..8");
+    if ((n_dev || iota_payload || first_bits != 8) && mode == 1) mode = 0; // these need the rowscan kernels
     if (mode == 1) return radix_sort_onesweep(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
-    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary, iota_payload, mode == 2);
+    return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary, iota_payload, mode == 2,
+                              (uint32_t)(p0 - k0), first_bits);
 }
 
 // the look-back's timeout word (workspace word 1028): non-zero after a sort = a chained scan gave up
@@ -588,8 +643,6 @@ int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value)
 static void sorter_free(splat_sorter *s) {
     if (s->keys) (void)hipFree(s->keys);
     if (s->keys_b) (void)hipFree(s->keys_b);
-    if (s->payload) (void)hipFree(s->payload);
-    if (s->payload_b) (void)hipFree(s->payload_b);
     if (s->hist) (void)hipFree(s->hist);
     if (s->d_count) (void)hipFree(s->d_count);
     s->keys = s->keys_b = s->payload = s->payload_b = s->hist = s->d_count = nullptr;
@@ -609,12 +662,15 @@ int sorter_reserve(splat_sorter *s, uint32_t capacity) {
     size_t hist_a = ((size_t)256 * div_up((uint32_t)padded, RS_PART_KEYS) + 256) * 4;
     size_t hist_b = ((size_t)1280 + (size_t)4 * div_up((uint32_t)padded, OS_ITEMS * RS_THREADS) * 256) * 4;
     size_t hist_bytes = hist_a > hist_b ? hist_a : hist_b;
-    if (hipMalloc((void **)&s->keys, bytes) != hipSuccess || hipMalloc((void **)&s->keys_b, bytes) != hipSuccess ||
-        hipMalloc((void **)&s->payload, bytes) != hipSuccess || hipMalloc((void **)&s->payload_b, bytes) != hipSuccess ||
+    // keys|payload of each ping-pong side are ONE allocation (payload = keys + padded): between passes
+    // the sort stores interleaved (key, payload) pairs over the whole of it
+    if (hipMalloc((void **)&s->keys, 2 * bytes) != hipSuccess || hipMalloc((void **)&s->keys_b, 2 * bytes) != hipSuccess ||
         hipMalloc((void **)&s->hist, hist_bytes) != hipSuccess || hipMalloc((void **)&s->d_count, 16) != hipSuccess) {
         sorter_free(s);
         return ctx_fail(ctx, SPLAT_ERR_OOM, "sorter hipMalloc");
     }
+    s->payload = s->keys + padded;
+    s->payload_b = s->keys_b + padded;
     if (hipMemset(s->hist, 0, hist_bytes) != hipSuccess) {
         sorter_free(s);
         return ctx_fail(ctx, SPLAT_ERR_HIP, "sorter workspace hipMemset");
