@@ -257,7 +257,16 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     // the number of keys of that digit in items < i: a stable rank, with the LDS round trips
     // pipelined (nothing waits on them until phase B) instead of chained.
     uint32_t rank[ITEMS];
-    if (RANK_ATOMIC) {
+    // Returning LDS atomics that collide on one address serialise (64 lanes on one counter = 64 LDS
+    // cycles), so a partition dominated by one digit — the top byte of depth keys — ranks faster
+    // with ballots, whose cost does not depend on the digit distribution.  Rowscan mode knows the
+    // partition's digit counts before it starts (upsweep): pick per workgroup.
+    bool use_atomic = RANK_ATOMIC;
+    if (RANK_ATOMIC && !ONESWEEP) {
+        const uint32_t next = (part + 1 < num_parts) ? scanned_hist[(size_t)tid * num_parts + part + 1] : digit_total;
+        use_atomic = !__syncthreads_or((next - row_prefix) > PART_KEYS / 4); // some digit holds > 25 % of the partition
+    }
+    if (use_atomic) {
         // Measured property of gfx950 (splat_probe_lds_atomic_order, run once per context; the ballot
         // path below is used if it ever fails): the lanes of one returning LDS atomic that hit the same
         // address complete in ascending lane order.  Then old = atomicAdd(&counter[digit], 1) IS the
