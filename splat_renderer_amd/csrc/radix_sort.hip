@@ -3,19 +3,23 @@
 // Reference contract: /root/reference/src/RadixSorter.ts:39-100,197-271 (8 bits x 4 passes, result
 // back in payload_a, stable).  The reference's WGSL (src/shaders/radix-sort.wgsl) emulates 32-wide
 // subgroup match/rank through LDS and chains workgroups with a spinning decoupled look-back; this
-// file is a wave64 design instead:
+// file is a wave64 design instead.  Default ("rowscan") mode, per pass:
 //
-//   per pass:  k_radix_upsweep   per-partition 256-bin digit histogram (LDS atomics), written
-//                                digit-major: row d = counts of digit d over the partitions
-//              k_radix_rowscan   256 workgroups, one per digit row: exclusive scan along the
-//                                partitions in place + the row total
-//              k_radix_downsweep scans the 256 row totals itself (digit bases), then each wave ranks its 16x64 keys with __ballot match masks
-//                                (rank = popcount of same-digit lanes below me + running per-wave
-//                                digit counter in LDS), the workgroup reorders keys by digit in
-//                                LDS so global stores go out in digit runs, then scatters.
+//   k_radix_upsweep    per 4096-key partition a 256-bin digit histogram (per-wave LDS histograms),
+//                      written digit-major: row d = counts of digit d over the partitions
+//   k_radix_rowscan    256 workgroups, one per digit row: exclusive scan along the partitions in
+//                      place + the row total
+//   k_radix_downsweep  scans the 256 row totals itself (digit bases); each wave ranks its 16x64 keys
+//                      (returning LDS atomics where the lane-order probe allows and the partition is
+//                      not dominated by one digit, ballot match masks otherwise); the workgroup
+//                      reorders (key, payload) by digit in LDS so that global stores go out in digit
+//                      runs, then scatters.
 //
-// No inter-workgroup spinning: forward progress never depends on dispatch order (the guide's
-// "give every wave an exit condition" rule), at the price of reading the keys twice per pass.
+// No inter-workgroup waiting: forward progress never depends on dispatch order (the guide's "give
+// every wave an exit condition" rule), at the price of reading the keys twice per pass.  Between
+// passes the pairs are stored interleaved (uint2) so the scatter is one 8-byte access per element.
+// A selectable onesweep mode (one chained-scan kernel per pass, the reference's structure) is kept
+// for comparison; it measures slower on MI355X (see radix_sort_pairs).
 //
 // Roofline: HBM.  Algorithmic bytes per key per pass: 4 (upsweep read) + 8 (read key+payload)
 // + 8 (write) = 20; 80 B/key for the 4-pass depth sort.
