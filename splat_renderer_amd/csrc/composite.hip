@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             float2 col = make_float2(0.0f, 0.0f);
             uint32_t xm = 0, ym = 0;
             if (!f_ready) { // the first three batches of a tile: fetch now
-                f_idx = (e < count) ? p.indices[off + e] : 0xffffffffu;
+                f_idx = (tid < CBATCH && e < count) ? p.indices[off + e] : 0xffffffffu;
                 if (f_idx != 0xffffffffu) {
                     f_b = p.projected[(size_t)f_idx * 2];
                     f_r = reinterpret_cast<const float *>(p.projected)[(size_t)f_idx * 8 + 5];
@@ -149,12 +149,14 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     ym = span_mask16(b.y, b.w, tile_cy);
                 }
             }
-            s_geo[tid] = geo;
-            s_col[tid] = col;
-            s_mask[0][tid] = quadrant_mask(xm & 0xffu, ym & 0xffu);
-            s_mask[1][tid] = quadrant_mask(xm >> 8, ym & 0xffu);
-            s_mask[2][tid] = quadrant_mask(xm & 0xffu, ym >> 8);
-            s_mask[3][tid] = quadrant_mask(xm >> 8, ym >> 8);
+            if (tid < CBATCH) {
+                s_geo[tid] = geo;
+                s_col[tid] = col;
+                s_mask[0][tid] = quadrant_mask(xm & 0xffu, ym & 0xffu);
+                s_mask[1][tid] = quadrant_mask(xm >> 8, ym & 0xffu);
+                s_mask[2][tid] = quadrant_mask(xm & 0xffu, ym >> 8);
+                s_mask[3][tid] = quadrant_mask(xm >> 8, ym >> 8);
+            }
             // issue the fetches for later batches; nothing below waits for them until the next stage
             f_ready = false;
             if (base >= CBATCH) { // a tile that needed a second batch usually needs more
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     f_ready = true;
                 }
                 const uint32_t e2 = e + 2 * CBATCH; // batch k+2
-                n_idx = (e2 < count) ? p.indices[off + e2] : 0xffffffffu;
+                n_idx = (tid < CBATCH && e2 < count) ? p.indices[off + e2] : 0xffffffffu;
                 n_idx_valid = true;
             }
         }
