@@ -168,6 +168,15 @@ int splat_bin_counts(splat_binner *b, void **dptr);          /* getTileCountsBuf
 int splat_bin_offsets(splat_binner *b, void **dptr);         /* getTileOffsetsBuffer() u32[numTiles] (+1: [numTiles] = total) */
 int splat_bin_indices(splat_binner *b, void **dptr);         /* getTileIndicesBuffer() u32[total]    */
 int splat_bin_total(splat_binner *b, uint64_t *total_pairs); /* sum of counts of the last run */
+/* Order of work inside splat_render_frame (results are identical, tests hold both to the same lists):
+ *   SPLAT_FRAME_SORT_FIRST  global depth sort of the splats, then bin in sorted order (the staged API's order);
+ *   SPLAT_FRAME_TILE_FIRST  bin in index order, then depth-sort every tile's list (PerTileSorter,
+ *                           src/PerTileSorter.ts:66-122) — needs tile coordinates that fit 8 bits;
+ *   SPLAT_FRAME_ORDER_DEFAULT  the library's choice (environment SPLAT_FRAME_ORDER=sortfirst|tilefirst overrides). */
+#define SPLAT_FRAME_ORDER_DEFAULT (-1)
+#define SPLAT_FRAME_SORT_FIRST 0
+#define SPLAT_FRAME_TILE_FIRST 1
+int splat_bin_set_frame_order(splat_binner *b, int order);
 int splat_bin_dims(splat_binner *b, uint32_t *ntx, uint32_t *nty);
 
 /* ---- PerTileSorter.sort  (src/PerTileSorter.ts:66-122,174-213) --------------------------------- */

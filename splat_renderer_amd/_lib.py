@@ -73,6 +73,7 @@ SIGNATURES = {
     "splat_bin_offsets": (_i, [_vp, _pvp]),
     "splat_bin_indices": (_i, [_vp, _pvp]),
     "splat_bin_total": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "splat_bin_set_frame_order": (_i, [_vp, _i]),
     "splat_bin_dims": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "splat_validate_tile_order": (_i, [_vp, _vp, _vp, _u32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "splat_composite": (_i, [_vp, C.POINTER(CompositeCfg), _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _u32,

@@ -19,6 +19,7 @@
 #include "tile_range.h"
 
 #include <cstdlib>
+#include <sched.h>
 
 constexpr uint32_t BIN_THREADS = 256;
 constexpr uint32_t BIN_PER_THREAD = 4;
@@ -191,10 +192,20 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict
     if (lane == 0) offsets[t] = first; // offsets[tiles] = pairs
 }
 
+// report (optional): host-mapped pinned words that receive {pair total, overflow flag, frame sequence
+// number} — a sync-free frame's readback with no copy and no event in the stream (hipMemcpyAsync +
+// hipEventRecord left the GPU idle for ~14 us per frame between the binner and the composite).
 __global__ __launch_bounds__(256) void k_tile_counts(const uint32_t *__restrict__ offsets, uint32_t tiles,
-                                                     uint32_t *__restrict__ counts) {
+                                                     uint32_t *__restrict__ counts, const uint32_t *__restrict__ d_total,
+                                                     uint32_t *report, uint32_t seq) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t < tiles) counts[t] = offsets[t + 1] - offsets[t];
+    if (report && t == 0) {
+        report[0] = d_total[0];
+        report[1] = d_total[1];
+        __threadfence_system();
+        __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls this word
+    }
 }
 
 // PerTileSorter's job, as a check instead of a sort (src/PerTileSorter.ts:66-122 re-sorts every tile's
@@ -251,13 +262,33 @@ int binner_reserve_range32(splat_binner *b, uint32_t n_splats) {
     return SPLAT_OK;
 }
 
+static int binner_reserve_wide(splat_binner *b) {
+    splat_ctx *ctx = b->ctx;
+    if (b->pairs.capacity <= b->wide_cap) return SPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->wide_a) (void)hipFree(b->wide_a);
+    if (b->wide_b) (void)hipFree(b->wide_b);
+    b->wide_a = b->wide_b = nullptr;
+    b->wide_cap = 0;
+    const size_t bytes = (size_t)b->pairs.capacity * 8 + 256;
+    if (hipMalloc((void **)&b->wide_a, bytes) != hipSuccess || hipMalloc((void **)&b->wide_b, bytes) != hipSuccess)
+        return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc (pair values)");
+    b->wide_cap = b->pairs.capacity;
+    return SPLAT_OK;
+}
+
 // binSplats.  range32 (optional): per splat index, the packed range the projector computed with the
 // same BinParams (frame path); otherwise ranges are derived from the projected bounds here.
+// depth_keys (frame path, with range32): per splat index, its depth key — selects the tile-first
+// order of work (tile_first.hip): `sorted` is then unused, the lists are depth-sorted per tile.
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
-               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32, const uint32_t *n_sorted_dev) {
+               uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32, const uint32_t *n_sorted_dev,
+               const uint32_t *depth_keys) {
     splat_ctx *ctx = b->ctx;
+    const bool tile_first = depth_keys != nullptr;
     ARG_CHECK(ctx, width >= 1 && height >= 1);
-    ARG_CHECK(ctx, n_sorted == 0 || (projected && sorted));
+    ARG_CHECK(ctx, n_sorted == 0 || (projected && (sorted || tile_first)));
+    ARG_CHECK(ctx, !tile_first || (range32 && n_sorted == n_splats && !n_sorted_dev));
     const uint32_t ntx = div_up(width, b->tile), nty = div_up(height, b->tile); // GPUTileBinner.ts:198-200
     ARG_CHECK(ctx, ntx <= 65535 && nty <= 65535 && (uint64_t)ntx * nty <= (1u << 24));
     const uint32_t tiles = ntx * nty;
@@ -293,7 +324,10 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     uint32_t total32 = 0;
     bool async = false;
     if (n_sorted > 0) {
-        if (range32)
+        if (tile_first) {
+            rc = tf_count_launch(ctx, range32, n_splats, b->blocksums, b->d_total + 1);
+            if (rc != SPLAT_OK) return rc;
+        } else if (range32)
             hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
                                n_splats, (const uint32_t *)sorted, n_sorted, n_sorted_dev, bp, b->ranges, b->blocksums, b->d_total + 1);
         else
@@ -326,7 +360,33 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         }
     }
     b->total = async ? b->last_total : total32;
-    if (total32 > 0) {
+    if (total32 > 0 && tile_first) {
+        rc = binner_reserve_wide(b);
+        if (rc != SPLAT_OK) return rc;
+        rc = tf_expand_launch(ctx, range32, depth_keys, n_splats, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys,
+                              b->wide_a);
+        if (rc != SPLAT_OK) return rc;
+        uint32_t bits = 1;
+        while ((1u << bits) < tiles) ++bits;
+        const uint32_t *p_dev = async ? b->d_total : nullptr;
+        const uint32_t lo_bits = bits <= 8 ? bits : bits / 2;
+        bool primary = true;
+        rc = radix_sort_wide(ctx, b->pairs.keys, b->wide_a, b->pairs.keys_b, b->wide_b, b->pairs.hist, total32, p_dev, 0, bits, lo_bits,
+                             &primary);
+        if (rc != SPLAT_OK) return rc;
+        const uint32_t *sorted_tiles = primary ? b->pairs.keys : b->pairs.keys_b;
+        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 4)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
+                           tiles, b->offsets);
+        LAUNCH_CHECK(ctx, "k_tile_offsets");
+        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts, b->d_total,
+                           async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
+        LAUNCH_CHECK(ctx, "k_tile_counts");
+        // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
+        rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload);
+        if (rc != SPLAT_OK) return rc;
+        b->pairs.result_in_primary = true;
+        if (async) b->pending = true; // k_tile_counts reports {total, overflow, seq} into b->pinned
+    } else if (total32 > 0) {
         hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
                            b->ranges, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys, b->pairs.payload);
         LAUNCH_CHECK(ctx, "k_bin_expand");
@@ -344,13 +404,10 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 4)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
                            tiles, b->offsets);
         LAUNCH_CHECK(ctx, "k_tile_offsets");
-        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts);
+        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts, b->d_total,
+                           async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
         LAUNCH_CHECK(ctx, "k_tile_counts");
-        if (async) { // {total, overflow} come back without stalling the stream; examined at the next call
-            HIP_TRY(ctx, hipMemcpyAsync(b->pinned, b->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(b->readback_done, ctx->stream));
-            b->pending = true;
-        }
+        if (async) b->pending = true; // k_tile_counts reports {total, overflow, seq} into b->pinned; examined at the next call
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->counts, 0, (size_t)tiles * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(b->offsets, 0, (size_t)(tiles + 1) * 4, ctx->stream));
@@ -368,7 +425,17 @@ int binner_settle(splat_binner *b) {
     if (!b->pending) return SPLAT_OK;
     splat_ctx *ctx = b->ctx;
     b->pending = false;
-    HIP_TRY(ctx, hipEventSynchronize(b->readback_done));
+    // wait for that frame's report word (normally long there: it was launched a frame ago)
+    volatile uint32_t *rep = (volatile uint32_t *)b->pinned;
+    for (uint32_t spins = 0; rep[2] != b->seq; ++spins) {
+        if (spins < 64) continue;
+        if (hipStreamQuery(ctx->stream) == hipSuccess) { // everything launched has finished
+            if (rep[2] != b->seq) return ctx_fail(ctx, SPLAT_ERR_STATE, "binner: the pair-total report of the previous frame never arrived");
+            break;
+        }
+        sched_yield();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint32_t total = ((volatile uint32_t *)b->pinned)[0], overflow = ((volatile uint32_t *)b->pinned)[1];
     b->last_total = total;
     b->have_last = true;
@@ -398,7 +465,8 @@ int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out) {
     b->ctx = ctx;
     b->tile = tile_size;
     b->pairs.ctx = ctx;
-    if (hipMalloc((void **)&b->d_total, 16) != hipSuccess || hipHostMalloc((void **)&b->pinned, 16, hipHostMallocDefault) != hipSuccess ||
+    if (hipMalloc((void **)&b->d_total, 16) != hipSuccess || hipHostMalloc((void **)&b->pinned, 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&b->pinned_dev, b->pinned, 0) != hipSuccess ||
         hipEventCreateWithFlags(&b->readback_done, hipEventDisableTiming) != hipSuccess) {
         if (b->d_total) (void)hipFree(b->d_total);
         if (b->pinned) (void)hipHostFree(b->pinned);
@@ -417,6 +485,8 @@ void splat_bin_destroy(splat_binner *b) {
     sorter_free_members(&b->pairs);
     if (b->d_total) (void)hipFree(b->d_total);
     if (b->range32) (void)hipFree(b->range32);
+    if (b->wide_a) (void)hipFree(b->wide_a);
+    if (b->wide_b) (void)hipFree(b->wide_b);
     if (b->pinned) (void)hipHostFree(b->pinned);
     if (b->readback_done) (void)hipEventDestroy(b->readback_done);
     delete b;
@@ -429,6 +499,13 @@ int splat_bin_run(splat_binner *b, const void *projected, uint32_t n_splats, con
 }
 
 uint32_t splat_bin_tile_size(const splat_binner *b) { return b ? b->tile : 0; }
+
+int splat_bin_set_frame_order(splat_binner *b, int order) {
+    if (!b) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner is NULL");
+    ARG_CHECK(b->ctx, order >= SPLAT_FRAME_ORDER_DEFAULT && order <= SPLAT_FRAME_TILE_FIRST);
+    b->frame_order = order;
+    return SPLAT_OK;
+}
 
 int splat_bin_counts(splat_binner *b, void **dptr) {
     if (!b || !dptr) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "binner/dptr is NULL");

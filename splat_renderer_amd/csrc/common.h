@@ -108,6 +108,9 @@ struct splat_binner {
     uint32_t *range32 = nullptr;                    // per splat INDEX: 8-bit packed range written by the projector (frame path)
     uint32_t *d_total = nullptr;                    // [0] pair total of the last run, [1] overflow flag
     splat_sorter pairs;                             // (tileId, splatIdx) ping-pong buffers
+    uint2 *wide_a = nullptr, *wide_b = nullptr;     // tile-first path: (depth key, splat idx) per pair, ping-pong
+    uint32_t wide_cap = 0;
+    int frame_order = -1;                           // splat_bin_set_frame_order
     uint64_t total = 0;
     bool ran = false;
     // sync-free operation: when the previous frame's pair total is known and 1.125x of it fits the
@@ -120,7 +123,9 @@ struct splat_binner {
     bool have_last = false;
     uint32_t last_total = 0;
     uint32_t pair_limit = 0;   // pairs this frame's grids / stores are bounded by
-    uint32_t *pinned = nullptr; // 4 u32, host-pinned
+    uint32_t *pinned = nullptr; // 4 u32, host-pinned, mapped into the device's address space as pinned_dev
+    uint32_t *pinned_dev = nullptr;
+    uint32_t seq = 0;          // sequence number of the last sync-free frame; its report carries it
     hipEvent_t readback_done = nullptr;
 };
 
@@ -133,7 +138,14 @@ struct BinParams {
 int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
                uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32,
-               const uint32_t *n_sorted_dev = nullptr);
+               const uint32_t *n_sorted_dev = nullptr, const uint32_t *depth_keys = nullptr);
+// tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
+int tf_count_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t *blocksums, uint32_t *overflow_flag);
+int tf_expand_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, const uint32_t *block_base,
+                     uint32_t ntx, uint32_t pair_limit, uint32_t *overflow, uint32_t *pair_tile, uint2 *pair_val);
+int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx);
+int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2 *v1, uint32_t *hist, uint32_t n,
+                    const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, uint32_t first_bits, bool *result_in_primary);
 int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_ERR_CAPACITY if that frame overflowed
 // project.hip internal: the projector with the optional per-index tile range output
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,

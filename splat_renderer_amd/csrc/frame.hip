@@ -8,6 +8,8 @@
 #include "common.h"
 #include "tile_range.h"
 
+#include <cstdlib>
+
 __device__ __forceinline__ uint32_t depth_key_of(float depth) {
     uint32_t bits = __float_as_uint(depth);
     uint32_t mask = ((bits >> 31) == 1u) ? 0xffffffffu : 0x80000000u; // extract-depth-keys.wgsl:57-58
@@ -131,6 +133,17 @@ static int band_keys_device(splat_ctx *ctx, splat_sorter *sorter, const void *pr
     LAUNCH_CHECK(ctx, "k_band_scatter");
     stage_end(ctx, SPLAT_STAGE_PROJECT);
     return SPLAT_OK;
+}
+
+// which order of work splat_render_frame uses for this binner (see splat_bin_set_frame_order)
+static int g_frame_order = -2;
+static int frame_order(const splat_binner *b) {
+    if (b->frame_order >= 0) return b->frame_order;
+    if (g_frame_order == -2) {
+        g_frame_order = SPLAT_FRAME_SORT_FIRST;
+        if (const char *e = getenv("SPLAT_FRAME_ORDER")) g_frame_order = (e[0] == 't' || e[0] == '1') ? SPLAT_FRAME_TILE_FIRST : SPLAT_FRAME_SORT_FIRST;
+    }
+    return g_frame_order;
 }
 
 extern "C" {
@@ -283,14 +296,21 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
     // (the payload array is not written: payload = splat index, synthesised by the sort's first pass)
     rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp);
     if (rc != SPLAT_OK) return rc;
-    stage_begin(ctx, SPLAT_STAGE_SORT);
-    rc = radix_sort_pairs(ctx, sorter->keys, sorter->payload, sorter->keys_b, sorter->payload_b, sorter->hist, n, 0, 32,
-                          &sorter->result_in_primary, 0, nullptr, true); // RadixSorter.sort()
-    stage_end(ctx, SPLAT_STAGE_SORT);
-    if (rc != SPLAT_OK) return rc;
-    sorter->ran = true;
-    rc = binner_run(binner, projected, n, splat_sort_sorted_payload(sorter), n, width, height, row0, row1, range32);
-    if (rc != SPLAT_OK) return rc;
+    if (fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST) {
+        // bin in index order, depth-sort per tile: no global sort, no gather (tile_first.hip)
+        sorter->ran = false; // the sorter holds this frame's unsorted depth keys
+        rc = binner_run(binner, projected, n, nullptr, n, width, height, row0, row1, range32, nullptr, sorter->keys);
+        if (rc != SPLAT_OK) return rc;
+    } else {
+        stage_begin(ctx, SPLAT_STAGE_SORT);
+        rc = radix_sort_pairs(ctx, sorter->keys, sorter->payload, sorter->keys_b, sorter->payload_b, sorter->hist, n, 0, 32,
+                              &sorter->result_in_primary, 0, nullptr, true); // RadixSorter.sort()
+        stage_end(ctx, SPLAT_STAGE_SORT);
+        if (rc != SPLAT_OK) return rc;
+        sorter->ran = true;
+        rc = binner_run(binner, projected, n, splat_sort_sorted_payload(sorter), n, width, height, row0, row1, range32);
+        if (rc != SPLAT_OK) return rc;
+    }
     // (fields, not the public getters: those wait for a sync-free frame's pair total to come back)
     void *counts = binner->counts, *offsets = binner->offsets;
     void *indices = binner->pairs.result_in_primary ? binner->pairs.payload : binner->pairs.payload_b;

@@ -1,0 +1,384 @@
+// tile_first.hip — the frame path's binner: bin FIRST (in index order), depth-sort each tile's list after.
+//
+// Reference stages: GPUTileBinner.binSplats (/root/reference/src/GPUTileBinner.ts:190-338) followed by
+// PerTileSorter.sort (/root/reference/src/PerTileSorter.ts:66-122, src/shaders/sort-tile-splats.wgsl) — the
+// reference's own plan bins and then re-sorts every tile's list by depth.  The result contract is
+// unchanged: tile t's list is the stable depth order (key, then splat index) restricted to t, i.e.
+// TileBinner.binSorted (src/TileBinner.ts:426-495) applied to the stably sorted order.
+//
+// Why this order on MI355X: the sort-first path pays a 4-pass global sort of N keys and then gathers
+// each splat's tile range in sorted (= random) order, which is bound by every CU's L1 fill rate
+// (80 us for 5M splats).  Here nothing is gathered: pairs are expanded from the projector's per-index
+// arrays with coalesced reads, each pair carrying its own (depth key, index) as an 8-byte payload
+// through the 2-pass tile-id sort, and the depth order is established inside each tile by one
+// workgroup sorting a few thousand elements in LDS.
+//
+//   k_tf_count      pairs per 1024-index block                     N*4 B read
+//   (scan)          block bases + pair total (device side)
+//   k_tf_expand     (tile id) + (key, index) per pair              N*8 B read, P*12 B written
+//   radix_sort_wide stable by tile id, 2 passes                    P*(4 + 12 + 12) B per pass
+//   k_tile_offsets / k_tile_counts
+//   k_tile_sort     per tile: LSD radix on (key - tile min key)    P*8 B read, P*4 B written
+#include "common.h"
+#include "tile_range.h"
+
+constexpr uint32_t TF_THREADS = 256, TF_PER_THREAD = 4, TF_BLOCK = TF_THREADS * TF_PER_THREAD;
+constexpr uint32_t TF_STAGE = 4096; // pairs staged per block for contiguous stores
+static_assert(TF_BLOCK == 1024, "the stage word packs the block-local slot in 10 bits");
+
+__device__ __forceinline__ uint32_t range32_hits(uint32_t r) {
+    const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
+    return (tx0 > tx1 || ty0 > ty1) ? 0u : (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_count(const uint32_t *__restrict__ range32, uint32_t n,
+                                                         uint32_t *__restrict__ blocksums, uint32_t *__restrict__ overflow_flag) {
+    __shared__ uint32_t wsum[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow_flag = 0; // set by k_tf_expand of this frame if it clips
+    uint32_t local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * TF_BLOCK + k * TF_THREADS + threadIdx.x;
+        if (i < n) local += range32_hits(range32[i]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// The pairs of a block land in [block_base, block_base + block_total) in ascending splat index, then
+// row-major over the splat's tile rectangle; the stable tile sort keeps that order inside each
+// tile, so equal depth keys still resolve by ascending index after k_tile_sort.
+__global__ __launch_bounds__(TF_THREADS) void k_tf_expand(const uint32_t *__restrict__ range32,
+                                                          const uint32_t *__restrict__ depth_keys, uint32_t n,
+                                                          const uint32_t *__restrict__ block_base, uint32_t ntx,
+                                                          uint32_t pair_limit, uint32_t *__restrict__ overflow,
+                                                          uint32_t *__restrict__ pair_tile, uint2 *__restrict__ pair_val) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
+    __shared__ uint32_t s_key[TF_BLOCK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t first = blockIdx.x * TF_BLOCK;
+    uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        const uint32_t slot = k * TF_THREADS + tid, i = first + slot;
+        r[k] = 1u; // empty
+        uint32_t key = 0;
+        if (i < n) {
+            r[k] = range32[i];
+            key = depth_keys[i];
+        }
+        s_key[slot] = key;
+        h[k] = range32_hits(r[k]);
+    }
+    uint32_t off[TF_PER_THREAD];
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        uint32_t incl = h[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
+        __syncthreads();
+        off[k] = carry + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - h[k];
+        carry += s0 + s1 + s2 + s3;
+    }
+    const uint32_t total = carry, base = block_base[blockIdx.x];
+    if (total == 0) return;
+    // sync-free frames: pairs at or past the limit are dropped (and flagged); everything below the
+    // limit is written, so no later kernel ever indexes with a stale tile id or splat index
+    const bool clipped = base + total > pair_limit || base + total < base;
+    if (clipped && tid == 0) atomicOr(overflow, 1u);
+    if (base >= pair_limit) return;
+    const bool staged = total <= TF_STAGE;
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        if (h[k] == 0) continue;
+        const uint32_t tx0 = r[k] & 0xffu, tx1 = (r[k] >> 8) & 0xffu, ty0 = (r[k] >> 16) & 0xffu, ty1 = r[k] >> 24;
+        const uint32_t slot = k * TF_THREADS + tid;
+        uint32_t o = off[k];
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                if (staged) {
+                    stage[o] = ((ty * ntx + tx) << 10) | slot;
+                } else if (!clipped || base + o < pair_limit) {
+                    pair_tile[base + o] = ty * ntx + tx;
+                    pair_val[base + o] = make_uint2(s_key[slot], first + slot);
+                }
+                ++o;
+            }
+    }
+    if (staged) {
+        __syncthreads();
+        const uint32_t keep = clipped ? pair_limit - base : total;
+        for (uint32_t o = tid; o < keep && o < total; o += TF_THREADS) {
+            const uint32_t p = stage[o], slot = p & 1023u;
+            pair_tile[base + o] = p >> 10;
+            pair_val[base + o] = make_uint2(s_key[slot], first + slot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PerTileSorter: one workgroup per tile sorts the tile's (depth key, splat index) elements by key,
+// stable, and writes the tile's index list.
+//
+// LSD radix, 8 bits per pass, on (key - smallest key of the tile): a tile's keys span a narrow depth
+// range (<= 24 bits of difference at the bench sizes), so 3 passes instead of 4, and none at all for
+// a tile whose keys are equal.  Lists up to 5888 elements are sorted inside LDS — every thread
+// holds its elements in registers across the pass's barrier, so one LDS array is read and rewritten
+// in place.  Longer lists take the same passes through global memory (this tile's segment of the two
+// pair-value buffers as ping-pong), 4096 elements at a time.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t TS_THREADS = 256, TS_WAVES = 4;
+// Two size classes, one launch each over all tiles (a workgroup whose tile belongs to the other class
+// exits at once): the kernel is latency-bound (six barriers per pass, dependent LDS round trips), so
+// what matters is resident workgroups per CU, and most lists are short.
+//   short  <= 2048 elements:  8 per thread, 16 KiB staged -> seven workgroups per CU
+//   long    > 2048 elements: up to 24 per thread, 46 KiB staged -> three workgroups per CU; beyond 5888
+//           elements the passes go through global memory
+constexpr uint32_t TS_SHORT_ITEMS = 8, TS_LONG_ITEMS = 24;
+constexpr uint32_t TS_LDS_ELEMS = 5888; // 46 KiB + 5 KiB of counters: three workgroups in a CU's 160 KiB
+constexpr uint32_t TS_CHUNK_ITEMS = 16, TS_CHUNK = TS_CHUNK_ITEMS * TS_THREADS;
+
+struct TileSortShared {
+    uint32_t wave_hist[TS_WAVES][256];
+    uint32_t digit_base[256];
+    uint32_t wave_sums[TS_WAVES];
+    uint32_t kmin, kmax;
+};
+
+// rank of this lane's element among the elements of the same digit seen so far by this wave
+// (earlier instructions, then lower lanes), adding it to the wave's digit counter
+template <bool RANK_ATOMIC>
+__device__ __forceinline__ uint32_t wave_rank(uint32_t *wave_hist, uint32_t d) {
+    if (RANK_ATOMIC) return atomicAdd(&wave_hist[d], 1u); // lane-ordered returning LDS atomic (probed per context)
+    const uint64_t active = __ballot(true); // callers rank under `if (p < n)`: peers are active lanes only
+    uint32_t plo = (uint32_t)active, phi = (uint32_t)(active >> 32);
+#pragma unroll
+    for (uint32_t b = 0; b < 8; ++b) {
+        const uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+        const uint64_t bal = __ballot(m != 0);
+        plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);
+        phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
+    }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0));
+    const uint32_t leader = plo ? (uint32_t)__builtin_ctz(plo) : 32u + (uint32_t)__builtin_ctz(phi);
+    uint32_t prev = 0;
+    if (below == 0) prev = atomicAdd(&wave_hist[d], (uint32_t)(__popc(plo) + __popc(phi)));
+    return (uint32_t)__shfl((int)prev, (int)leader) + below;
+}
+
+// thread d: turns the four waves' counts of digit d into exclusive wave prefixes (in place) and returns
+// the total; then digit_base[d] = exclusive scan of the totals over the digits (+ nothing else)
+__device__ __forceinline__ uint32_t ts_wave_prefixes(TileSortShared &sh, uint32_t tid) {
+    const uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
+    sh.wave_hist[0][tid] = 0;
+    sh.wave_hist[1][tid] = c0;
+    sh.wave_hist[2][tid] = c0 + c1;
+    sh.wave_hist[3][tid] = c0 + c1 + c2;
+    return c0 + c1 + c2 + c3;
+}
+
+// exclusive scan of one value per thread over the 256 threads (two barriers)
+__device__ __forceinline__ uint32_t ts_scan256(TileSortShared &sh, uint32_t v, uint32_t tid) {
+    const uint32_t lane = tid & 63, w = tid >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t t = __shfl_up(incl, s);
+        if ((int)lane >= s) incl += t;
+    }
+    if (lane == 63) sh.wave_sums[w] = incl;
+    __syncthreads();
+    const uint32_t wprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+    __syncthreads();
+    return wprefix + incl - v;
+}
+
+template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS>
+__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
+                                                                                    uint32_t n_above, uint2 *vals, uint2 *scratch,
+                                                                                    uint32_t *__restrict__ out_idx) {
+    static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
+    constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_LDS_ELEMS ? TS_MAX_ITEMS * TS_THREADS : TS_LDS_ELEMS;
+    __shared__ TileSortShared sh;
+    __shared__ uint2 s_el[TS_CAP];
+    uint32_t *run_base = reinterpret_cast<uint32_t *>(s_el); // long-list path (s_el unused there): start of each digit's run
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t t = blockIdx.x;
+    const uint32_t base = offsets[t], n = offsets[t + 1] - base;
+    if (n <= n_above || (!LAST_CLASS && n > TS_CAP)) return; // empty, or another class's tile
+    if (tid == 0) {
+        sh.kmin = 0xffffffffu;
+        sh.kmax = 0;
+    }
+    __syncthreads();
+    uint2 *src = vals + base, *dst = scratch + base;
+    const bool in_lds = !LAST_CLASS || n <= TS_CAP;
+
+    // load (LDS path) and the tile's key range
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (uint32_t p = tid; p < n; p += TS_THREADS) {
+        const uint2 e = src[p];
+        if (in_lds) s_el[p] = e;
+        lo = min(lo, e.x);
+        hi = max(hi, e.x);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+    }
+    if (lane == 0) {
+        atomicMin(&sh.kmin, lo);
+        atomicMax(&sh.kmax, hi);
+    }
+    __syncthreads();
+    const uint32_t kmin = sh.kmin, range = sh.kmax - kmin;
+    const uint32_t passes = range == 0 ? 0u : (32u - (uint32_t)__builtin_clz(range) + 7u) / 8u;
+
+    if (in_lds) {
+        // per thread, wave-striped: position = (wave, item, lane).  Items go in groups of four so that
+        // four LDS reads, then four returning atomics, are in flight together (a branch per item
+        // would expose every round trip); positions past n are padding and do nothing.
+        const uint32_t items = ((n + TS_THREADS - 1) / TS_THREADS + 3u) & ~3u;
+        const uint32_t wbase = w * items * 64 + lane;
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t shift = pass * 8;
+            for (uint32_t i = tid; i < TS_WAVES * 256; i += TS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+            __syncthreads();
+            uint2 el[TS_MAX_ITEMS];
+            uint32_t rank[TS_MAX_ITEMS];
+#pragma unroll
+            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                if (g < items) {
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i) {
+                        const uint32_t p = wbase + i * 64;
+                        el[i] = s_el[p < n ? p : n - 1];
+                    }
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i) {
+                        const uint32_t p = wbase + i * 64;
+                        rank[i] = 0;
+                        if (p < n) rank[i] = wave_rank<RANK_ATOMIC>(sh.wave_hist[w], ((el[i].x - kmin) >> shift) & 255u);
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t dcount = ts_wave_prefixes(sh, tid);
+            const uint32_t excl = ts_scan256(sh, dcount, tid);
+            sh.digit_base[tid] = excl;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                if (g < items) {
+                    uint32_t pos[4];
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i) {
+                        const uint32_t d = ((el[i].x - kmin) >> shift) & 255u;
+                        pos[i - g] = sh.digit_base[d] + sh.wave_hist[w][d] + rank[i];
+                    }
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i)
+                        if (wbase + i * 64 < n) s_el[pos[i - g]] = el[i];
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t p = tid; p < n; p += TS_THREADS) out_idx[base + p] = s_el[p].y;
+        return;
+    }
+
+    // ---- long list: the same passes through global memory -------------------------------------
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const uint32_t shift = pass * 8;
+        // digit totals of the whole list -> start of every digit's run
+        sh.digit_base[tid] = 0;
+        __syncthreads();
+        for (uint32_t p = tid; p < n; p += TS_THREADS) atomicAdd(&sh.digit_base[((src[p].x - kmin) >> shift) & 255u], 1u);
+        __syncthreads();
+        const uint32_t tot = sh.digit_base[tid];
+        const uint32_t start = ts_scan256(sh, tot, tid);
+        run_base[tid] = start;
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += TS_CHUNK) {
+            for (uint32_t i = tid; i < TS_WAVES * 256; i += TS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+            __syncthreads();
+            uint2 el[TS_CHUNK_ITEMS];
+            uint32_t rank[TS_CHUNK_ITEMS];
+#pragma unroll
+            for (uint32_t i = 0; i < TS_CHUNK_ITEMS; ++i) {
+                const uint32_t p = c0 + w * (TS_CHUNK_ITEMS * 64) + i * 64 + lane;
+                el[i] = src[p < n ? p : n - 1];
+                rank[i] = 0;
+                if (p < n) rank[i] = wave_rank<RANK_ATOMIC>(sh.wave_hist[w], ((el[i].x - kmin) >> shift) & 255u);
+            }
+            __syncthreads();
+            const uint32_t dcount = ts_wave_prefixes(sh, tid);
+            const uint32_t rb = run_base[tid];
+            sh.digit_base[tid] = rb; // this chunk's elements of digit tid start here
+            run_base[tid] = rb + dcount;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t i = 0; i < TS_CHUNK_ITEMS; ++i) {
+                const uint32_t p = c0 + w * (TS_CHUNK_ITEMS * 64) + i * 64 + lane;
+                if (p < n) {
+                    const uint32_t d = ((el[i].x - kmin) >> shift) & 255u;
+                    dst[sh.digit_base[d] + sh.wave_hist[w][d] + rank[i]] = el[i];
+                }
+            }
+            __syncthreads();
+        }
+        uint2 *tmp = src; src = dst; dst = tmp;
+        __threadfence_block(); // the next pass reads what other waves of this workgroup just stored
+        __syncthreads();
+    }
+    for (uint32_t p = tid; p < n; p += TS_THREADS) out_idx[base + p] = src[p].y;
+}
+
+int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx) {
+    if (ctx->lds_atomic_ordered < 0) {
+        uint64_t bad = 1;
+        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+        if (prc != SPLAT_OK) return prc;
+        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
+    }
+    const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
+    if (ctx->lds_atomic_ordered == 1) {
+        hipLaunchKernelGGL((k_tile_sort<true, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
+                           scratch, out_idx);
+        hipLaunchKernelGGL((k_tile_sort<true, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
+                           vals, scratch, out_idx);
+    } else {
+        hipLaunchKernelGGL((k_tile_sort<false, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
+                           scratch, out_idx);
+        hipLaunchKernelGGL((k_tile_sort<false, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
+                           vals, scratch, out_idx);
+    }
+    LAUNCH_CHECK(ctx, "k_tile_sort");
+    return SPLAT_OK;
+}
+
+int tf_count_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t *blocksums, uint32_t *overflow_flag) {
+    hipLaunchKernelGGL(k_tf_count, dim3(div_up(n, TF_BLOCK)), dim3(TF_THREADS), 0, ctx->stream, range32, n, blocksums, overflow_flag);
+    LAUNCH_CHECK(ctx, "k_tf_count");
+    return SPLAT_OK;
+}
+
+int tf_expand_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, const uint32_t *block_base,
+                     uint32_t ntx, uint32_t pair_limit, uint32_t *overflow, uint32_t *pair_tile, uint2 *pair_val) {
+    hipLaunchKernelGGL(k_tf_expand, dim3(div_up(n, TF_BLOCK)), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, block_base, ntx,
+                       pair_limit, overflow, pair_tile, pair_val);
+    LAUNCH_CHECK(ctx, "k_tf_expand");
+    return SPLAT_OK;
+}

@@ -356,6 +356,13 @@ class GPUTileBinner:
         check(self.device.lib.splat_bin_total(self._b, C.byref(t)), self.device.ctx)
         return int(t.value)
 
+    def setFrameOrder(self, order):
+        """Order of work of the whole-frame call: "sortFirst" (global depth sort, bin in sorted order),
+        "tileFirst" (bin in index order, PerTileSorter-style depth sort of every tile's list) or
+        "default".  Same lists either way."""
+        code = {"default": -1, "sortFirst": 0, "tileFirst": 1}[order] if isinstance(order, str) else int(order)
+        check(self.device.lib.splat_bin_set_frame_order(self._b, code), self.device.ctx)
+
     def getTileSize(self):  # :361-363
         return self.tileSize
 
@@ -525,11 +532,13 @@ class Renderer:
     on the device.  (The reference's body — opaque depth-tested quads — is out of scope.)"""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", numPoints=0, tileSize=16,
-                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True):
+                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None):
         self.device, self.numPoints, self.tileSize = device, numPoints, tileSize
         self.projector = SplatProjector(device, numPoints)
         self.sorter = RadixSorter(device, numPoints)
         self.binner = GPUTileBinner(device, tileSize)
+        if frameOrder is not None:
+            self.binner.setFrameOrder(frameOrder)
         self.mode, self.earlyOut = mode, earlyOut
         self.output = None
         self.outputFloat = None

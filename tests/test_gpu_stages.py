@@ -571,3 +571,100 @@ def test_sequential_renderer_honours_given_order(device):
     assert err.max() <= TOL_EARLY_OUT_BOUND and (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
     for o in (r, pm, nbuf, obuf):
         o.destroy()
+
+
+# ---- tile-first frame order (bin in index order, PerTileSorter-style depth sort per tile) -----------
+TF_CASES = CASES + [
+    (20000, 64, 64, 21, 6.0),     # 16 tiles, thousands of entries each: lists beyond the in-LDS capacity
+    (30000, 48, 32, 22, 8.0),     # 6 tiles x ~30000 entries: the long-list (global memory) passes
+    (5000, 1920, 1080, 23, 1.0),  # 8160 tiles, most of them empty or single-entry
+]
+
+
+def _tile_first_frame(device, props, normals, u, n, w, h, want_float=True):
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="tileFirst")
+    r.render(u, pbuf, nbuf, None, w, h, wantFloat=want_float)
+    return r, pbuf, nbuf
+
+
+@pytest.mark.parametrize("n,w,h,seed,rs", TF_CASES)
+def test_tile_first_lists_and_image_match_sort_first(device, n, w, h, seed, rs):
+    props, normals, u = make_case(n, w, h, seed, rs)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h)
+    total = ref["indices"].shape[0]
+    assert r.binner.getTotalIndices() == total
+    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    got = r.readPixelsFloat()
+    r2 = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
+    r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    assert np.array_equal(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32))  # same lists -> same bits
+    for o in (r, r2, pbuf, nbuf):
+        o.destroy()
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "seven_points", "quadruplets"])
+def test_tile_first_depth_ties_resolve_by_index(device, kind):
+    """Depth is the distance to the camera, so splats at the same position share a key exactly: equal
+    keys must come out in ascending index (the stable order); a tile whose keys are all equal takes no
+    radix pass at all.  Radii still differ, so the duplicates cover different tile rectangles."""
+    n, w, h = 6000, 128, 96
+    props, normals, u = make_case(n, w, h, 31, 2.0)
+    distinct = {"all_equal": 1, "seven_points": 7, "quadruplets": n // 4}[kind]
+    props[:, :3] = props[np.arange(n) % distinct, :3] * np.float32(0.3 if distinct < 10 else 1.0)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    assert np.unique(ref["keys"][:n]).size <= distinct  # the construction really produces ties
+    r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h, want_float=False)
+    total = ref["indices"].shape[0]
+    assert r.binner.getTotalIndices() == total
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    for o in (r, pbuf, nbuf):
+        o.destroy()
+
+
+def test_tile_first_sync_free_repeat_and_overflow(device):
+    n, w, h = 20000, 320, 200
+    small, normals, u = make_case(n, w, h, 61, 0.5)
+    big = small.copy()
+    big[:, 3] *= 6.0
+    ref_s, ref_b = oracle_pipeline(small, normals, u, w, h), oracle_pipeline(big, normals, u, w, h)
+    sbuf, bbuf, nbuf = device.createBufferFrom(small), device.createBufferFrom(big), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="tileFirst")
+    r.render(u, sbuf, nbuf, None, w, h, wantFloat=True)
+    first = r.readPixelsFloat().copy()
+    for _ in range(3):
+        r.render(u, sbuf, nbuf, None, w, h, wantFloat=True)  # sync-free
+    assert not r.previousFrameOverflowed
+    assert np.array_equal(r.readPixelsFloat().view(np.uint32), first.view(np.uint32))
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref_s["indices"].shape[0]), ref_s["indices"])
+    r.render(u, bbuf, nbuf, None, w, h, wantFloat=True)      # outgrows the sync-free limit
+    r.readPixelsFloat()                                       # finish(): detects, renders again
+    assert r.previousFrameOverflowed
+    assert r.binner.getTotalIndices() == ref_b["indices"].shape[0]
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref_b["indices"].shape[0]), ref_b["indices"])
+    for o in (r, sbuf, bbuf, nbuf):
+        o.destroy()
+
+
+def test_tile_first_full_size_C2(device):
+    """5M @1080p: both frame orders must give identical tile lists (11.28M entries) and images."""
+    n, w, h = sr.scene.CONFIGS["C2"]
+    props, normals, u = make_case(n, w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    a = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
+    b = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="tileFirst")
+    a.render(u, pbuf, nbuf, None, w, h)
+    b.render(u, pbuf, nbuf, None, w, h)
+    total = a.binner.getTotalIndices()
+    assert total == b.binner.getTotalIndices() == 11280103
+    assert np.array_equal(a.binner.getTileOffsetsBuffer().read(np.uint32), b.binner.getTileOffsetsBuffer().read(np.uint32))
+    assert np.array_equal(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total))
+    assert np.array_equal(a.readPixels(), b.readPixels())
+    for _ in range(3):  # sync-free frames
+        b.render(u, pbuf, nbuf, None, w, h)
+    assert np.array_equal(a.readPixels(), b.readPixels())
+    for o in (a, b, pbuf, nbuf):
+        o.destroy()
