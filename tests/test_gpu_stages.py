@@ -317,7 +317,8 @@ def test_update_props(device):
         o.destroy()
 
 
-def test_full_frame_C0(device):
+@pytest.mark.parametrize("order", ["sortFirst", "tileFirst", "default"])
+def test_full_frame_C0(device, order):
     """BASELINE configs[0]: 10k Gaussians @256x256, whole frame through splat_render_frame."""
     n, w, h = sr.scene.CONFIGS["C0"]
     props, normals, u = make_case(n, w, h)
@@ -326,9 +327,10 @@ def test_full_frame_C0(device):
     want, want8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"],
                                  ref["counts"], ref["offsets"], w, h)
     pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
-    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
     r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-    assert np.array_equal(r.sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"])
+    if order == "sortFirst":  # (the tile-first order never sorts the splats globally)
+        assert np.array_equal(r.sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"])
     assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32), ref["indices"])
     err = np.abs(r.readPixelsFloat() - want)
     assert err.max() <= TOL_EARLY_OUT_BOUND
@@ -423,7 +425,7 @@ def test_full_size_C2_properties(device):
     n, w, h = sr.scene.CONFIGS["C2"]
     props, normals, u = make_case(n, w, h)
     pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
-    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
     r.render(u, pbuf, nbuf, None, w, h)
     order = r.sorter.getSortedIndicesBuffer().read(np.uint32, n)
     keys = r.sorter.getSortedKeysBuffer().read(np.uint32, n)
