@@ -277,15 +277,35 @@ static int binner_reserve_wide(splat_binner *b) {
     return SPLAT_OK;
 }
 
+int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted) {
+    splat_ctx *ctx = b->ctx;
+    if (tiles <= b->tiles_cap && n_sorted <= b->splats_cap) return SPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t tc = tiles > b->tiles_cap ? tiles : b->tiles_cap;
+    uint32_t sc = n_sorted > b->splats_cap ? n_sorted : b->splats_cap;
+    binner_free(b);
+    if (hipMalloc((void **)&b->counts, (size_t)tc * 4 + 16) != hipSuccess ||
+        hipMalloc((void **)&b->offsets, (size_t)tc * 4 + 16) != hipSuccess ||
+        hipMalloc((void **)&b->blocksums, (size_t)div_up(sc, BIN_BLOCK) * 4 + 16) != hipSuccess ||
+        hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess) {
+        binner_free(b);
+        return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
+    }
+    b->tiles_cap = tc;
+    b->splats_cap = sc;
+    return SPLAT_OK;
+}
+
 // binSplats.  range32 (optional): per splat index, the packed range the projector computed with the
 // same BinParams (frame path); otherwise ranges are derived from the projected bounds here.
 // depth_keys (frame path, with range32): per splat index, its depth key — selects the tile-first
 // order of work (tile_first.hip): `sorted` is then unused, the lists are depth-sorted per tile.
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
                uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32, const uint32_t *n_sorted_dev,
-               const uint32_t *depth_keys) {
+               const uint32_t *depth_keys, bool precounted) {
     splat_ctx *ctx = b->ctx;
     const bool tile_first = depth_keys != nullptr;
+    ARG_CHECK(ctx, !precounted || tile_first); // the caller already filled blocksums (1024-index blocks) and zeroed the overflow flag
     ARG_CHECK(ctx, width >= 1 && height >= 1);
     ARG_CHECK(ctx, n_sorted == 0 || (projected && (sorted || tile_first)));
     ARG_CHECK(ctx, !tile_first || (range32 && n_sorted == n_splats && !n_sorted_dev));
@@ -296,28 +316,15 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     if (tile_row0 > tile_row1) tile_row0 = tile_row1;
     const uint32_t blocks = div_up(n_sorted, BIN_BLOCK);
 
-    if (tiles > b->tiles_cap || n_sorted > b->splats_cap) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        uint32_t tc = tiles > b->tiles_cap ? tiles : b->tiles_cap;
-        uint32_t sc = n_sorted > b->splats_cap ? n_sorted : b->splats_cap;
-        binner_free(b);
-        if (hipMalloc((void **)&b->counts, (size_t)tc * 4 + 16) != hipSuccess ||
-            hipMalloc((void **)&b->offsets, (size_t)tc * 4 + 16) != hipSuccess ||
-            hipMalloc((void **)&b->blocksums, (size_t)div_up(sc, BIN_BLOCK) * 4 + 16) != hipSuccess ||
-            hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess) {
-            binner_free(b);
-            return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
-        }
-        b->tiles_cap = tc;
-        b->splats_cap = sc;
-    }
+    int rc = binner_reserve(b, tiles, n_sorted);
+    if (rc != SPLAT_OK) return rc;
     b->ntx = ntx;
     b->nty = nty;
     b->ran = false;
     const BinParams bp = {width, height, b->tile, ntx, nty, tile_row0, tile_row1};
 
     // the previous frame's async readback (if any): learn its pair total, detect overflow
-    int rc = binner_settle(b);
+    rc = binner_settle(b);
     if (rc != SPLAT_OK) return rc;
 
     stage_begin(ctx, SPLAT_STAGE_BIN);
@@ -325,8 +332,10 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     bool async = false;
     if (n_sorted > 0) {
         if (tile_first) {
-            rc = tf_count_launch(ctx, range32, n_splats, b->blocksums, b->d_total + 1);
-            if (rc != SPLAT_OK) return rc;
+            if (!precounted) {
+                rc = tf_count_launch(ctx, range32, n_splats, b->blocksums, b->d_total + 1);
+                if (rc != SPLAT_OK) return rc;
+            }
         } else if (range32)
             hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
                                n_splats, (const uint32_t *)sorted, n_sorted, n_sorted_dev, bp, b->ranges, b->blocksums, b->d_total + 1);

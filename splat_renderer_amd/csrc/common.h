@@ -89,6 +89,7 @@ struct splat_sorter {
     uint32_t last_count = 0, count_bound = 0;
     uint32_t *pinned_count = nullptr; // 4 u32 host-pinned
     hipEvent_t count_event = nullptr;
+    uint32_t kept_blocks = 0; // tile-first band frame: hist[0..kept_blocks) holds per-block kept counts, not yet summed
     bool result_in_primary = true;
     bool ran = false;
     int mode = -1; // -1 = library default, 0 = upsweep/rowscan/downsweep, 1 = onesweep (chained scan)
@@ -138,7 +139,8 @@ struct BinParams {
 int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
                uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32,
-               const uint32_t *n_sorted_dev = nullptr, const uint32_t *depth_keys = nullptr);
+               const uint32_t *n_sorted_dev = nullptr, const uint32_t *depth_keys = nullptr, bool precounted = false);
+int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-tile and per-position buffers
 // tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
 int tf_count_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t *blocksums, uint32_t *overflow_flag);
 int tf_expand_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, const uint32_t *block_base,

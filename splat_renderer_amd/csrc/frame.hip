@@ -67,6 +67,49 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare(const float4 *__r
     if (threadIdx.x == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// Tile-first band frame: the same pass, 1024 records per block (the binner's block size), also
+// counting each block's tile-splat pairs — it stands in for k_tf_count, and a splat outside the band
+// simply has an empty range (no compaction, no sort of the kept splats).
+constexpr uint32_t BTF_PER_THREAD = 4, BTF_BLOCK = BAND_THREADS * BTF_PER_THREAD;
+static_assert(BTF_BLOCK == 1024, "must match tile_first.hip's TF_BLOCK");
+
+__global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *__restrict__ records, uint32_t n, BinParams bp,
+                                                                  uint32_t *__restrict__ keys_by_idx, uint32_t *__restrict__ range32,
+                                                                  uint32_t *__restrict__ kept_blocks,
+                                                                  uint32_t *__restrict__ pair_blocks,
+                                                                  uint32_t *__restrict__ overflow_flag) {
+    __shared__ uint32_t wsum[2][4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow_flag = 0; // set by k_tf_expand of this frame if it clips
+    uint32_t kept = 0, pairs = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + threadIdx.x;
+        if (i < n) {
+            const float4 a = records[(size_t)i * 2], b = records[(size_t)i * 2 + 1];
+            uint32_t tx0, tx1, ty0, ty1;
+            const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
+            range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
+            keys_by_idx[i] = depth_key_of(b.x);
+            kept += ok ? 1u : 0u;
+            pairs += ok ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kept += __shfl_xor(kept, d);
+        pairs += __shfl_xor(pairs, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wsum[0][threadIdx.x >> 6] = kept;
+        wsum[1][threadIdx.x >> 6] = pairs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kept_blocks[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+        pair_blocks[blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
+}
+
 // compact: the kept (key, global index) pairs of block b go to [base[b], ...) in ascending index order
 __global__ __launch_bounds__(BAND_THREADS) void k_band_compact(const uint32_t *__restrict__ keys_by_idx,
                                                                const uint32_t *__restrict__ range32, uint32_t n,
@@ -175,14 +218,42 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     const uint32_t tile = cfg->tile_size, nty = div_up(height, tile);
     uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (row0 > row1) row0 = row1;
+    const uint32_t ntx = div_up(width, tile);
+    const bool fast = ntx <= 256 && nty <= 256 && n_records > 0;
+    if (fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST) {
+        // tile-first: one pass over the records (keys, band-clamped ranges, pair counts), then the
+        // binner in index order — a splat outside the band has an empty range and costs nothing more
+        if (n_records > sorter->capacity) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_band_frame: n_records exceeds the sorter's capacity");
+        int rc = binner_reserve_range32(binner, n_records);
+        if (rc != SPLAT_OK) return rc;
+        rc = binner_reserve(binner, ntx * nty, n_records);
+        if (rc != SPLAT_OK) return rc;
+        const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
+        const uint32_t blocks = div_up(n_records, BTF_BLOCK);
+        stage_begin(ctx, SPLAT_STAGE_PROJECT);
+        hipLaunchKernelGGL(k_band_prepare_tf, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp,
+                           sorter->keys, binner->range32, sorter->hist, binner->blocksums, binner->d_total + 1);
+        LAUNCH_CHECK(ctx, "k_band_prepare_tf");
+        stage_end(ctx, SPLAT_STAGE_PROJECT);
+        sorter->ran = false;
+        sorter->count_pending = false;
+        sorter->kept_blocks = blocks; // the kept count is summed on demand (splat_band_kept / splat_band_settle)
+        rc = binner_run(binner, records, n_records, nullptr, n_records, width, height, row0, row1, binner->range32, nullptr, sorter->keys,
+                        true);
+        if (rc != SPLAT_OK) return rc;
+        splat_composite_cfg c2 = *cfg;
+        c2.tile_row0 = row0;
+        c2.tile_row1 = row1;
+        return splat_composite(ctx, &c2, (const char *)props + 16, 2, normals, 1, records, binner->pairs.payload, binner->counts,
+                               binner->offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr);
+    }
+    sorter->kept_blocks = 0;
     // keep -> sort -> bin with the kept count living on the device: no host round trip in here
     int rc = band_settle_count(ctx, sorter); // the previous frame's kept count (async readback)
     if (rc != SPLAT_OK) {
         binner->have_last = false; // its pair total came from the truncated set: do not size the next frame from it
         return rc;
     }
-    const uint32_t ntx = div_up(width, tile);
-    const bool fast = ntx <= 256 && nty <= 256 && n_records > 0;
     uint32_t *range32 = nullptr;
     // grids of the sort and of the binner's count/expand are sized for `bound` kept splats: all
     // records on a first frame, 1.125x the previous frame's kept count afterwards
@@ -253,6 +324,10 @@ int splat_band_settle(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner
     }
     rc = binner_settle(binner);
     if (rc != SPLAT_OK) return rc;
+    if (sorter->kept_blocks) { // tile-first band frame: no kept-count bound to settle, the count is summed on demand
+        if (pairs_host) *pairs_host = binner->total;
+        return n_kept_host ? splat_band_kept(ctx, sorter, n_kept_host) : SPLAT_OK;
+    }
     if (n_kept_host) *n_kept_host = sorter->last_count;
     if (pairs_host) *pairs_host = binner->total;
     return SPLAT_OK;
@@ -263,6 +338,11 @@ int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host)
     ARG_CHECK(ctx, sorter && n_kept_host);
     int rc = ctx_ensure_pinned(ctx, 16);
     if (rc != SPLAT_OK) return rc;
+    if (sorter->kept_blocks) { // tile-first band frame: sum the per-block kept counts now
+        rc = scan_exclusive_u32(ctx, sorter->hist, sorter->hist, sorter->kept_blocks, sorter->d_count);
+        if (rc != SPLAT_OK) return rc;
+        sorter->kept_blocks = 0;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, sorter->d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *n_kept_host = *(volatile uint32_t *)ctx->pinned;
