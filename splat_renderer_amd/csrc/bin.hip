@@ -236,6 +236,8 @@ static void binner_free(splat_binner *b) {
     if (b->offsets) (void)hipFree(b->offsets);
     if (b->blocksums) (void)hipFree(b->blocksums);
     if (b->ranges) (void)hipFree(b->ranges);
+    if (b->tf_hist) (void)hipFree(b->tf_hist);
+    b->tf_hist = nullptr;
     b->counts = b->offsets = b->blocksums = nullptr;
     b->ranges = nullptr;
     b->tiles_cap = b->splats_cap = 0;
@@ -287,7 +289,8 @@ int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted) {
     if (hipMalloc((void **)&b->counts, (size_t)tc * 4 + 16) != hipSuccess ||
         hipMalloc((void **)&b->offsets, (size_t)tc * 4 + 16) != hipSuccess ||
         hipMalloc((void **)&b->blocksums, (size_t)div_up(sc, BIN_BLOCK) * 4 + 16) != hipSuccess ||
-        hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess) {
+        hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess ||
+        hipMalloc((void **)&b->tf_hist, ((size_t)256 * div_up(sc, BIN_BLOCK) + 256) * 4) != hipSuccess) {
         binner_free(b);
         return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
     }
@@ -302,10 +305,9 @@ int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted) {
 // order of work (tile_first.hip): `sorted` is then unused, the lists are depth-sorted per tile.
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
                uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32, const uint32_t *n_sorted_dev,
-               const uint32_t *depth_keys, bool precounted) {
+               const uint32_t *depth_keys) {
     splat_ctx *ctx = b->ctx;
     const bool tile_first = depth_keys != nullptr;
-    ARG_CHECK(ctx, !precounted || tile_first); // the caller already filled blocksums (1024-index blocks) and zeroed the overflow flag
     ARG_CHECK(ctx, width >= 1 && height >= 1);
     ARG_CHECK(ctx, n_sorted == 0 || (projected && (sorted || tile_first)));
     ARG_CHECK(ctx, !tile_first || (range32 && n_sorted == n_splats && !n_sorted_dev));
@@ -327,15 +329,22 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     rc = binner_settle(b);
     if (rc != SPLAT_OK) return rc;
 
+    // tile ids up to 16 bits, sorted in two passes with the bits split evenly (13 bits -> 6 + 7) rather
+    // than 8 + 5: a pass scatters in digit runs, and 64 + 128 bins give longer runs than 256 + 32
+    uint32_t tf_bits = 1;
+    while ((1u << tf_bits) < tiles) ++tf_bits;
+    const uint32_t tf_lo_bits = tf_bits <= 8 ? tf_bits : tf_bits / 2;
+
     stage_begin(ctx, SPLAT_STAGE_BIN);
     uint32_t total32 = 0;
     bool async = false;
     if (n_sorted > 0) {
         if (tile_first) {
-            if (!precounted) {
-                rc = tf_count_launch(ctx, range32, n_splats, b->blocksums, b->d_total + 1);
-                if (rc != SPLAT_OK) return rc;
-            }
+            // per 1024-splat block: its pairs per low tile-id digit (the first sort pass's histogram) and in total
+            rc = tf_hist_launch(ctx, range32, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->blocksums, b->d_total + 1);
+            if (rc != SPLAT_OK) return rc;
+            rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, BIN_BLOCK));
+            if (rc != SPLAT_OK) return rc;
         } else if (range32)
             hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
                                n_splats, (const uint32_t *)sorted, n_sorted, n_sorted_dev, bp, b->ranges, b->blocksums, b->d_total + 1);
@@ -372,16 +381,15 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     if (total32 > 0 && tile_first) {
         rc = binner_reserve_wide(b);
         if (rc != SPLAT_OK) return rc;
-        rc = tf_expand_launch(ctx, range32, depth_keys, n_splats, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys,
-                              b->wide_a);
+        // first pass of the tile-id sort, fused with the expansion (tile_first.hip); later kernels take
+        // their pair count from d_total[2], which k_tf_scatter sets (0 if the pairs do not fit)
+        rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
+                               b->d_total + 1, b->pairs.keys, b->wide_a);
         if (rc != SPLAT_OK) return rc;
-        uint32_t bits = 1;
-        while ((1u << bits) < tiles) ++bits;
-        const uint32_t *p_dev = async ? b->d_total : nullptr;
-        const uint32_t lo_bits = bits <= 8 ? bits : bits / 2;
+        const uint32_t *p_dev = b->d_total + 2;
         bool primary = true;
-        rc = radix_sort_wide(ctx, b->pairs.keys, b->wide_a, b->pairs.keys_b, b->wide_b, b->pairs.hist, total32, p_dev, 0, bits, lo_bits,
-                             &primary);
+        rc = radix_sort_wide(ctx, b->pairs.keys, b->wide_a, b->pairs.keys_b, b->wide_b, b->pairs.hist, total32, p_dev, tf_lo_bits, tf_bits,
+                             8, &primary);
         if (rc != SPLAT_OK) return rc;
         const uint32_t *sorted_tiles = primary ? b->pairs.keys : b->pairs.keys_b;
         hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 4)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
@@ -394,7 +402,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
-        if (async) b->pending = true; // k_tile_counts reports {total, overflow, seq} into b->pinned
+        if (async) b->pending = true; // k_tile_counts reports {total, overflow, seq} into b->pinned; examined at the next call
     } else if (total32 > 0) {
         hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
                            b->ranges, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys, b->pairs.payload);

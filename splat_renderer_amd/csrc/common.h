@@ -111,6 +111,7 @@ struct splat_binner {
     splat_sorter pairs;                             // (tileId, splatIdx) ping-pong buffers
     uint2 *wide_a = nullptr, *wide_b = nullptr;     // tile-first path: (depth key, splat idx) per pair, ping-pong
     uint32_t wide_cap = 0;
+    uint32_t *tf_hist = nullptr;                    // tile-first path: per 1024-splat block digit histograms (first sort pass)
     int frame_order = -1;                           // splat_bin_set_frame_order
     uint64_t total = 0;
     bool ran = false;
@@ -139,12 +140,15 @@ struct BinParams {
 int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
                uint32_t height, uint32_t tile_row0, uint32_t tile_row1, const uint32_t *range32,
-               const uint32_t *n_sorted_dev = nullptr, const uint32_t *depth_keys = nullptr, bool precounted = false);
+               const uint32_t *n_sorted_dev = nullptr, const uint32_t *depth_keys = nullptr);
 int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-tile and per-position buffers
 // tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
-int tf_count_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t *blocksums, uint32_t *overflow_flag);
-int tf_expand_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, const uint32_t *block_base,
-                     uint32_t ntx, uint32_t pair_limit, uint32_t *overflow, uint32_t *pair_tile, uint2 *pair_val);
+int tf_hist_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t ntx, uint32_t mask, uint32_t *hist,
+                   uint32_t *blocksums, uint32_t *overflow_flag);
+int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
+                      const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
+                      uint2 *out_val);
+int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx);
 int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2 *v1, uint32_t *hist, uint32_t n,
                     const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, uint32_t first_bits, bool *result_in_primary);

@@ -67,20 +67,15 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare(const float4 *__r
     if (threadIdx.x == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// Tile-first band frame: the same pass, 1024 records per block (the binner's block size), also
-// counting each block's tile-splat pairs — it stands in for k_tf_count, and a splat outside the band
-// simply has an empty range (no compaction, no sort of the kept splats).
+// Tile-first band frame: the same pass, 1024 records per block; a splat outside the band simply has
+// an empty range (no compaction, no sort of the kept splats).
 constexpr uint32_t BTF_PER_THREAD = 4, BTF_BLOCK = BAND_THREADS * BTF_PER_THREAD;
-static_assert(BTF_BLOCK == 1024, "must match tile_first.hip's TF_BLOCK");
 
 __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *__restrict__ records, uint32_t n, BinParams bp,
                                                                   uint32_t *__restrict__ keys_by_idx, uint32_t *__restrict__ range32,
-                                                                  uint32_t *__restrict__ kept_blocks,
-                                                                  uint32_t *__restrict__ pair_blocks,
-                                                                  uint32_t *__restrict__ overflow_flag) {
-    __shared__ uint32_t wsum[2][4];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow_flag = 0; // set by k_tf_expand of this frame if it clips
-    uint32_t kept = 0, pairs = 0;
+                                                                  uint32_t *__restrict__ kept_blocks) {
+    __shared__ uint32_t wsum[4];
+    uint32_t kept = 0;
 #pragma unroll
     for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
         const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + threadIdx.x;
@@ -91,23 +86,13 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
             range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
             keys_by_idx[i] = depth_key_of(b.x);
             kept += ok ? 1u : 0u;
-            pairs += ok ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0u;
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        kept += __shfl_xor(kept, d);
-        pairs += __shfl_xor(pairs, d);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        wsum[0][threadIdx.x >> 6] = kept;
-        wsum[1][threadIdx.x >> 6] = pairs;
-    }
+    for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = kept;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        kept_blocks[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
-        pair_blocks[blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
-    }
+    if (threadIdx.x == 0) kept_blocks[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // compact: the kept (key, global index) pairs of block b go to [base[b], ...) in ascending index order
@@ -226,20 +211,17 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         if (n_records > sorter->capacity) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_band_frame: n_records exceeds the sorter's capacity");
         int rc = binner_reserve_range32(binner, n_records);
         if (rc != SPLAT_OK) return rc;
-        rc = binner_reserve(binner, ntx * nty, n_records);
-        if (rc != SPLAT_OK) return rc;
         const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
         const uint32_t blocks = div_up(n_records, BTF_BLOCK);
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
         hipLaunchKernelGGL(k_band_prepare_tf, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp,
-                           sorter->keys, binner->range32, sorter->hist, binner->blocksums, binner->d_total + 1);
+                           sorter->keys, binner->range32, sorter->hist);
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
         sorter->ran = false;
         sorter->count_pending = false;
         sorter->kept_blocks = blocks; // the kept count is summed on demand (splat_band_kept / splat_band_settle)
-        rc = binner_run(binner, records, n_records, nullptr, n_records, width, height, row0, row1, binner->range32, nullptr, sorter->keys,
-                        true);
+        rc = binner_run(binner, records, n_records, nullptr, n_records, width, height, row0, row1, binner->range32, nullptr, sorter->keys);
         if (rc != SPLAT_OK) return rc;
         splat_composite_cfg c2 = *cfg;
         c2.tile_row0 = row0;

@@ -581,6 +581,12 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
     return SPLAT_OK;
 }
 
+int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts) {
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, hist + (size_t)256 * parts);
+    LAUNCH_CHECK(ctx, "k_radix_rowscan");
+    return SPLAT_OK;
+}
+
 // Stable sort of (u32 key, 8-byte payload) elements by key bits [bit_begin, bit_end): same three
 // kernels per pass (4096-element partitions).  hist needs 256*parts+256 words for parts = ceil(n / 4096).  Result side reported as for radix_sort_pairs.
 int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2 *v1, uint32_t *hist, uint32_t n,

@@ -31,102 +31,6 @@ __device__ __forceinline__ uint32_t range32_hits(uint32_t r) {
     return (tx0 > tx1 || ty0 > ty1) ? 0u : (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
 }
 
-__global__ __launch_bounds__(TF_THREADS) void k_tf_count(const uint32_t *__restrict__ range32, uint32_t n,
-                                                         uint32_t *__restrict__ blocksums, uint32_t *__restrict__ overflow_flag) {
-    __shared__ uint32_t wsum[4];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow_flag = 0; // set by k_tf_expand of this frame if it clips
-    uint32_t local = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        const uint32_t i = blockIdx.x * TF_BLOCK + k * TF_THREADS + threadIdx.x;
-        if (i < n) local += range32_hits(range32[i]);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
-    __syncthreads();
-    if (threadIdx.x == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// The pairs of a block land in [block_base, block_base + block_total) in ascending splat index, then
-// row-major over the splat's tile rectangle; the stable tile sort keeps that order inside each
-// tile, so equal depth keys still resolve by ascending index after k_tile_sort.
-__global__ __launch_bounds__(TF_THREADS) void k_tf_expand(const uint32_t *__restrict__ range32,
-                                                          const uint32_t *__restrict__ depth_keys, uint32_t n,
-                                                          const uint32_t *__restrict__ block_base, uint32_t ntx,
-                                                          uint32_t pair_limit, uint32_t *__restrict__ overflow,
-                                                          uint32_t *__restrict__ pair_tile, uint2 *__restrict__ pair_val) {
-    __shared__ uint32_t wsum[4];
-    __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
-    __shared__ uint32_t s_key[TF_BLOCK];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t first = blockIdx.x * TF_BLOCK;
-    uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
-#pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        const uint32_t slot = k * TF_THREADS + tid, i = first + slot;
-        r[k] = 1u; // empty
-        uint32_t key = 0;
-        if (i < n) {
-            r[k] = range32[i];
-            key = depth_keys[i];
-        }
-        s_key[slot] = key;
-        h[k] = range32_hits(r[k]);
-    }
-    uint32_t off[TF_PER_THREAD];
-    uint32_t carry = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        uint32_t incl = h[k];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
-        __syncthreads();
-        off[k] = carry + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - h[k];
-        carry += s0 + s1 + s2 + s3;
-    }
-    const uint32_t total = carry, base = block_base[blockIdx.x];
-    if (total == 0) return;
-    // sync-free frames: pairs at or past the limit are dropped (and flagged); everything below the
-    // limit is written, so no later kernel ever indexes with a stale tile id or splat index
-    const bool clipped = base + total > pair_limit || base + total < base;
-    if (clipped && tid == 0) atomicOr(overflow, 1u);
-    if (base >= pair_limit) return;
-    const bool staged = total <= TF_STAGE;
-#pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        if (h[k] == 0) continue;
-        const uint32_t tx0 = r[k] & 0xffu, tx1 = (r[k] >> 8) & 0xffu, ty0 = (r[k] >> 16) & 0xffu, ty1 = r[k] >> 24;
-        const uint32_t slot = k * TF_THREADS + tid;
-        uint32_t o = off[k];
-        for (uint32_t ty = ty0; ty <= ty1; ++ty)
-            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                if (staged) {
-                    stage[o] = ((ty * ntx + tx) << 10) | slot;
-                } else if (!clipped || base + o < pair_limit) {
-                    pair_tile[base + o] = ty * ntx + tx;
-                    pair_val[base + o] = make_uint2(s_key[slot], first + slot);
-                }
-                ++o;
-            }
-    }
-    if (staged) {
-        __syncthreads();
-        const uint32_t keep = clipped ? pair_limit - base : total;
-        for (uint32_t o = tid; o < keep && o < total; o += TF_THREADS) {
-            const uint32_t p = stage[o], slot = p & 1023u;
-            pair_tile[base + o] = p >> 10;
-            pair_val[base + o] = make_uint2(s_key[slot], first + slot);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // PerTileSorter: one workgroup per tile sorts the tile's (depth key, splat index) elements by key,
 // stable, and writes the tile's index list.
@@ -179,17 +83,17 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t *wave_hist, uint32_t d) {
 
 // thread d: turns the four waves' counts of digit d into exclusive wave prefixes (in place) and returns
 // the total; then digit_base[d] = exclusive scan of the totals over the digits (+ nothing else)
-__device__ __forceinline__ uint32_t ts_wave_prefixes(TileSortShared &sh, uint32_t tid) {
-    const uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
-    sh.wave_hist[0][tid] = 0;
-    sh.wave_hist[1][tid] = c0;
-    sh.wave_hist[2][tid] = c0 + c1;
-    sh.wave_hist[3][tid] = c0 + c1 + c2;
+__device__ __forceinline__ uint32_t ts_wave_prefixes(uint32_t (*wave_hist)[256], uint32_t tid) {
+    const uint32_t c0 = wave_hist[0][tid], c1 = wave_hist[1][tid], c2 = wave_hist[2][tid], c3 = wave_hist[3][tid];
+    wave_hist[0][tid] = 0;
+    wave_hist[1][tid] = c0;
+    wave_hist[2][tid] = c0 + c1;
+    wave_hist[3][tid] = c0 + c1 + c2;
     return c0 + c1 + c2 + c3;
 }
 
 // exclusive scan of one value per thread over the 256 threads (two barriers)
-__device__ __forceinline__ uint32_t ts_scan256(TileSortShared &sh, uint32_t v, uint32_t tid) {
+__device__ __forceinline__ uint32_t ts_scan256(uint32_t *wave_sums, uint32_t v, uint32_t tid) {
     const uint32_t lane = tid & 63, w = tid >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -197,11 +101,197 @@ __device__ __forceinline__ uint32_t ts_scan256(TileSortShared &sh, uint32_t v, u
         const uint32_t t = __shfl_up(incl, s);
         if ((int)lane >= s) incl += t;
     }
-    if (lane == 63) sh.wave_sums[w] = incl;
+    if (lane == 63) wave_sums[w] = incl;
     __syncthreads();
-    const uint32_t wprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+    const uint32_t wprefix = (w > 0 ? wave_sums[0] : 0u) + (w > 1 ? wave_sums[1] : 0u) + (w > 2 ? wave_sums[2] : 0u);
     __syncthreads();
     return wprefix + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The pairs are never written in expansion order: a 1024-splat block IS a partition of the tile-id
+// sort's first pass.  k_tf_hist counts the block's pairs per low tile-id digit (the upsweep's
+// histogram, straight from the ranges); k_tf_scatter expands the block into LDS, ranks the pairs by
+// that digit and scatters (tile id | depth key, index) to their first-pass positions (the downsweep).
+// Saved per frame: the expanded array's write and two reads (12 + 4 + 12 B per pair).
+//
+// Order inside a block: ascending splat index, then row-major over the splat's tile rectangle; the
+// stable passes keep it inside each tile, so equal depth keys still resolve by ascending index.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TF_THREADS) void k_tf_hist(const uint32_t *__restrict__ range32, uint32_t n, uint32_t ntx,
+                                                        uint32_t mask, uint32_t num_parts, uint32_t *__restrict__ hist,
+                                                        uint32_t *__restrict__ blocksums, uint32_t *__restrict__ overflow_flag) {
+    __shared__ uint32_t lh[4][256];
+    __shared__ uint32_t wsum[4];
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) *overflow_flag = 0; // set by k_tf_scatter of this frame if the pairs do not fit
+    for (uint32_t i = tid; i < 4 * 256; i += TF_THREADS) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        const uint32_t i = blockIdx.x * TF_BLOCK + k * TF_THREADS + tid;
+        if (i >= n) continue;
+        const uint32_t r = range32[i];
+        const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
+        if (tx0 > tx1 || ty0 > ty1) continue;
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * ntx + tx) & mask], 1u);
+        local += (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0) wsum[w] = local;
+    __syncthreads();
+    hist[(size_t)tid * num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+    if (tid == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+constexpr uint32_t TFS_ITEMS = TF_STAGE / TF_THREADS; // 16 staged pairs per thread and round
+
+struct TfScatterShared {
+    uint32_t wave_hist[TS_WAVES][256];
+    uint32_t digit_base[256];  // round-local start of each digit's run
+    uint32_t global_base[256]; // where this block's pairs of each digit start in the output (advances per round)
+    uint32_t wave_sums[TS_WAVES];
+};
+
+// d_total: [0] = pair total of this frame (scan of the block sums); [2] (out) = the count the later
+// kernels work on: the total, or 0 when it exceeds pair_limit (then nothing is written and the
+// overflow flag is raised: the frame is rendered again with room).
+template <bool RANK_ATOMIC>
+__global__ __launch_bounds__(TF_THREADS) void k_tf_scatter(const uint32_t *__restrict__ range32,
+                                                           const uint32_t *__restrict__ depth_keys, uint32_t n, uint32_t ntx,
+                                                           uint32_t mask, uint32_t num_parts,
+                                                           const uint32_t *__restrict__ scanned_hist,
+                                                           const uint32_t *__restrict__ totals, uint32_t *__restrict__ d_total,
+                                                           uint32_t pair_limit, uint32_t *__restrict__ overflow,
+                                                           uint32_t *__restrict__ out_tile, uint2 *__restrict__ out_val) {
+    __shared__ TfScatterShared sh;
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
+    __shared__ uint32_t s_key[TF_BLOCK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t first = blockIdx.x * TF_BLOCK;
+    const uint32_t all_pairs = d_total[0];
+    if (all_pairs > pair_limit) {
+        if (blockIdx.x == 0 && tid == 0) {
+            atomicOr(overflow, 1u);
+            d_total[2] = 0;
+        }
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) d_total[2] = all_pairs;
+
+    uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        const uint32_t slot = k * TF_THREADS + tid, i = first + slot;
+        r[k] = 1u; // empty
+        uint32_t key = 0;
+        if (i < n) {
+            r[k] = range32[i];
+            key = depth_keys[i];
+        }
+        s_key[slot] = key;
+        h[k] = range32_hits(r[k]);
+    }
+    // start of this block's pairs of digit tid: digit start (scan of the digit totals) + the earlier blocks' share
+    const uint32_t digit_total = totals[tid];
+    uint32_t gincl = digit_total;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t t = __shfl_up(gincl, s);
+        if ((int)lane >= s) gincl += t;
+    }
+    if (lane == 63) sh.wave_sums[w] = gincl;
+    // offsets of every splat's pairs inside the block, position-major (k, thread): ascending splat index
+    uint32_t off[TF_PER_THREAD];
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+        uint32_t incl = h[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
+        __syncthreads();
+        off[k] = carry + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - h[k];
+        carry += s0 + s1 + s2 + s3;
+    }
+    const uint32_t total = carry;
+    if (total == 0) return;
+    {
+        const uint32_t gprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+        sh.global_base[tid] = gprefix + gincl - digit_total + scanned_hist[(size_t)tid * num_parts + blockIdx.x];
+    }
+    // rounds of TF_STAGE pairs (one round unless the block's splats are unusually large)
+    for (uint32_t c0 = 0; c0 < total; c0 += TF_STAGE) {
+        const uint32_t cnt = (total - c0 < TF_STAGE) ? total - c0 : TF_STAGE;
+        for (uint32_t i = tid; i < TS_WAVES * 256; i += TF_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
+            if (h[k] == 0 || off[k] >= c0 + TF_STAGE || off[k] + h[k] <= c0) continue;
+            const uint32_t tx0 = r[k] & 0xffu, tx1 = (r[k] >> 8) & 0xffu, ty0 = (r[k] >> 16) & 0xffu, ty1 = r[k] >> 24;
+            const uint32_t slot = k * TF_THREADS + tid;
+            uint32_t o = off[k] - c0; // may wrap below zero for pairs of an earlier round: the range check rejects them
+            for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    if (o < TF_STAGE) stage[o] = ((ty * ntx + tx) << 10) | slot;
+                    ++o;
+                }
+        }
+        __syncthreads();
+        // rank by digit, wave-striped positions (wave, item, lane), items in groups of four
+        const uint32_t items = ((cnt + TF_THREADS - 1) / TF_THREADS + 3u) & ~3u;
+        const uint32_t wbase = w * items * 64 + lane;
+        uint32_t el[TFS_ITEMS], rank[TFS_ITEMS];
+#pragma unroll
+        for (uint32_t g = 0; g < TFS_ITEMS; g += 4) {
+            if (g < items) {
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    const uint32_t p = wbase + i * 64;
+                    el[i] = stage[p < cnt ? p : cnt - 1];
+                }
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    rank[i] = 0;
+                    if (wbase + i * 64 < cnt) rank[i] = wave_rank<RANK_ATOMIC>(sh.wave_hist[w], (el[i] >> 10) & mask);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t dcount = ts_wave_prefixes(sh.wave_hist, tid);
+        const uint32_t excl = ts_scan256(sh.wave_sums, dcount, tid);
+        sh.digit_base[tid] = excl;
+        __syncthreads();
+        // reorder in place (every thread holds its elements in registers): digit runs become contiguous
+#pragma unroll
+        for (uint32_t g = 0; g < TFS_ITEMS; g += 4) {
+            if (g < items) {
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    const uint32_t d = (el[i] >> 10) & mask;
+                    if (wbase + i * 64 < cnt) stage[sh.digit_base[d] + sh.wave_hist[w][d] + rank[i]] = el[i];
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t pos = tid; pos < cnt; pos += TF_THREADS) {
+            const uint32_t e = stage[pos], slot = e & 1023u, d = (e >> 10) & mask;
+            const uint32_t g = sh.global_base[d] + (pos - sh.digit_base[d]);
+            out_tile[g] = e >> 10;
+            out_val[g] = make_uint2(s_key[slot], first + slot);
+        }
+        __syncthreads();
+        sh.global_base[tid] += dcount; // the next round's pairs of digit tid follow this round's
+        __syncthreads();
+    }
 }
 
 template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS>
@@ -275,8 +365,8 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
                 }
             }
             __syncthreads();
-            const uint32_t dcount = ts_wave_prefixes(sh, tid);
-            const uint32_t excl = ts_scan256(sh, dcount, tid);
+            const uint32_t dcount = ts_wave_prefixes(sh.wave_hist, tid);
+            const uint32_t excl = ts_scan256(sh.wave_sums, dcount, tid);
             sh.digit_base[tid] = excl;
             __syncthreads();
 #pragma unroll
@@ -308,7 +398,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
         for (uint32_t p = tid; p < n; p += TS_THREADS) atomicAdd(&sh.digit_base[((src[p].x - kmin) >> shift) & 255u], 1u);
         __syncthreads();
         const uint32_t tot = sh.digit_base[tid];
-        const uint32_t start = ts_scan256(sh, tot, tid);
+        const uint32_t start = ts_scan256(sh.wave_sums, tot, tid);
         run_base[tid] = start;
         __syncthreads();
         for (uint32_t c0 = 0; c0 < n; c0 += TS_CHUNK) {
@@ -324,7 +414,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
                 if (p < n) rank[i] = wave_rank<RANK_ATOMIC>(sh.wave_hist[w], ((el[i].x - kmin) >> shift) & 255u);
             }
             __syncthreads();
-            const uint32_t dcount = ts_wave_prefixes(sh, tid);
+            const uint32_t dcount = ts_wave_prefixes(sh.wave_hist, tid);
             const uint32_t rb = run_base[tid];
             sh.digit_base[tid] = rb; // this chunk's elements of digit tid start here
             run_base[tid] = rb + dcount;
@@ -369,16 +459,33 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     return SPLAT_OK;
 }
 
-int tf_count_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t *blocksums, uint32_t *overflow_flag) {
-    hipLaunchKernelGGL(k_tf_count, dim3(div_up(n, TF_BLOCK)), dim3(TF_THREADS), 0, ctx->stream, range32, n, blocksums, overflow_flag);
-    LAUNCH_CHECK(ctx, "k_tf_count");
+int tf_hist_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t ntx, uint32_t mask, uint32_t *hist,
+                   uint32_t *blocksums, uint32_t *overflow_flag) {
+    const uint32_t parts = div_up(n, TF_BLOCK);
+    hipLaunchKernelGGL(k_tf_hist, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, n, ntx, mask, parts, hist, blocksums,
+                       overflow_flag);
+    LAUNCH_CHECK(ctx, "k_tf_hist");
     return SPLAT_OK;
 }
 
-int tf_expand_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, const uint32_t *block_base,
-                     uint32_t ntx, uint32_t pair_limit, uint32_t *overflow, uint32_t *pair_tile, uint2 *pair_val) {
-    hipLaunchKernelGGL(k_tf_expand, dim3(div_up(n, TF_BLOCK)), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, block_base, ntx,
-                       pair_limit, overflow, pair_tile, pair_val);
-    LAUNCH_CHECK(ctx, "k_tf_expand");
+// hist: k_tf_hist's output after radix_rowscan_launch (rows scanned in place, digit totals behind them)
+int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
+                      const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
+                      uint2 *out_val) {
+    const uint32_t parts = div_up(n, TF_BLOCK);
+    const uint32_t *totals = hist + (size_t)256 * parts;
+    if (ctx->lds_atomic_ordered < 0) {
+        uint64_t bad = 1;
+        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+        if (prc != SPLAT_OK) return prc;
+        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
+    }
+    if (ctx->lds_atomic_ordered == 1)
+        hipLaunchKernelGGL(k_tf_scatter<true>, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, hist,
+                           totals, d_total, pair_limit, overflow, out_tile, out_val);
+    else
+        hipLaunchKernelGGL(k_tf_scatter<false>, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, hist,
+                           totals, d_total, pair_limit, overflow, out_tile, out_val);
+    LAUNCH_CHECK(ctx, "k_tf_scatter");
     return SPLAT_OK;
 }
