@@ -331,9 +331,9 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
 
     // tile ids up to 16 bits, sorted in two passes with the bits split evenly (13 bits -> 6 + 7) rather
     // than 8 + 5: a pass scatters in digit runs, and 64 + 128 bins give longer runs than 256 + 32
-    uint32_t tf_bits = 1;
-    while ((1u << tf_bits) < tiles) ++tf_bits;
-    const uint32_t tf_lo_bits = tf_bits <= 8 ? tf_bits : tf_bits / 2;
+    const uint32_t tf_bits = tile_id_bits(tiles), tf_lo_bits = tile_id_low_bits(tiles);
+    const bool hist_ready = b->tf_hist_ready;
+    b->tf_hist_ready = false;
 
     stage_begin(ctx, SPLAT_STAGE_BIN);
     uint32_t total32 = 0;
@@ -341,7 +341,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     if (n_sorted > 0) {
         if (tile_first) {
             // per 1024-splat block: its pairs per low tile-id digit (the first sort pass's histogram) and in total
-            rc = tf_hist_launch(ctx, range32, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->blocksums, b->d_total + 1);
+            if (!hist_ready) rc = tf_hist_launch(ctx, range32, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->blocksums, b->d_total + 1);
             if (rc != SPLAT_OK) return rc;
             rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, BIN_BLOCK));
             if (rc != SPLAT_OK) return rc;

@@ -113,6 +113,7 @@ struct splat_binner {
     uint32_t wide_cap = 0;
     uint32_t *tf_hist = nullptr;                    // tile-first path: per 1024-splat block digit histograms (first sort pass)
     int frame_order = -1;                           // splat_bin_set_frame_order
+    bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
     uint64_t total = 0;
     bool ran = false;
     // sync-free operation: when the previous frame's pair total is known and 1.125x of it fits the
@@ -136,6 +137,23 @@ struct BinParams {
     uint32_t width, height, tile, ntx, nty, row0, row1;
 };
 
+// Where the frame path's projector leaves the first sort pass's histogram (tile_first.hip): per
+// 1024-splat block the pairs per low tile-id digit (digit-major, num_parts columns) and in total.
+struct TfHistOut {
+    uint32_t *hist, *blocksums, *overflow_flag;
+    uint32_t mask, num_parts;
+};
+// tile-id bits and their split over the two sort passes (13 bits -> 6 + 7: longer digit runs than 8 + 5)
+static inline uint32_t tile_id_bits(uint32_t tiles) {
+    uint32_t bits = 1;
+    while ((1u << bits) < tiles) ++bits;
+    return bits;
+}
+static inline uint32_t tile_id_low_bits(uint32_t tiles) {
+    const uint32_t bits = tile_id_bits(tiles);
+    return bits <= 8 ? bits : bits / 2;
+}
+
 // bin.hip internals used by frame.hip
 int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
@@ -156,4 +174,4 @@ int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_
 // project.hip internal: the projector with the optional per-index tile range output
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
-                   const BinParams *bp);
+                   const BinParams *bp, const TfHistOut *hist_out = nullptr);

@@ -356,10 +356,19 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
         range32 = binner->range32;
     }
     ARG_CHECK(ctx, (((uintptr_t)props | (uintptr_t)projected) & 15) == 0);
-    // (the payload array is not written: payload = splat index, synthesised by the sort's first pass)
-    rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp);
+    const bool tile_first = fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST;
+    TfHistOut ho = {};
+    if (tile_first) { // the projector also counts each 1024-splat block's pairs per low tile-id digit
+        rc = binner_reserve(binner, ntx * nty, n);
+        if (rc != SPLAT_OK) return rc;
+        ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, 1024)};
+    }
+    // (the payload array is not written: payload = splat index)
+    rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
+                        tile_first ? &ho : nullptr);
     if (rc != SPLAT_OK) return rc;
-    if (fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST) {
+    binner->tf_hist_ready = tile_first;
+    if (tile_first) {
         // bin in index order, depth-sort per tile: no global sort, no gather (tile_first.hip)
         sorter->ran = false; // the sorter holds this frame's unsorted depth keys
         rc = binner_run(binner, projected, n, nullptr, n, width, height, row0, row1, range32, nullptr, sorter->keys);

@@ -34,19 +34,12 @@ __device__ __forceinline__ uint32_t depth_key(float depth) {
     return bits ^ mask;
 }
 
+// One splat: record, key, payload, packed tile range.  Returns the packed range (1 = empty).
 template <bool WITH_KEYS, bool WITH_RANGE>
-__global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
-                                                 uint32_t stride_vec4, uint32_t n, uint32_t n_padded, uint32_t index_base,
-                                                 float4 *__restrict__ projected, uint32_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, BinParams bp) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) {
-        if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
-            keys[i] = 0xffffffffu;
-            if (payload) payload[i] = 0xffffffffu;
-        }
-        return;
-    }
+__device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                uint32_t i, uint32_t index_base, float4 *__restrict__ projected,
+                                                uint32_t *__restrict__ keys, uint32_t *__restrict__ payload,
+                                                uint32_t *__restrict__ range32, const BinParams &bp) {
     float4 pr = pos_radius[(size_t)i * stride_vec4];
     float x = pr.x, y = pr.y, z = pr.z, radius = pr.w;
     float dx = x - u.eye[0], dy = y - u.eye[1], dz = z - u.eye[2];
@@ -73,11 +66,68 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
         keys[i] = depth_key(depth);
         if (payload) payload[i] = index_base + i; // (frame path: the sort's first pass synthesises it)
     }
-    if (WITH_RANGE) { // the binner's clamped tile range while the bounds are still in registers:
-        // after the sort it is then a 4-byte gather instead of a 16-byte one
+    uint32_t packed = 1u;
+    if (WITH_RANGE) { // the binner's clamped tile range while the bounds are still in registers
         uint32_t tx0, tx1, ty0, ty1;
         const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
-        range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
+        packed = pack_range32(ok, tx0, tx1, ty0, ty1);
+        range32[i] = packed;
+    }
+    return packed;
+}
+
+template <bool WITH_KEYS, bool WITH_RANGE>
+__global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
+                                                 uint32_t stride_vec4, uint32_t n, uint32_t n_padded, uint32_t index_base,
+                                                 float4 *__restrict__ projected, uint32_t *__restrict__ keys,
+                                                 uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, BinParams bp) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) {
+        if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
+            keys[i] = 0xffffffffu;
+            if (payload) payload[i] = 0xffffffffu;
+        }
+        return;
+    }
+    project_one<WITH_KEYS, WITH_RANGE>(u, pos_radius, stride_vec4, i, index_base, projected, keys, payload, range32, bp);
+}
+
+// Tile-first frame path: 1024 splats per workgroup (the binner's block), and while each splat's tile
+// rectangle is in registers the block's pairs are counted per low tile-id digit — the histogram the
+// first pass of the tile-id sort needs (tile_first.hip, k_tf_hist does the same from range32 when the
+// ranges come from elsewhere).  The kernel is HBM-bound; the LDS counting hides under the stores.
+__global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                      uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
+                                                      TfHistOut ho) {
+    __shared__ uint32_t lh[4][256];
+    __shared__ uint32_t wsum[4];
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
+    for (uint32_t j = tid; j < 4 * 256; j += 256) (&lh[0][0])[j] = 0;
+    __syncthreads();
+    uint32_t local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = blockIdx.x * 1024u + k * 256u + tid;
+        if (i >= n) {
+            if (i < n_padded) keys[i] = 0xffffffffu;
+            continue;
+        }
+        const uint32_t r = project_one<true, true>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp);
+        const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
+        if (tx0 > tx1 || ty0 > ty1) continue;
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * bp.ntx + tx) & ho.mask], 1u);
+        local += (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0) wsum[w] = local;
+    __syncthreads();
+    if (blockIdx.x < ho.num_parts) { // (blocks that only pad keys past n have no histogram column)
+        ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+        if (tid == 0) ho.blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
@@ -106,7 +156,7 @@ __global__ __launch_bounds__(256) void k_update_props(const float4 *__restrict__
 
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
-                   const BinParams *bp) {
+                   const BinParams *bp, const TfHistOut *hist_out) {
     FrameUniforms u;
     for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
     u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
@@ -117,7 +167,10 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
     const float4 *src = (const float4 *)pos_radius + (size_t)index_base * pr_stride_vec4;
     stage_begin(ctx, SPLAT_STAGE_PROJECT);
     dim3 grid(div_up(work, 256)), block(256);
-    if (keys && range32)
+    if (hist_out && keys && range32 && !payload && index_base == 0)
+        hipLaunchKernelGGL(k_project_hist, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
+                           (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out);
+    else if (keys && range32)
         hipLaunchKernelGGL((k_project<true, true>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, index_base,
                            (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, range32, *bp);
     else if (keys)
@@ -141,7 +194,7 @@ int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
     ARG_CHECK(ctx, (keys == nullptr) == (payload == nullptr));
     ARG_CHECK(ctx, keys == nullptr || n_padded >= n);
     ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected) & 15) == 0);
-    return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, n, 0, projected, keys, payload, n_padded, nullptr, nullptr);
+    return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, n, 0, projected, keys, payload, n_padded, nullptr, nullptr, nullptr);
 }
 
 int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t first,
@@ -150,7 +203,7 @@ int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_r
     ARG_CHECK(ctx, uniforms && (count == 0 || (pos_radius && projected_slice)) && pr_stride_vec4 >= 1);
     ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected_slice) & 15) == 0);
     return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, count, first, projected_slice, nullptr, nullptr, 0, nullptr,
-                          nullptr);
+                          nullptr, nullptr);
 }
 
 int splat_extract_keys(splat_ctx *ctx, const void *projected, uint32_t n, uint32_t n_padded, void *keys, void *payload) {

@@ -160,7 +160,7 @@ struct TfScatterShared {
 // kernels work on: the total, or 0 when it exceeds pair_limit (then nothing is written and the
 // overflow flag is raised: the frame is rendered again with room).
 template <bool RANK_ATOMIC>
-__global__ __launch_bounds__(TF_THREADS) void k_tf_scatter(const uint32_t *__restrict__ range32,
+__global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__restrict__ range32,
                                                            const uint32_t *__restrict__ depth_keys, uint32_t n, uint32_t ntx,
                                                            uint32_t mask, uint32_t num_parts,
                                                            const uint32_t *__restrict__ scanned_hist,
@@ -315,13 +315,42 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
     uint2 *src = vals + base, *dst = scratch + base;
     const bool in_lds = !LAST_CLASS || n <= TS_CAP;
 
-    // load (LDS path) and the tile's key range
+    // load (LDS path) and the tile's key range.  All of a thread's loads are issued before the first
+    // is used: one load per loop trip left every workgroup waiting out up to 23 memory latencies in a
+    // row (48 of the kernel's 76 us at C2 went there).
     uint32_t lo = 0xffffffffu, hi = 0;
-    for (uint32_t p = tid; p < n; p += TS_THREADS) {
-        const uint2 e = src[p];
-        if (in_lds) s_el[p] = e;
-        lo = min(lo, e.x);
-        hi = max(hi, e.x);
+    if (in_lds) {
+        uint2 v[TS_MAX_ITEMS];
+#pragma unroll
+        for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+            if (g * TS_THREADS < n) {
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    const uint32_t p = tid + i * TS_THREADS;
+                    v[i] = src[p < n ? p : n - 1];
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+            if (g * TS_THREADS < n) {
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    const uint32_t p = tid + i * TS_THREADS;
+                    if (p < n) {
+                        s_el[p] = v[i];
+                        lo = min(lo, v[i].x);
+                        hi = max(hi, v[i].x);
+                    }
+                }
+            }
+        }
+    } else {
+        for (uint32_t p = tid; p < n; p += TS_THREADS) {
+            const uint32_t k = src[p].x;
+            lo = min(lo, k);
+            hi = max(hi, k);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
