@@ -162,6 +162,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
     }
 }
 
+// report: host-mapped pinned words that receive {pair total, overflow flag, frame sequence number} —
+// a sync-free frame's readback with no copy and no event in the stream (hipMemcpyAsync +
+// hipEventRecord left the GPU idle for ~14 us per frame between the binner and the composite).
+__device__ __forceinline__ void tile_report(const uint32_t *d_total, uint32_t *report, uint32_t seq) {
+    report[0] = d_total[0];
+    report[1] = d_total[1];
+    __threadfence_system();
+    __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls this word
+}
+
 // Tile offsets and counts from the tile-sorted pair keys: offsets[t] = index of the first pair whose
 // tile id is >= t (the same values as the exclusive scan of the counts, TileBinner.ts:452-459).
 // One WAVE per tile does a 65-ary search: every step the 64 lanes probe 64 evenly spaced positions of
@@ -171,8 +181,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
 // before its first pair).
 __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict__ sorted_tiles, uint32_t pairs_host,
                                                       const uint32_t *__restrict__ pairs_dev, uint32_t tiles,
-                                                      uint32_t *__restrict__ offsets) {
+                                                      uint32_t *__restrict__ offsets, const uint32_t *__restrict__ d_total,
+                                                      uint32_t *report, uint32_t seq) {
     const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (report && blockIdx.x == 0 && threadIdx.x == 0) tile_report(d_total, report, seq);
     if (t > tiles) return;
     const uint32_t pairs = pairs_dev ? min(*pairs_dev, pairs_host) : pairs_host;
     uint32_t lo = 0, hi = pairs; // invariant: every pair before lo has id < t, every pair from hi on has id >= t
@@ -192,20 +204,10 @@ __global__ __launch_bounds__(256) void k_tile_offsets(const uint32_t *__restrict
     if (lane == 0) offsets[t] = first; // offsets[tiles] = pairs
 }
 
-// report (optional): host-mapped pinned words that receive {pair total, overflow flag, frame sequence
-// number} — a sync-free frame's readback with no copy and no event in the stream (hipMemcpyAsync +
-// hipEventRecord left the GPU idle for ~14 us per frame between the binner and the composite).
 __global__ __launch_bounds__(256) void k_tile_counts(const uint32_t *__restrict__ offsets, uint32_t tiles,
-                                                     uint32_t *__restrict__ counts, const uint32_t *__restrict__ d_total,
-                                                     uint32_t *report, uint32_t seq) {
+                                                     uint32_t *__restrict__ counts) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t < tiles) counts[t] = offsets[t + 1] - offsets[t];
-    if (report && t == 0) {
-        report[0] = d_total[0];
-        report[1] = d_total[1];
-        __threadfence_system();
-        __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls this word
-    }
 }
 
 // PerTileSorter's job, as a check instead of a sort (src/PerTileSorter.ts:66-122 re-sorts every tile's
@@ -343,7 +345,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
             // per 1024-splat block: its pairs per low tile-id digit (the first sort pass's histogram) and in total
             if (!hist_ready) rc = tf_hist_launch(ctx, range32, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->blocksums, b->d_total + 1);
             if (rc != SPLAT_OK) return rc;
-            rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, BIN_BLOCK));
+            rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, BIN_BLOCK), 1u << tf_lo_bits);
             if (rc != SPLAT_OK) return rc;
         } else if (range32)
             hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
@@ -352,10 +354,14 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
             hipLaunchKernelGGL(k_bin_count<false>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected,
                                nullptr, n_splats, (const uint32_t *)sorted, n_sorted, n_sorted_dev, bp, b->ranges, b->blocksums, b->d_total + 1);
         LAUNCH_CHECK(ctx, "k_bin_count");
-        rc = scan_exclusive_u32(ctx, b->blocksums, b->blocksums, blocks, b->d_total); // PrefixSumScanner.scan :296-303
-        if (rc != SPLAT_OK) return rc;
         const uint64_t want_async = (uint64_t)b->last_total + b->last_total / 8 + 4096; // 12.5 % frame-to-frame growth
         async = b->allow_async && b->have_last && b->last_total > 0 && want_async <= b->pairs.capacity;
+        // block bases + pair total (PrefixSumScanner.scan :296-303).  A sync-free tile-first frame needs
+        // neither: positions come from the digit histogram and k_tf_scatter sums the total itself.
+        if (!(tile_first && async)) {
+            rc = scan_exclusive_u32(ctx, b->blocksums, b->blocksums, blocks, b->d_total);
+            if (rc != SPLAT_OK) return rc;
+        }
         if (async) {
             b->pair_limit = (uint32_t)want_async;
             total32 = b->pair_limit; // grid bound; the real count is read on the device
@@ -393,16 +399,15 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         if (rc != SPLAT_OK) return rc;
         const uint32_t *sorted_tiles = primary ? b->pairs.keys : b->pairs.keys_b;
         hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 4)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
-                           tiles, b->offsets);
+                           tiles, b->offsets, b->d_total, async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
         LAUNCH_CHECK(ctx, "k_tile_offsets");
-        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts, b->d_total,
-                           async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
-        LAUNCH_CHECK(ctx, "k_tile_counts");
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
-        rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload);
+        // (its first launch also writes the tile counts)
+        rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
+                              b->counts);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
-        if (async) b->pending = true; // k_tile_counts reports {total, overflow, seq} into b->pinned; examined at the next call
+        if (async) b->pending = true; // k_tile_offsets reported {total, overflow, seq} into b->pinned; examined at the next call
     } else if (total32 > 0) {
         hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
                            b->ranges, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys, b->pairs.payload);
@@ -419,12 +424,11 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         if (rc != SPLAT_OK) return rc;
         const uint32_t *sorted_tiles = b->pairs.result_in_primary ? b->pairs.keys : b->pairs.keys_b;
         hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 4)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
-                           tiles, b->offsets);
+                           tiles, b->offsets, b->d_total, async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
         LAUNCH_CHECK(ctx, "k_tile_offsets");
-        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts, b->d_total,
-                           async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
+        hipLaunchKernelGGL(k_tile_counts, dim3(div_up(tiles, 256)), dim3(256), 0, ctx->stream, b->offsets, tiles, b->counts);
         LAUNCH_CHECK(ctx, "k_tile_counts");
-        if (async) b->pending = true; // k_tile_counts reports {total, overflow, seq} into b->pinned; examined at the next call
+        if (async) b->pending = true; // k_tile_offsets reported {total, overflow, seq} into b->pinned; examined at the next call
     } else {
         HIP_TRY(ctx, hipMemsetAsync(b->counts, 0, (size_t)tiles * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(b->offsets, 0, (size_t)(tiles + 1) * 4, ctx->stream));

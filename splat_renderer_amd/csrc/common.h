@@ -166,8 +166,9 @@ int tf_hist_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
                       uint2 *out_val);
-int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts); // rows -> exclusive prefixes, totals at hist + 256*parts
-int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx);
+int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
+int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
+                     uint32_t *counts);
 int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2 *v1, uint32_t *hist, uint32_t n,
                     const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, uint32_t first_bits, bool *result_in_primary);
 int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_ERR_CAPACITY if that frame overflowed

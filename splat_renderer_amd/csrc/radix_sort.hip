@@ -121,10 +121,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__
 // rowscan: block d turns row d of hist into its exclusive prefix over partitions; totals[d] = row sum
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t ROWSCAN_THREADS = 1024;
+// (rows: digits that can occur this pass, mask + 1; the rows above hold zeros already and only need a zero total)
 __global__ __launch_bounds__(ROWSCAN_THREADS) void k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t num_parts,
-                                                                   uint32_t *__restrict__ totals) {
+                                                                   uint32_t *__restrict__ totals, uint32_t rows) {
     __shared__ uint32_t wsum[ROWSCAN_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (blockIdx.x >= rows) {
+        if (tid == 0) totals[blockIdx.x] = 0;
+        return;
+    }
     uint32_t *row = hist + (size_t)blockIdx.x * num_parts;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < num_parts; base += ROWSCAN_THREADS) {
@@ -551,7 +556,7 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
                                RS_PART_KEYS, hist);
         LAUNCH_CHECK(ctx, "k_radix_upsweep");
         uint32_t *totals = hist + (size_t)256 * parts;
-        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals);
+        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals, mask + 1);
         LAUNCH_CHECK(ctx, "k_radix_rowscan");
         // iota_payload: the input payload is 0,1,2,... (fresh from the projector): the first pass
         // synthesises it instead of reading 4 B per key that the projector would have had to write
@@ -581,8 +586,8 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
     return SPLAT_OK;
 }
 
-int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts) {
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, hist + (size_t)256 * parts);
+int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows) {
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, hist + (size_t)256 * parts, rows);
     LAUNCH_CHECK(ctx, "k_radix_rowscan");
     return SPLAT_OK;
 }
@@ -615,7 +620,7 @@ int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2
                            RSW_PART_KEYS, hist);
         LAUNCH_CHECK(ctx, "k_radix_upsweep");
         uint32_t *totals = hist + (size_t)256 * parts;
-        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals);
+        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals, mask + 1);
         LAUNCH_CHECK(ctx, "k_radix_rowscan");
 #define SPLAT_DSW(IT, RA)                                                                                                    \
     hipLaunchKernelGGL((k_radix_downsweep_wide<IT, RA>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, n_dev, shift, \

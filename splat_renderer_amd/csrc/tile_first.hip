@@ -156,9 +156,9 @@ struct TfScatterShared {
     uint32_t wave_sums[TS_WAVES];
 };
 
-// d_total: [0] = pair total of this frame (scan of the block sums); [2] (out) = the count the later
-// kernels work on: the total, or 0 when it exceeds pair_limit (then nothing is written and the
-// overflow flag is raised: the frame is rendered again with room).
+// d_total (out): [0] = pair total of this frame (the sum of the digit totals); [2] = the count the
+// later kernels work on: the total, or 0 when it exceeds pair_limit (then nothing is written and
+// the overflow flag is raised: the frame is rendered again with room).
 template <bool RANK_ATOMIC>
 __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__restrict__ range32,
                                                            const uint32_t *__restrict__ depth_keys, uint32_t n, uint32_t ntx,
@@ -173,15 +173,25 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     __shared__ uint32_t s_key[TF_BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t first = blockIdx.x * TF_BLOCK;
-    const uint32_t all_pairs = d_total[0];
-    if (all_pairs > pair_limit) {
-        if (blockIdx.x == 0 && tid == 0) {
-            atomicOr(overflow, 1u);
-            d_total[2] = 0;
-        }
-        return;
+    // digit starts = exclusive scan of the digit totals; their sum is this frame's pair total
+    const uint32_t digit_total = totals[tid];
+    uint32_t gincl = digit_total;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t t = __shfl_up(gincl, s);
+        if ((int)lane >= s) gincl += t;
     }
-    if (blockIdx.x == 0 && tid == 0) d_total[2] = all_pairs;
+    if (lane == 63) sh.wave_sums[w] = gincl;
+    __syncthreads();
+    const uint32_t gprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+    const uint32_t all_pairs = sh.wave_sums[0] + sh.wave_sums[1] + sh.wave_sums[2] + sh.wave_sums[3];
+    if (blockIdx.x == 0 && tid == 0) {
+        d_total[0] = all_pairs;
+        d_total[2] = all_pairs > pair_limit ? 0u : all_pairs;
+        if (all_pairs > pair_limit) atomicOr(overflow, 1u);
+    }
+    if (all_pairs > pair_limit) return;
+    __syncthreads(); // wave_sums is reused below
 
     uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
 #pragma unroll
@@ -196,15 +206,6 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
         s_key[slot] = key;
         h[k] = range32_hits(r[k]);
     }
-    // start of this block's pairs of digit tid: digit start (scan of the digit totals) + the earlier blocks' share
-    const uint32_t digit_total = totals[tid];
-    uint32_t gincl = digit_total;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t t = __shfl_up(gincl, s);
-        if ((int)lane >= s) gincl += t;
-    }
-    if (lane == 63) sh.wave_sums[w] = gincl;
     // offsets of every splat's pairs inside the block, position-major (k, thread): ascending splat index
     uint32_t off[TF_PER_THREAD];
     uint32_t carry = 0;
@@ -225,10 +226,8 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     }
     const uint32_t total = carry;
     if (total == 0) return;
-    {
-        const uint32_t gprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
-        sh.global_base[tid] = gprefix + gincl - digit_total + scanned_hist[(size_t)tid * num_parts + blockIdx.x];
-    }
+    // where this block's pairs of digit tid start: digit start + the earlier blocks' share
+    sh.global_base[tid] = gprefix + gincl - digit_total + scanned_hist[(size_t)tid * num_parts + blockIdx.x];
     // rounds of TF_STAGE pairs (one round unless the block's splats are unusually large)
     for (uint32_t c0 = 0; c0 < total; c0 += TF_STAGE) {
         const uint32_t cnt = (total - c0 < TF_STAGE) ? total - c0 : TF_STAGE;
@@ -297,7 +296,8 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
 template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS>
 __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
                                                                                     uint32_t n_above, uint2 *vals, uint2 *scratch,
-                                                                                    uint32_t *__restrict__ out_idx) {
+                                                                                    uint32_t *__restrict__ out_idx,
+                                                                                    uint32_t *__restrict__ counts) {
     static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
     constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_LDS_ELEMS ? TS_MAX_ITEMS * TS_THREADS : TS_LDS_ELEMS;
     __shared__ TileSortShared sh;
@@ -306,6 +306,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t t = blockIdx.x;
     const uint32_t base = offsets[t], n = offsets[t + 1] - base;
+    if (counts && tid == 0) counts[t] = n; // (first launch: the tile counts the composite reads)
     if (n <= n_above || (!LAST_CLASS && n > TS_CAP)) return; // empty, or another class's tile
     if (tid == 0) {
         sh.kmin = 0xffffffffu;
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
     for (uint32_t p = tid; p < n; p += TS_THREADS) out_idx[base + p] = src[p].y;
 }
 
-int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx) {
+int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
+                     uint32_t *counts) {
     if (ctx->lds_atomic_ordered < 0) {
         uint64_t bad = 1;
         int prc = radix_probe_lds_atomic_order(ctx, &bad);
@@ -475,14 +477,14 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
     if (ctx->lds_atomic_ordered == 1) {
         hipLaunchKernelGGL((k_tile_sort<true, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
-                           scratch, out_idx);
+                           scratch, out_idx, counts);
         hipLaunchKernelGGL((k_tile_sort<true, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
-                           vals, scratch, out_idx);
+                           vals, scratch, out_idx, nullptr);
     } else {
         hipLaunchKernelGGL((k_tile_sort<false, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
-                           scratch, out_idx);
+                           scratch, out_idx, counts);
         hipLaunchKernelGGL((k_tile_sort<false, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
-                           vals, scratch, out_idx);
+                           vals, scratch, out_idx, nullptr);
     }
     LAUNCH_CHECK(ctx, "k_tile_sort");
     return SPLAT_OK;
