@@ -67,32 +67,53 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare(const float4 *__r
     if (threadIdx.x == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// Tile-first band frame: the same pass, 1024 records per block; a splat outside the band simply has
-// an empty range (no compaction, no sort of the kept splats).
+// Tile-first band frame: the same pass, 1024 records per block (the binner's block), which also counts
+// the block's pairs per low tile-id digit like k_project_hist; a splat outside the band simply has an
+// empty range (no compaction, no sort of the kept splats).
 constexpr uint32_t BTF_PER_THREAD = 4, BTF_BLOCK = BAND_THREADS * BTF_PER_THREAD;
 
 __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *__restrict__ records, uint32_t n, BinParams bp,
                                                                   uint32_t *__restrict__ keys_by_idx, uint32_t *__restrict__ range32,
-                                                                  uint32_t *__restrict__ kept_blocks) {
-    __shared__ uint32_t wsum[4];
-    uint32_t kept = 0;
+                                                                  uint32_t *__restrict__ kept_blocks, TfHistOut ho) {
+    __shared__ uint32_t lh[4][256]; // the block's pairs per low tile-id digit, as k_project_hist counts them
+    __shared__ uint32_t wsum[2][4];
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
+    for (uint32_t j = tid; j < 4 * 256; j += BAND_THREADS) (&lh[0][0])[j] = 0;
+    __syncthreads();
+    uint32_t kept = 0, pairs = 0;
 #pragma unroll
     for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
-        const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + threadIdx.x;
+        const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + tid;
         if (i < n) {
             const float4 a = records[(size_t)i * 2], b = records[(size_t)i * 2 + 1];
             uint32_t tx0, tx1, ty0, ty1;
             const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
             range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
             keys_by_idx[i] = depth_key_of(b.x);
-            kept += ok ? 1u : 0u;
+            if (ok) {
+                for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                    for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * bp.ntx + tx) & ho.mask], 1u);
+                kept += 1u;
+                pairs += (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+            }
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = kept;
+    for (int d = 32; d >= 1; d >>= 1) {
+        kept += __shfl_xor(kept, d);
+        pairs += __shfl_xor(pairs, d);
+    }
+    if ((tid & 63) == 0) {
+        wsum[0][w] = kept;
+        wsum[1][w] = pairs;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) kept_blocks[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+    if (tid == 0) {
+        kept_blocks[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+        ho.blocksums[blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
 }
 
 // compact: the kept (key, global index) pairs of block b go to [base[b], ...) in ascending index order
@@ -211,13 +232,17 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         if (n_records > sorter->capacity) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_band_frame: n_records exceeds the sorter's capacity");
         int rc = binner_reserve_range32(binner, n_records);
         if (rc != SPLAT_OK) return rc;
+        rc = binner_reserve(binner, ntx * nty, n_records);
+        if (rc != SPLAT_OK) return rc;
         const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
         const uint32_t blocks = div_up(n_records, BTF_BLOCK);
+        const TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
         hipLaunchKernelGGL(k_band_prepare_tf, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp,
-                           sorter->keys, binner->range32, sorter->hist);
+                           sorter->keys, binner->range32, sorter->hist, ho);
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
+        binner->tf_hist_ready = true;
         sorter->ran = false;
         sorter->count_pending = false;
         sorter->kept_blocks = blocks; // the kept count is summed on demand (splat_band_kept / splat_band_settle)
