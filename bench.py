@@ -172,6 +172,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
                    "pairs_P": pairs, "pairs_consumed_P_used": round(p_used), "parallelism": "1 GPU",
+                   "frame_order": os.environ.get("SPLAT_FRAME_ORDER", "tile-first (bin, then depth-sort per tile; library default)"),
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name),

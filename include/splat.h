@@ -180,9 +180,11 @@ int splat_bin_set_frame_order(splat_binner *b, int order);
 int splat_bin_dims(splat_binner *b, uint32_t *ntx, uint32_t *nty);
 
 /* ---- PerTileSorter.sort  (src/PerTileSorter.ts:66-122,174-213) --------------------------------- */
-/* The reference re-sorts every tile's list by depth in LDS (racy, capped at 2048: SURVEY I3).  The
- * binner here emits every list already in (depth key, index) order, so the stage is a CHECK: counts
- * adjacent pairs of one tile that are not strictly increasing in (depth key, splat index).
+/* The reference re-sorts every tile's list by depth in LDS (racy, capped at 2048: SURVEY I3).
+ * splat_bin_run bins an already sorted order, so its lists leave it in (depth key, index) order and
+ * for the staged API the stage is a CHECK: counts adjacent pairs of one tile that are not strictly
+ * increasing in (depth key, splat index).  (Inside splat_render_frame's tile-first order the per-tile
+ * sort is real — any list length, stable — see splat_bin_set_frame_order.)
  * tile_offsets must have num_tiles + 1 entries (as splat_bin_offsets returns).  Synchronises. */
 int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void *tile_offsets,
                               uint32_t num_tiles, const void *tile_indices, uint64_t total_pairs,

@@ -377,9 +377,12 @@ class GPUTileBinner:
 
 class PerTileSorter:
     """src/PerTileSorter.ts:6-223.  The reference's per-tile LDS sort is racy and capped at 2048
-    entries; GPUTileBinner here already emits every list in (depth key, index) order, so
-    sort() has nothing to reorder.  It keeps the reference's argument list and, with validate=True,
-    runs the order CHECK on the device and returns the number of out-of-order neighbours (0)."""
+    entries.  As a stage of the staged API it has nothing to reorder: binSplats bins an
+    already sorted order, so every list leaves GPUTileBinner in (depth key, index) order; sort() keeps
+    the reference's argument list and, with validate=True, runs the order CHECK on the device and
+    returns the number of out-of-order neighbours (0).  The real per-tile depth sort (any list length,
+    stable) lives inside the whole-frame call: Renderer.render bins in index order and sorts every
+    tile's list in LDS (csrc/tile_first.hip, k_tile_sort)."""
 
     def __init__(self, device, validate=False):
         self.device, self.validate = device, validate

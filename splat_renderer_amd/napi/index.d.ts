@@ -18,7 +18,7 @@ export class SplatProjector { constructor(device: Device, numSplats: number); pr
 export class DepthKeyExtractor { constructor(device: Device); extract(enc: CommandEncoder | null, projectedBuffer: Buffer, keysBuffer: Buffer, payloadBuffer: Buffer, numSplats: number, paddedSize: number): void; cleanupTempBuffers(): void; }
 export class RadixSorter { constructor(device: Device, numSplats: number); readonly paddedSize: number; sort(numKeys?: number, bitBegin?: number, bitEnd?: number): void; getSortedIndicesBuffer(): Buffer; getKeysBuffer(): Buffer; getPayloadBuffer(): Buffer; cleanupTempBuffers(): void; destroy(): void; }
 export class PrefixSumScanner { constructor(device: Device); scan(enc: CommandEncoder | null, inputBuffer: Buffer, outputBuffer: Buffer, numElements: number): Promise<void>; cleanupTempBuffers(): void; }
-export class GPUTileBinner { constructor(device: Device, tileSize: number); binSplats(enc: CommandEncoder | null, projectedBuffer: Buffer, sortedIndicesBuffer: Buffer, numSplats: number, screenWidth: number, screenHeight: number): Promise<void>; getTileOffsetsBuffer(): Buffer; getTileIndicesBuffer(): Buffer; getTileCountsBuffer(): Buffer; getTotalIndices(): number; getTileSize(): number; cleanupTempBuffers(): void; destroy(): void; }
+export class GPUTileBinner { constructor(device: Device, tileSize: number); setFrameOrder(order: "default" | "sortFirst" | "tileFirst"): void; binSplats(enc: CommandEncoder | null, projectedBuffer: Buffer, sortedIndicesBuffer: Buffer, numSplats: number, screenWidth: number, screenHeight: number): Promise<void>; getTileOffsetsBuffer(): Buffer; getTileIndicesBuffer(): Buffer; getTileCountsBuffer(): Buffer; getTotalIndices(): number; getTileSize(): number; cleanupTempBuffers(): void; destroy(): void; }
 export class PerTileSorter { constructor(device: Device, validate?: boolean); violations: number; sort(enc: CommandEncoder | null, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, splatIndicesBuffer: Buffer, numTiles: number, maxSplatsPerTile: number, totalPairs?: number): number | undefined; cleanupTempBuffers(): void; destroy(): void; }
 export class SequentialRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numSplats?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, splatPropertyBuffer: Buffer, sortedIndexBuffer: Buffer, curvatureBuffer: Buffer, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
 export class ComputeShaderRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean }); render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }

@@ -125,6 +125,9 @@ class GPUTileBinner {
     this.prefixSumScanner = new PrefixSumScanner(device); // :49
     this.numTiles = 0;
   }
+  // order of work of the whole-frame call: 'tileFirst' (bin in index order, PerTileSorter-style depth sort per tile;
+  // the default), 'sortFirst' (global depth sort, bin in sorted order) or 'default'; same lists either way
+  setFrameOrder(order) { native.bin_set_frame_order(this.device.ctx, this.handle, { default: -1, sortFirst: 0, tileFirst: 1 }[order]); }
   async binSplats(commandEncoder, projectedBuffer, sortedIndicesBuffer, numSplats, screenWidth, screenHeight) { // :190-338
     native.bin_run(this.device.ctx, this.handle, projectedBuffer.ptr, numSplats, sortedIndicesBuffer.ptr, numSplats, screenWidth, screenHeight, 0, U32_MAX);
     this.numTiles = Math.ceil(screenWidth / this.tileSize) * Math.ceil(screenHeight / this.tileSize);

@@ -196,6 +196,7 @@ FN(sort_run) { /* (ctx, sorter, n, bitBegin, bitEnd) */
     return check(env, x, splat_sort_run(s, n, b0, b1), mk_undefined(env));
 }
 FN(sort_set_mode) { ARGS(3); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); int m = (int)arg_number(&c, 2); BAIL; return check(env, x, splat_sort_set_mode(s, m), mk_undefined(env)); }
+FN(bin_set_frame_order) { ARGS(3); splat_ctx *x = arg_external(&c, 0); splat_binner *b = arg_external(&c, 1); int o = (int)arg_number(&c, 2); BAIL; return check(env, x, splat_bin_set_frame_order(b, o), mk_undefined(env)); }
 FN(scan_u32) {
     ARGS(5); splat_ctx *x = arg_external(&c, 0); void *in = arg_dptr(&c, 1), *out = arg_dptr(&c, 2); uint32_t n = (uint32_t)arg_number(&c, 3);
     void *tot = arg_dptr(&c, 4); BAIL;
@@ -270,7 +271,7 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(project), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
-        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame),
+        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;
