@@ -170,8 +170,7 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
 
 struct DownsweepShared {
     uint32_t wave_hist[RS_WAVES][256]; // running per-wave digit counters -> wave offsets
-    uint32_t digit_base[256];          // partition-local start of each digit run
-    uint32_t global_base[256];         // global start of this partition's run of each digit
+    uint32_t global_base[256];         // (global start of this partition's run of each digit) - (its partition-local start)
     uint32_t wave_sums[RS_WAVES];
     uint32_t wave_gsums[RS_WAVES];
 };
@@ -324,10 +323,6 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     // thread d: exclusive prefix over waves for digit d, and the partition's count of d
     uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
     uint32_t dcount = c0 + c1 + c2 + c3;
-    sh.wave_hist[0][tid] = 0;
-    sh.wave_hist[1][tid] = c0;
-    sh.wave_hist[2][tid] = c0 + c1;
-    sh.wave_hist[3][tid] = c0 + c1 + c2;
     if (ONESWEEP) row_prefix = lookback(status, part, tid, dcount, err);
     // exclusive scan of dcount over the 256 digits and, in the same shuffles, of the global digit
     // totals (start of digit d in the output)
@@ -347,8 +342,14 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     __syncthreads();
     uint32_t wprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
     uint32_t gprefix = (w > 0 ? sh.wave_gsums[0] : 0u) + (w > 1 ? sh.wave_gsums[1] : 0u) + (w > 2 ? sh.wave_gsums[2] : 0u);
-    sh.digit_base[tid] = wprefix + incl - dcount;
-    sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix;
+    // one table lookup per element in each of the two loops below instead of two: the wave prefixes
+    // absorb the digit's local start, and global_base holds (global start - local start)
+    const uint32_t local_start = wprefix + incl - dcount;
+    sh.wave_hist[0][tid] = local_start;
+    sh.wave_hist[1][tid] = local_start + c0;
+    sh.wave_hist[2][tid] = local_start + c0 + c1;
+    sh.wave_hist[3][tid] = local_start + c0 + c1 + c2;
+    sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix - local_start;
     __syncthreads();
 
     // reorder inside the partition: same-digit keys become contiguous, stable
@@ -356,7 +357,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     for (uint32_t i = 0; i < ITEMS; ++i) {
         uint32_t d = (key[i] >> shift) & mask;
         if (!FULL) d = (wbase + i * 64 < valid) ? d : 255u;
-        const uint32_t pos = sh.digit_base[d] + sh.wave_hist[w][d] + rank[i];
+        const uint32_t pos = sh.wave_hist[w][d] + rank[i];
         if constexpr (WIDE) {
             reinterpret_cast<uint32_t *>(s_kp)[pos] = key[i];
             (s_kp + PART_KEYS / 2)[pos] = pay[i];
@@ -375,13 +376,13 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
             if constexpr (WIDE) {
                 const uint32_t k = reinterpret_cast<const uint32_t *>(s_kp)[pos];
                 const uint32_t d = (k >> shift) & mask;
-                const uint32_t g = sh.global_base[d] + (pos - sh.digit_base[d]);
+                const uint32_t g = sh.global_base[d] + pos;
                 keys_out[g] = k;
                 pay_out[g] = (s_kp + PART_KEYS / 2)[pos];
             } else {
                 const uint2 kp = s_kp[pos];
                 const uint32_t d = (kp.x >> shift) & mask;
-                const uint32_t g = sh.global_base[d] + (pos - sh.digit_base[d]);
+                const uint32_t g = sh.global_base[d] + pos;
                 if (OUT_PAIRS) {
                     reinterpret_cast<uint2 *>(keys_out)[g] = kp; // one 8-byte store, 128-byte digit runs
                 } else {
