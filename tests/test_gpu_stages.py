@@ -670,3 +670,33 @@ def test_tile_first_full_size_C2(device):
     assert np.array_equal(a.readPixels(), b.readPixels())
     for o in (a, b, pbuf, nbuf):
         o.destroy()
+
+
+@pytest.mark.parametrize("order", ["tileFirst", "sortFirst"])
+def test_frame_with_nothing_on_screen_then_something(device, order):
+    """Every splat behind/outside the view: no pairs at all (empty lists, background image), on a first
+    frame and on a sync-free frame after a populated one; then the populated scene again."""
+    n, w, h = 3000, 160, 96
+    props, normals, u = make_case(n, w, h, 71, 1.0)
+    away = props.copy()
+    away[:, 0] += np.float32(500.0)  # far off to the side: every clamped box is empty
+    ref = oracle_pipeline(props, normals, u, w, h)
+    ref_away = oracle_pipeline(away, normals, u, w, h)
+    assert ref_away["indices"].shape[0] == 0 and ref["indices"].shape[0] > 0
+    want_away, _, _ = O.composite(O.MODE_FRONT_TO_BACK, True, away[:, 4:], normals, ref_away["proj"], ref_away["indices"],
+                                  ref_away["counts"], ref_away["offsets"], w, h)
+    pbuf, abuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(away), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
+    r.render(u, abuf, nbuf, None, w, h, wantFloat=True)            # first frame: empty
+    assert r.binner.getTotalIndices() == 0
+    assert not r.binner.getTileCountsBuffer().read(np.uint32).any()
+    assert np.array_equal(r.readPixelsFloat(), want_away)
+    for buf, rr in ((pbuf, ref), (pbuf, ref), (abuf, ref_away), (pbuf, ref)):
+        r.render(u, buf, nbuf, None, w, h, wantFloat=True)
+        total = rr["indices"].shape[0]
+        assert r.finish() == total
+        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), rr["counts"])
+        if total:
+            assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), rr["indices"])
+    for o in (r, pbuf, abuf, nbuf):
+        o.destroy()
