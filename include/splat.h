@@ -193,13 +193,18 @@ int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void 
 /* ---- ComputeShaderRenderer.render / TileRenderer.render  (src/ComputeShaderRenderer.ts:97-198,362-422) */
 #define SPLAT_COMPOSITE_FRONT_TO_BACK 0     /* SURVEY §8a contract 3: nearest on top (default) */
 #define SPLAT_COMPOSITE_REFERENCE_LITERAL 1 /* src/ComputeShaderRenderer.ts:175-190 as written */
+#define SPLAT_RECORDS_PROJECTED 0
+#define SPLAT_RECORDS_COMPACT 1
 typedef struct splat_composite_cfg {
     uint32_t mode;       /* SPLAT_COMPOSITE_* */
     uint32_t early_out;  /* 1 = stop a pixel at alpha >= 0.99 (reference :187-190) */
     uint32_t tile_size;  /* must equal the binner's; only 16 is implemented */
     uint32_t tile_row0;  /* render tile rows [tile_row0, tile_row1) (multi-GPU band) */
     uint32_t tile_row1;  /* UINT32_MAX = to the last row */
-    uint32_t reserved[3];
+    uint32_t record_format; /* what `projected` / `records` point at: SPLAT_RECORDS_PROJECTED (32-byte
+                             * ProjectedSplat, the reference's struct) or SPLAT_RECORDS_COMPACT (16-byte
+                             * exchange records, see splat_project_slice_compact) */
+    uint32_t reserved[2];
 } splat_composite_cfg;
 /* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
  * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;
@@ -223,6 +228,17 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
 int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
                         uint32_t pr_stride_vec4, uint32_t first, uint32_t count,
                         void *projected_slice);
+/* The multi-GPU exchange format: 16 bytes per splat, float4 {screen centre x, y, screen radius, depth}.
+ * The 32-byte ProjectedSplat is a pure function of it — bounds = centre -/+ radius * 1.5 in the
+ * projector's own operation order (src/SplatProjector.ts:119-121), originalIndex = position in the
+ * gathered array — so ranks all-gather half the bytes and splat_band_frame / splat_composite rebuild
+ * what they need bit-exactly (cfg->record_format = SPLAT_RECORDS_COMPACT).  splat_expand_compact
+ * materialises ProjectedSplat records (originalIndex = index_base + i) for callers that want them. */
+int splat_project_slice_compact(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
+                                uint32_t pr_stride_vec4, uint32_t first, uint32_t count,
+                                void *records16_slice);
+int splat_expand_compact(splat_ctx *ctx, const void *records16, uint32_t n, uint32_t index_base,
+                         void *projected);
 /* Stable compaction of the splats whose clamped tile-row range meets [tile_row0, tile_row1):
  * writes (depth key, global index) pairs in ascending index order into the sorter's input
  * buffers and the number kept to *n_kept_host (synchronises). */

@@ -123,38 +123,64 @@ static inline void to_screen(const float *u, float x, float y, float z, float *s
     *sy = ((1.0f - ny) * 0.5f) * u[21];
 }
 
+/* the projector up to the point where the record is formed: screen centre, screen radius, depth */
+static void project_centre(const float *u, const float *p, float *scx_out, float *scy_out, float *max_r_out,
+                           float *depth_out) {
+    float x = p[0], y = p[1], z = p[2], radius = p[3];
+    /* :77 depth = distance(worldPos, cameraPosition) */
+    float dx = x - u[16], dy = y - u[17], dz = z - u[18];
+    float depth = sqrtf((dx * dx + dy * dy) + dz * dz);
+    float scx, scy;
+    to_screen(u, x, y, z, &scx, &scy);
+    /* :93-113 six axis-aligned offsets, in the shader's order */
+    const float off[6][3] = {{radius, 0, 0}, {-radius, 0, 0}, {0, radius, 0},
+                             {0, -radius, 0}, {0, 0, radius}, {0, 0, -radius}};
+    float max_r = 0.0f;
+    for (int k = 0; k < 6; ++k) {
+        float ox, oy;
+        to_screen(u, x + off[k][0], y + off[k][1], z + off[k][2], &ox, &oy);
+        float ex = scx - ox, ey = scy - oy;
+        float dist = sqrtf(ex * ex + ey * ey);
+        max_r = fmaxf(max_r, dist); /* WGSL max(): NaN handling is implementation-defined;
+                                       fmaxf drops a NaN operand, the HIP kernel does the same */
+    }
+    *scx_out = scx; *scy_out = scy; *max_r_out = max_r; *depth_out = depth;
+}
+
+/* record = f(centre, radius, depth, index): :119-128 */
+static void form_record(float scx, float scy, float max_r, float depth, uint32_t idx, float *o) {
+    float padded = max_r * 1.5f; /* :119 */
+    o[0] = scx - padded; o[1] = scy - padded; /* :120 */
+    o[2] = scx + padded; o[3] = scy + padded; /* :121 */
+    o[4] = depth;
+    o[5] = max_r;
+    memcpy(&o[6], &idx, 4); /* :128 originalIndex */
+    o[7] = 0.0f;
+}
+
 void orc_project(const float uniforms[22], const float *pos_radius, size_t stride, uint32_t n,
                  float *projected) {
-    const float *u = uniforms;
     for (uint32_t i = 0; i < n; ++i) {
-        const float *p = pos_radius + (size_t)i * stride;
-        float x = p[0], y = p[1], z = p[2], radius = p[3];
-        /* :77 depth = distance(worldPos, cameraPosition) */
-        float dx = x - u[16], dy = y - u[17], dz = z - u[18];
-        float depth = sqrtf((dx * dx + dy * dy) + dz * dz);
-        float scx, scy;
-        to_screen(u, x, y, z, &scx, &scy);
-        /* :93-113 six axis-aligned offsets, in the shader's order */
-        const float off[6][3] = {{radius, 0, 0}, {-radius, 0, 0}, {0, radius, 0},
-                                 {0, -radius, 0}, {0, 0, radius}, {0, 0, -radius}};
-        float max_r = 0.0f;
-        for (int k = 0; k < 6; ++k) {
-            float ox, oy;
-            to_screen(u, x + off[k][0], y + off[k][1], z + off[k][2], &ox, &oy);
-            float ex = scx - ox, ey = scy - oy;
-            float dist = sqrtf(ex * ex + ey * ey);
-            max_r = fmaxf(max_r, dist); /* WGSL max(): NaN handling is implementation-defined;
-                                           fmaxf drops a NaN operand, the HIP kernel does the same */
-        }
-        float padded = max_r * 1.5f; /* :119 */
-        float *o = projected + (size_t)i * ORC_PROJ_FLOATS;
-        o[0] = scx - padded; o[1] = scy - padded; /* :120 */
-        o[2] = scx + padded; o[3] = scy + padded; /* :121 */
-        o[4] = depth;
-        o[5] = max_r;
-        uint32_t idx = i;
-        memcpy(&o[6], &idx, 4); /* :128 originalIndex */
-        o[7] = 0.0f;
+        float scx, scy, max_r, depth;
+        project_centre(uniforms, pos_radius + (size_t)i * stride, &scx, &scy, &max_r, &depth);
+        form_record(scx, scy, max_r, depth, i, projected + (size_t)i * ORC_PROJ_FLOATS);
+    }
+}
+
+/* The multi-GPU exchange format (no reference counterpart: the reference is single-device): 16 bytes
+ * per splat {screen centre x, y, screen radius, depth}; the 32-byte record is a pure function of it. */
+void orc_project_compact(const float uniforms[22], const float *pos_radius, size_t stride, uint32_t n,
+                         float *records16) {
+    for (uint32_t i = 0; i < n; ++i) {
+        float *o = records16 + (size_t)i * 4;
+        project_centre(uniforms, pos_radius + (size_t)i * stride, &o[0], &o[1], &o[2], &o[3]);
+    }
+}
+
+void orc_expand_compact(const float *records16, uint32_t n, uint32_t index_base, float *projected) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *c = records16 + (size_t)i * 4;
+        form_record(c[0], c[1], c[2], c[3], index_base + i, projected + (size_t)i * ORC_PROJ_FLOATS);
     }
 }
 

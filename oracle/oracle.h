@@ -48,6 +48,11 @@ void orc_camera(const float target[3], double distance, double azimuth, double e
  * interleaved buffer, 4 for a split plane). */
 void orc_project(const float uniforms[22], const float *pos_radius, size_t stride_floats,
                  uint32_t n, float *projected);
+/* multi-GPU exchange format: float4 {screen centre x, y, screen radius, depth} per splat, and its
+ * expansion to the 32-byte record (originalIndex = index_base + i) */
+void orc_project_compact(const float uniforms[22], const float *pos_radius, size_t stride_floats, uint32_t n,
+                         float *records16);
+void orc_expand_compact(const float *records16, uint32_t n, uint32_t index_base, float *projected);
 
 /* extract-depth-keys main (src/shaders/extract-depth-keys.wgsl:37-63). */
 void orc_extract_keys(const float *projected, uint32_t n, uint32_t n_padded,

@@ -36,6 +36,8 @@ def lib():
         L.orc_camera.argtypes = [fp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_double, C.c_double, fp, fp]
         L.orc_project.argtypes = [fp, fp, C.c_size_t, C.c_uint32, fp]
+        L.orc_project_compact.argtypes = [fp, fp, C.c_size_t, C.c_uint32, fp]
+        L.orc_expand_compact.argtypes = [fp, C.c_uint32, C.c_uint32, fp]
         L.orc_extract_keys.argtypes = [fp, C.c_uint32, C.c_uint32, u32p, u32p]
         L.orc_sort_pairs.argtypes = [u32p, u32p, C.c_uint32]
         L.orc_scan_exclusive.argtypes = [u32p, u32p, C.c_uint32]
@@ -103,6 +105,23 @@ def project(u, props):
     n, stride = props.shape
     out = np.zeros((n, 8), np.float32)
     lib().orc_project(_f(_c32(u)), _f(props), stride, n, _f(out))
+    return out
+
+
+def project_compact(u, props):
+    """The multi-GPU exchange records: (n,4) f32 {screen centre x, y, screen radius, depth}."""
+    props = _c32(props)
+    n, stride = props.shape
+    out = np.zeros((n, 4), np.float32)
+    lib().orc_project_compact(_f(_c32(u)), _f(props), stride, n, _f(out))
+    return out
+
+
+def expand_compact(records16, index_base=0):
+    """(n,4) exchange records -> (n,8) ProjectedSplat records with originalIndex = index_base + i."""
+    rec = _c32(records16)
+    out = np.zeros((rec.shape[0], 8), np.float32)
+    lib().orc_expand_compact(_f(rec), rec.shape[0], index_base, _f(out))
     return out
 
 

@@ -15,6 +15,7 @@ ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -
 STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2, 3, 4
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
 MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
+RECORDS_PROJECTED, RECORDS_COMPACT = 0, 1
 U32_MAX = 0xFFFFFFFF
 
 
@@ -26,7 +27,8 @@ class SplatError(RuntimeError):
 
 class CompositeCfg(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("early_out", C.c_uint32), ("tile_size", C.c_uint32),
-                ("tile_row0", C.c_uint32), ("tile_row1", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("tile_row0", C.c_uint32), ("tile_row1", C.c_uint32), ("record_format", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
 
 
 # name -> (restype, argtypes); the single source of truth checked against include/splat.h by
@@ -81,6 +83,8 @@ SIGNATURES = {
     "splat_render_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), C.POINTER(C.c_float), _vp, _vp, _u32, _u32,
                                 _u32, _vp, _vp, _vp]),
     "splat_project_slice": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
+    "splat_project_slice_compact": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
+    "splat_expand_compact": (_i, [_vp, _vp, _u32, _u32, _vp]),
     "splat_band_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "splat_band_settle": (_i, [_vp, _vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "splat_band_kept": (_i, [_vp, _vp, C.POINTER(_u32)]),

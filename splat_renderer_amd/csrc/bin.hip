@@ -508,6 +508,7 @@ void splat_bin_destroy(splat_binner *b) {
     if (b->range32) (void)hipFree(b->range32);
     if (b->wide_a) (void)hipFree(b->wide_a);
     if (b->wide_b) (void)hipFree(b->wide_b);
+    if (b->expanded) (void)hipFree(b->expanded);
     if (b->pinned) (void)hipHostFree(b->pinned);
     if (b->readback_done) (void)hipEventDestroy(b->readback_done);
     delete b;

@@ -113,6 +113,8 @@ struct splat_binner {
     uint32_t wide_cap = 0;
     uint32_t *tf_hist = nullptr;                    // tile-first path: per 1024-splat block digit histograms (first sort pass)
     int frame_order = -1;                           // splat_bin_set_frame_order
+    void *expanded = nullptr;                       // band frame: ProjectedSplat records rebuilt from compact exchange records
+    uint32_t expanded_cap = 0;
     bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
     uint64_t total = 0;
     bool ran = false;

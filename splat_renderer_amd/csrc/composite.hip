@@ -30,7 +30,8 @@ constexpr int CBATCH = 256;   // list entries staged per round
 struct CompositeParams {
     const float4 *color;  uint32_t color_stride;   // vec4(rgb, opacity)
     const float4 *normals; uint32_t normal_stride; // vec4(normal, scaleFactor)
-    const float4 *projected;                       // 2 x float4 per splat
+    const float4 *projected;                       // 2 x float4 per splat (ProjectedSplat), or 1 x float4 (compact exchange record)
+    uint32_t compact;
     const uint32_t *indices, *counts, *offsets;
     uint32_t width, height, ntx, tile_row0;
     uint32_t *out_rgba8;
@@ -71,6 +72,21 @@ __device__ __forceinline__ uint32_t span_mask16(float lo, float hi, float c0) {
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+// bounds and screen radius of splat idx.  Compact exchange records (multi-GPU frame) carry {centre x,
+// y, radius, depth}: the bounds are rebuilt exactly as the projector forms them (SplatProjector.ts:
+// 119-121) — with explicitly rounded operations, because this file is compiled with contraction on.
+__device__ __forceinline__ void fetch_record(const CompositeParams &p, uint32_t idx, float4 &bounds, float &radius) {
+    if (p.compact) {
+        const float4 c = p.projected[idx];
+        const float padded = __fmul_rn(c.z, 1.5f);
+        bounds = make_float4(__fsub_rn(c.x, padded), __fsub_rn(c.y, padded), __fadd_rn(c.x, padded), __fadd_rn(c.y, padded));
+        radius = c.z;
+    } else {
+        bounds = p.projected[(size_t)idx * 2];
+        radius = reinterpret_cast<const float *>(p.projected)[(size_t)idx * 8 + 5];
+    }
 }
 
 template <int MODE, bool EARLY_OUT>
@@ -128,8 +144,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             if (!f_ready) { // the first three batches of a tile: fetch now
                 f_idx = (tid < CBATCH && e < count) ? p.indices[off + e] : 0xffffffffu;
                 if (f_idx != 0xffffffffu) {
-                    f_b = p.projected[(size_t)f_idx * 2];
-                    f_r = reinterpret_cast<const float *>(p.projected)[(size_t)f_idx * 8 + 5];
+                    fetch_record(p, f_idx, f_b, f_r);
                     f_c = p.color[(size_t)f_idx * p.color_stride];
                     f_n = p.normals[(size_t)f_idx * p.normal_stride];
                 }
@@ -163,8 +178,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 if (n_idx_valid) { // index of batch k+1 arrived a batch ago: its gathers go out now
                     f_idx = n_idx;
                     if (f_idx != 0xffffffffu) {
-                        f_b = p.projected[(size_t)f_idx * 2];
-                        f_r = reinterpret_cast<const float *>(p.projected)[(size_t)f_idx * 8 + 5];
+                        fetch_record(p, f_idx, f_b, f_r);
                         f_c = p.color[(size_t)f_idx * p.color_stride];
                         f_n = p.normals[(size_t)f_idx * p.normal_stride];
                     }
@@ -270,6 +284,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     ARG_CHECK(ctx, cfg != nullptr);
     ARG_CHECK(ctx, cfg->tile_size == CT); // the kernel's quadrant mapping is built for 16x16 tiles
     ARG_CHECK(ctx, cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK || cfg->mode == SPLAT_COMPOSITE_REFERENCE_LITERAL);
+    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_COMPACT);
     ARG_CHECK(ctx, width >= 1 && height >= 1 && width <= 65535u * CT && height <= 65535u * CT);
     ARG_CHECK(ctx, color_opacity && normals && projected && tile_indices && tile_counts && tile_offsets);
     ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
@@ -284,6 +299,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.normals = (const float4 *)normals;
     p.normal_stride = normal_stride_vec4;
     p.projected = (const float4 *)projected;
+    p.compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
     p.indices = (const uint32_t *)tile_indices;
     p.counts = (const uint32_t *)tile_counts;
     p.offsets = (const uint32_t *)tile_offsets;

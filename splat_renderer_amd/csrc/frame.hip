@@ -72,6 +72,8 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare(const float4 *__r
 // empty range (no compaction, no sort of the kept splats).
 constexpr uint32_t BTF_PER_THREAD = 4, BTF_BLOCK = BAND_THREADS * BTF_PER_THREAD;
 
+// COMPACT: records are the 16-byte exchange records; the bounds are rebuilt as the projector forms them.
+template <bool COMPACT>
 __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *__restrict__ records, uint32_t n, BinParams bp,
                                                                   uint32_t *__restrict__ keys_by_idx, uint32_t *__restrict__ range32,
                                                                   uint32_t *__restrict__ kept_blocks, TfHistOut ho) {
@@ -86,11 +88,21 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
     for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
         const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + tid;
         if (i < n) {
-            const float4 a = records[(size_t)i * 2], b = records[(size_t)i * 2 + 1];
+            float4 a;
+            float depth;
+            if (COMPACT) {
+                const float4 c = records[i];
+                const float padded = c.z * 1.5f; // SplatProjector.ts:119-121 (this file is compiled with -ffp-contract=off)
+                a = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
+                depth = c.w;
+            } else {
+                a = records[(size_t)i * 2];
+                depth = records[(size_t)i * 2 + 1].x;
+            }
             uint32_t tx0, tx1, ty0, ty1;
             const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
             range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
-            keys_by_idx[i] = depth_key_of(b.x);
+            keys_by_idx[i] = depth_key_of(depth);
             if (ok) {
                 for (uint32_t ty = ty0; ty <= ty1; ++ty)
                     for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * bp.ntx + tx) & ho.mask], 1u);
@@ -226,6 +238,26 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (row0 > row1) row0 = row1;
     const uint32_t ntx = div_up(width, tile);
     const bool fast = ntx <= 256 && nty <= 256 && n_records > 0;
+    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_COMPACT);
+    const bool compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
+    ARG_CHECK(ctx, ((uintptr_t)records & 15) == 0);
+    if (compact && n_records > 0 && !(fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST)) {
+        // the other orders of work read ProjectedSplat records: rebuild them once (bit-exact) and go on
+        if (n_records > binner->expanded_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (binner->expanded) (void)hipFree(binner->expanded);
+            binner->expanded = nullptr;
+            binner->expanded_cap = 0;
+            if (hipMalloc(&binner->expanded, (size_t)n_records * 32 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "band frame hipMalloc");
+            binner->expanded_cap = n_records;
+        }
+        int rc = splat_expand_compact(ctx, records, n_records, 0, binner->expanded);
+        if (rc != SPLAT_OK) return rc;
+        splat_composite_cfg c2 = *cfg;
+        c2.record_format = SPLAT_RECORDS_PROJECTED;
+        return splat_band_frame(ctx, sorter, binner, &c2, props, normals, binner->expanded, n_records, width, height, out_rgba8,
+                                out_rgba32f, consumed_dptr);
+    }
     if (fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST) {
         // tile-first: one pass over the records (keys, band-clamped ranges, pair counts), then the
         // binner in index order — a splat outside the band has an empty range and costs nothing more
@@ -238,8 +270,12 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         const uint32_t blocks = div_up(n_records, BTF_BLOCK);
         const TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
-        hipLaunchKernelGGL(k_band_prepare_tf, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp,
-                           sorter->keys, binner->range32, sorter->hist, ho);
+        if (compact)
+            hipLaunchKernelGGL(k_band_prepare_tf<true>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records,
+                               bp, sorter->keys, binner->range32, sorter->hist, ho);
+        else
+            hipLaunchKernelGGL(k_band_prepare_tf<false>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records,
+                               bp, sorter->keys, binner->range32, sorter->hist, ho);
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
         binner->tf_hist_ready = true;

@@ -34,13 +34,8 @@ __device__ __forceinline__ uint32_t depth_key(float depth) {
     return bits ^ mask;
 }
 
-// One splat: record, key, payload, packed tile range.  Returns the packed range (1 = empty).
-template <bool WITH_KEYS, bool WITH_RANGE>
-__device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
-                                                uint32_t i, uint32_t index_base, float4 *__restrict__ projected,
-                                                uint32_t *__restrict__ keys, uint32_t *__restrict__ payload,
-                                                uint32_t *__restrict__ range32, const BinParams &bp) {
-    float4 pr = pos_radius[(size_t)i * stride_vec4];
+// The projector up to the point where the record is formed: screen centre, screen radius, depth.
+__device__ __forceinline__ float4 project_centre(const FrameUniforms &u, float4 pr) {
     float x = pr.x, y = pr.y, z = pr.z, radius = pr.w;
     float dx = x - u.eye[0], dy = y - u.eye[1], dz = z - u.eye[2];
     float depth = sqrtf((dx * dx + dy * dy) + dz * dz); // SplatProjector.ts:77
@@ -57,6 +52,17 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const fl
         float ex = scx - sx, ey = scy - sy;
         max_r = fmaxf(max_r, sqrtf(ex * ex + ey * ey));
     }
+    return make_float4(scx, scy, max_r, depth);
+}
+
+// One splat: record, key, payload, packed tile range.  Returns the packed range (1 = empty).
+template <bool WITH_KEYS, bool WITH_RANGE>
+__device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                uint32_t i, uint32_t index_base, float4 *__restrict__ projected,
+                                                uint32_t *__restrict__ keys, uint32_t *__restrict__ payload,
+                                                uint32_t *__restrict__ range32, const BinParams &bp) {
+    const float4 c = project_centre(u, pos_radius[(size_t)i * stride_vec4]);
+    const float scx = c.x, scy = c.y, max_r = c.z, depth = c.w;
     float padded = max_r * 1.5f; // :119
     float4 a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
     float4 b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
@@ -74,6 +80,26 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const fl
         range32[i] = packed;
     }
     return packed;
+}
+
+// Multi-GPU exchange records (no reference counterpart): 16 bytes per splat, float4 {screen
+// centre x, y, screen radius, depth}.  The 32-byte ProjectedSplat is a pure function of it (bounds =
+// centre -/+ radius * 1.5 in this file's operation order, originalIndex = position in the gathered
+// array), so the ranks exchange half the bytes and rebuild records bit-exactly where they need them.
+__global__ __launch_bounds__(256) void k_project_compact(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                         uint32_t n, float4 *__restrict__ records16) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) records16[i] = project_centre(u, pos_radius[(size_t)i * stride_vec4]);
+}
+
+__global__ __launch_bounds__(256) void k_expand_compact(const float4 *__restrict__ records16, uint32_t n, uint32_t index_base,
+                                                        float4 *__restrict__ projected) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = records16[i];
+    const float padded = c.z * 1.5f;
+    projected[(size_t)i * 2] = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
+    projected[(size_t)i * 2 + 1] = make_float4(c.w, c.z, __uint_as_float(index_base + i), 0.0f);
 }
 
 template <bool WITH_KEYS, bool WITH_RANGE>
@@ -204,6 +230,39 @@ int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_r
     ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected_slice) & 15) == 0);
     return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, count, first, projected_slice, nullptr, nullptr, 0, nullptr,
                           nullptr, nullptr);
+}
+
+static void load_uniforms(FrameUniforms &u, const float *uniforms) {
+    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
+    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
+    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
+}
+
+int splat_project_slice_compact(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4,
+                                uint32_t first, uint32_t count, void *records16_slice) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, uniforms && (count == 0 || (pos_radius && records16_slice)) && pr_stride_vec4 >= 1);
+    ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)records16_slice) & 15) == 0);
+    if (count == 0) return SPLAT_OK;
+    FrameUniforms u;
+    load_uniforms(u, uniforms);
+    stage_begin(ctx, SPLAT_STAGE_PROJECT);
+    hipLaunchKernelGGL(k_project_compact, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream, u,
+                       (const float4 *)pos_radius + (size_t)first * pr_stride_vec4, pr_stride_vec4, count, (float4 *)records16_slice);
+    LAUNCH_CHECK(ctx, "k_project_compact");
+    stage_end(ctx, SPLAT_STAGE_PROJECT);
+    return SPLAT_OK;
+}
+
+int splat_expand_compact(splat_ctx *ctx, const void *records16, uint32_t n, uint32_t index_base, void *projected) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, n == 0 || (records16 && projected));
+    ARG_CHECK(ctx, (((uintptr_t)records16 | (uintptr_t)projected) & 15) == 0);
+    if (n == 0) return SPLAT_OK;
+    hipLaunchKernelGGL(k_expand_compact, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (const float4 *)records16, n, index_base,
+                       (float4 *)projected);
+    LAUNCH_CHECK(ctx, "k_expand_compact");
+    return SPLAT_OK;
 }
 
 int splat_extract_keys(splat_ctx *ctx, const void *projected, uint32_t n, uint32_t n_padded, void *keys, void *payload) {

@@ -3,11 +3,13 @@
 The reference is single-device (no collective anywhere), so this module has no
 reference counterpart; it composes the same C-ABI stages:
 
-    rank r:  project splats [r*per, (r+1)*per)            splat_project_slice
-             all-gather the 32-byte ProjectedSplat shards  <- the frame's only exchange (RCCL/xGMI)
-             keep splats whose tile rows meet my band     splat_band_keys  (stable compaction)
-             sort kept (depth key, global index) pairs    splat_sort_run
-             bin + composite my tile rows only            splat_bin_run / splat_composite
+    rank r:  project splats [r*per, (r+1)*per)            splat_project_slice_compact
+             all-gather the 16-byte exchange records       <- the frame's only exchange (RCCL/xGMI)
+             my band's frame from the gathered records     splat_band_frame (record_format = COMPACT)
+
+The exchange record is float4 {screen centre x, y, screen radius, depth}: the 32-byte ProjectedSplat is a
+pure function of it and of the record's position in the gathered array (= global splat index), so half
+the bytes cross xGMI and every rank rebuilds bounds bit-exactly where it needs them.
 
 Per-tile lists are the global stable order restricted to the tile, so the stitched image is
 bit-identical to the single-GPU frame (tests/test_gpu_stages.py::test_band_rendering... on one GPU,
@@ -25,7 +27,7 @@ from . import _lib
 from ._lib import CompositeCfg, check
 
 TILE = 16
-REC_FLOATS = 8
+REC_FLOATS = 4  # exchange record: centre x, centre y, screen radius, depth
 
 
 def shard_size(n, world):
@@ -122,14 +124,14 @@ class HipStages:
 
     def project_slice(self, uniforms, props_ptr, first, count, out_records):
         u = np.ascontiguousarray(uniforms, np.float32)
-        check(self.lib.splat_project_slice(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
-                                           out_records.data_ptr()), self.ctx)
+        check(self.lib.splat_project_slice_compact(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
+                                                   out_records.data_ptr()), self.ctx)
 
     def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False):
         """settle=False (frame loops): sync-free; a frame whose pairs outgrew 1.5x the previous frame's
         is only noticed at the next call (which then has room).  settle=True: wait for this frame's pair
         total and render it again if it overflowed — results are final on return."""
-        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1)
+        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1, _lib.RECORDS_COMPACT)
         args = (self.ctx, self.sorter, self.binner, C.byref(cfg), props_ptr, normals_ptr, records.data_ptr(), n_records,
                 self.width, self.height, out_image.data_ptr(), None,
                 self.consumed.data_ptr() if self.consumed is not None else None)
@@ -174,7 +176,7 @@ class BandRenderer:
         self.nty = -(-height // tile)
         self.row0, self.row1 = band_rows(self.nty, rank, world)
         self.all_gather = all_gather
-        # shard padding (indices >= n) is NaN-bounded once: NaN bins nowhere and never changes
+        # shard padding (indices >= n) is all-NaN once: NaN bins nowhere and never changes
         self.shard = stages.new_records(self.per, fill_nan=True)
         self.gathered = stages.new_records(self.per * world) if world > 1 else self.shard
         self.image = stages.new_image()

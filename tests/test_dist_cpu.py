@@ -27,7 +27,7 @@ class OracleStages:
         self.kept = 0
 
     def new_records(self, count, fill_nan=False):
-        t = torch.zeros((count, 8), dtype=torch.float32)
+        t = torch.zeros((count, 4), dtype=torch.float32)  # the 16-byte exchange records
         if fill_nan:
             t.fill_(float("nan"))
         return t
@@ -36,12 +36,10 @@ class OracleStages:
         return torch.zeros((self.height, self.width, 4), dtype=torch.uint8)
 
     def project_slice(self, uniforms, props, first, count, out_records):
-        rec = O.project(uniforms, props[first:first + count])
-        rec[:, 6] = np.arange(first, first + count, dtype=np.uint32).view(np.float32)  # global originalIndex
-        out_records[:count] = torch.from_numpy(rec)
+        out_records[:count] = torch.from_numpy(O.project_compact(uniforms, props[first:first + count]))
 
     def band_frame(self, records, n_records, props, normals, row0, row1, out_image, settle=False):
-        rec = records.numpy()
+        rec = O.expand_compact(records.numpy())  # ProjectedSplat records, originalIndex = position = global index
         ntx, nty = -(-self.width // self.tile), -(-self.height // self.tile)
         # splat_band_keys: keep splats whose clamped tile rows meet [row0,row1), ascending index
         keep = []

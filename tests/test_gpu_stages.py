@@ -3,11 +3,14 @@
 Bit-exact: ProjectedSplat records, keys, payload, sort order, scan, tile counts/offsets/lists.
 Tolerance (stated below): composited pixels.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import splat_renderer_amd as sr
 from oracle import oracle as O
+from splat_renderer_amd import _lib
 from tests.helpers import make_case, oracle_pipeline
 
 pytestmark = pytest.mark.gpu
@@ -699,4 +702,62 @@ def test_frame_with_nothing_on_screen_then_something(device, order):
         if total:
             assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), rr["indices"])
     for o in (r, pbuf, abuf, nbuf):
+        o.destroy()
+
+
+def test_compact_exchange_records_rebuild_projected_records_bit_exactly(device):
+    """The multi-GPU exchange format (16 B: centre, radius, depth) against the oracle, and its expansion
+    against the projector's own 32-byte records — bit for bit, including originalIndex."""
+    n, w, h = 20000, 250, 130
+    props, normals, u = make_case(n, w, h, 9, 1.0)
+    want16 = O.project_compact(u, props)
+    want32 = O.project(u, props)
+    assert np.array_equal(O.expand_compact(want16).view(np.uint32), want32.view(np.uint32))
+    lib, ctx = device.lib, device.ctx
+    pbuf = device.createBufferFrom(props)
+    first, count = 777, 15000
+    rec16 = device.createBuffer(count * 16)
+    rec32 = device.createBuffer(count * 32)
+    uf = np.ascontiguousarray(u, np.float32)
+    _lib.check(lib.splat_project_slice_compact(ctx, uf.ctypes.data_as(C.POINTER(C.c_float)), pbuf.ptr, 2, first, count, rec16.ptr), ctx)
+    got16 = rec16.read(np.float32).reshape(count, 4)
+    assert np.array_equal(got16.view(np.uint32), want16[first:first + count].view(np.uint32))
+    _lib.check(lib.splat_expand_compact(ctx, rec16.ptr, count, first, rec32.ptr), ctx)
+    got32 = rec32.read(np.float32).reshape(count, 8)
+    assert np.array_equal(got32.view(np.uint32), want32[first:first + count].view(np.uint32))
+    for o in (pbuf, rec16, rec32):
+        o.destroy()
+
+
+@pytest.mark.parametrize("order", ["tileFirst", "sortFirst"])
+def test_band_frame_from_compact_records_matches_frame_from_projected_records(device, order):
+    """splat_band_frame fed the 16-byte records (what the ranks all-gather) and fed the 32-byte records
+    must give the same lists and the same float image, in either order of work."""
+    n, w, h = 30000, 320, 208
+    props, normals, u = make_case(n, w, h, 13, 1.5)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    lib, ctx = device.lib, device.ctx
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    rec16, rec32 = device.createBuffer(n * 16), device.createBuffer(n * 32)
+    uf = np.ascontiguousarray(u, np.float32)
+    up = uf.ctypes.data_as(C.POINTER(C.c_float))
+    _lib.check(lib.splat_project_slice_compact(ctx, up, pbuf.ptr, 2, 0, n, rec16.ptr), ctx)
+    _lib.check(lib.splat_project_slice(ctx, up, pbuf.ptr, 2, 0, n, rec32.ptr), ctx)
+    images = []
+    for fmt, rec in ((_lib.RECORDS_COMPACT, rec16), (_lib.RECORDS_PROJECTED, rec32)):
+        sorter, binner = sr.RadixSorter(device, n), sr.GPUTileBinner(device, 16)
+        binner.setFrameOrder(order)
+        out = device.createBuffer(w * h * 16)
+        cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, fmt)
+        _lib.check(lib.splat_band_frame(ctx, sorter._s, binner._b, C.byref(cfg), pbuf.ptr, nbuf.ptr, rec.ptr, n, w, h, None, out.ptr,
+                                        None), ctx)
+        binner._tiles = -(-w // 16) * -(-h // 16)
+        total = ref["indices"].shape[0]
+        assert binner.getTotalIndices() == total
+        assert np.array_equal(binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+        images.append(out.read(np.float32).reshape(h, w, 4).copy())
+        for o in (sorter, binner, out):
+            o.destroy()
+    assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+    for o in (pbuf, nbuf, rec16, rec32):
         o.destroy()

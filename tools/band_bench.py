@@ -47,5 +47,5 @@ for world in worlds:
         torch.cuda.synchronize()
         out.append(((time.perf_counter() - t0) / K * 1e3, r1 - r0, st.kept))
     print(f"{name} G={world}: per-rank ms (rows, kept): " + "  ".join(f"{t:.3f} ({rr},{k})" for t, rr, k in out)
-          + f"   max {max(t for t, _, _ in out):.3f} ms  [+ all-gather of {per * 32 / 1e6:.0f} MB shards]")
+          + f"   max {max(t for t, _, _ in out):.3f} ms  [+ all-gather of {per * 16 / 1e6:.0f} MB shards]")
     st.destroy()
