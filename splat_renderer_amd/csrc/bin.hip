@@ -450,9 +450,14 @@ int binner_settle(splat_binner *b) {
     volatile uint32_t *rep = (volatile uint32_t *)b->pinned;
     for (uint32_t spins = 0; rep[2] != b->seq; ++spins) {
         if (spins < 64) continue;
-        if (hipStreamQuery(ctx->stream) == hipSuccess) { // everything launched has finished
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) { // everything launched has finished
             if (rep[2] != b->seq) return ctx_fail(ctx, SPLAT_ERR_STATE, "binner: the pair-total report of the previous frame never arrived");
             break;
+        }
+        if (q != hipErrorNotReady) { // the stream is in error: the report will never come, do not spin on it
+            b->have_last = false;
+            return ctx_fail(ctx, SPLAT_ERR_HIP, "binner: waiting for the previous frame's pair total", q);
         }
         sched_yield();
     }

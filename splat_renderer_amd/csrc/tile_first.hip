@@ -193,25 +193,32 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     if (all_pairs > pair_limit) return;
     __syncthreads(); // wave_sums is reused below
 
+    // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
+    static_assert(TF_PER_THREAD == 4, "uint4 loads");
     uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
-#pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        const uint32_t slot = k * TF_THREADS + tid, i = first + slot;
-        r[k] = 1u; // empty
-        uint32_t key = 0;
-        if (i < n) {
-            r[k] = range32[i];
-            key = depth_keys[i];
+    {
+        const uint32_t i0 = first + tid * 4;
+        uint4 rr = make_uint4(1u, 1u, 1u, 1u), kk = make_uint4(0, 0, 0, 0); // 1 = empty range
+        if (i0 + 3 < n) {
+            rr = reinterpret_cast<const uint4 *>(range32)[i0 >> 2];
+            kk = reinterpret_cast<const uint4 *>(depth_keys)[i0 >> 2];
+        } else {
+            if (i0 < n) { rr.x = range32[i0]; kk.x = depth_keys[i0]; }
+            if (i0 + 1 < n) { rr.y = range32[i0 + 1]; kk.y = depth_keys[i0 + 1]; }
+            if (i0 + 2 < n) { rr.z = range32[i0 + 2]; kk.z = depth_keys[i0 + 2]; }
         }
-        s_key[slot] = key;
-        h[k] = range32_hits(r[k]);
-    }
-    // offsets of every splat's pairs inside the block, position-major (k, thread): ascending splat index
-    uint32_t off[TF_PER_THREAD];
-    uint32_t carry = 0;
+        reinterpret_cast<uint4 *>(s_key)[tid] = kk;
+        r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
 #pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        uint32_t incl = h[k];
+        for (uint32_t k = 0; k < TF_PER_THREAD; ++k) h[k] = range32_hits(r[k]);
+    }
+    // offsets of every splat's pairs inside the block, in ascending splat index: one block scan of the
+    // per-thread totals, then the thread's own running sum
+    uint32_t off[TF_PER_THREAD];
+    uint32_t carry;
+    {
+        const uint32_t mine = (h[0] + h[1]) + (h[2] + h[3]);
+        uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(incl, d);
@@ -220,9 +227,11 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
         const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
-        __syncthreads();
-        off[k] = carry + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - h[k];
-        carry += s0 + s1 + s2 + s3;
+        off[0] = (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - mine;
+        off[1] = off[0] + h[0];
+        off[2] = off[1] + h[1];
+        off[3] = off[2] + h[2];
+        carry = s0 + s1 + s2 + s3;
     }
     const uint32_t total = carry;
     if (total == 0) return;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
         for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
             if (h[k] == 0 || off[k] >= c0 + TF_STAGE || off[k] + h[k] <= c0) continue;
             const uint32_t tx0 = r[k] & 0xffu, tx1 = (r[k] >> 8) & 0xffu, ty0 = (r[k] >> 16) & 0xffu, ty1 = r[k] >> 24;
-            const uint32_t slot = k * TF_THREADS + tid;
+            const uint32_t slot = tid * TF_PER_THREAD + k;
             uint32_t o = off[k] - c0; // may wrap below zero for pairs of an earlier round: the range check rejects them
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
             out_tile[g] = e >> 10;
             out_val[g] = make_uint2(s_key[slot], first + slot);
         }
+        if (c0 + TF_STAGE >= total) break; // (the usual case: one round)
         __syncthreads();
         sh.global_base[tid] += dcount; // the next round's pairs of digit tid follow this round's
         __syncthreads();
