@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
         wsum[1][w] = pairs;
     }
     __syncthreads();
-    ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+    if (tid <= ho.mask) ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
     if (tid == 0) {
         kept_blocks[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
         ho.blocksums[blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
     if ((tid & 63) == 0) wsum[w] = local;
     __syncthreads();
     if (blockIdx.x < ho.num_parts) { // (blocks that only pad keys past n have no histogram column)
-        ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+        if (tid <= ho.mask) ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
         if (tid == 0) ho.blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__
     const uint32_t n = sort_count(n_host, n_dev);
     const uint32_t base = blockIdx.x * part_keys; // multiple of 256 keys = 1 KiB: uint4 loads stay aligned
     if (base >= n) { // partition past the end (device-side n): an all-zero column
-        hist[(size_t)tid * num_parts + blockIdx.x] = 0;
+        if (tid <= mask) hist[(size_t)tid * num_parts + blockIdx.x] = 0;
         return;
     }
     for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__
             atomicAdd(&lh[w][(keys[IN_PAIRS ? (size_t)i * 2 : (size_t)i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    uint32_t c = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
-    hist[(size_t)tid * num_parts + blockIdx.x] = c;
+    // (rows above the mask are never read: a 4-byte store per row is a 64-byte line at the memory side)
+    if (tid <= mask) hist[(size_t)tid * num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,7 +237,8 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     if (!ONESWEEP) // (onesweep: zeroed by the caller before its ticket barrier)
         for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
     // rowscan mode: digit tid in earlier partitions; onesweep mode: found by look-back below
-    uint32_t row_prefix = ONESWEEP ? 0u : scanned_hist[(size_t)tid * num_parts + part];
+    // (digits above the mask do not occur: their rows are neither written nor read)
+    uint32_t row_prefix = (ONESWEEP || tid > mask) ? 0u : scanned_hist[(size_t)tid * num_parts + part];
     const uint32_t digit_total = totals[tid]; // global count of digit tid (this pass)
 
     // striped load: item i of lane l of wave w is element w*WAVE_KEYS + i*64 + l (position order =
@@ -280,7 +281,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     // partition's digit counts before it starts (upsweep): pick per workgroup.
     bool use_atomic = RANK_ATOMIC;
     if (RANK_ATOMIC && !ONESWEEP) {
-        const uint32_t next = (part + 1 < num_parts) ? scanned_hist[(size_t)tid * num_parts + part + 1] : digit_total;
+        const uint32_t next = tid > mask ? 0u : (part + 1 < num_parts) ? scanned_hist[(size_t)tid * num_parts + part + 1] : digit_total;
         use_atomic = !__syncthreads_or((next - row_prefix) > PART_KEYS / 4); // some digit holds > 25 % of the partition
     }
     if (use_atomic) {

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_hist(const uint32_t *__restri
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
     if ((tid & 63) == 0) wsum[w] = local;
     __syncthreads();
-    hist[(size_t)tid * num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+    if (tid <= mask) hist[(size_t)tid * num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
     if (tid == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     const uint32_t total = carry;
     if (total == 0) return;
     // where this block's pairs of digit tid start: digit start + the earlier blocks' share
-    sh.global_base[tid] = gprefix + gincl - digit_total + scanned_hist[(size_t)tid * num_parts + blockIdx.x];
+    sh.global_base[tid] = gprefix + gincl - digit_total + (tid <= mask ? scanned_hist[(size_t)tid * num_parts + blockIdx.x] : 0u);
     // rounds of TF_STAGE pairs (one round unless the block's splats are unusually large)
     for (uint32_t c0 = 0; c0 < total; c0 += TF_STAGE) {
         const uint32_t cnt = (total - c0 < TF_STAGE) ? total - c0 : TF_STAGE;
