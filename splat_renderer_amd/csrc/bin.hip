@@ -336,15 +336,14 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     const uint32_t tf_bits = tile_id_bits(tiles), tf_lo_bits = tile_id_low_bits(tiles);
     const bool hist_ready = b->tf_hist_ready;
     b->tf_hist_ready = false;
+    ARG_CHECK(ctx, !tile_first || hist_ready); // the caller's projector / band prepare has counted the first pass's histogram
 
     stage_begin(ctx, SPLAT_STAGE_BIN);
     uint32_t total32 = 0;
     bool async = false;
     if (n_sorted > 0) {
         if (tile_first) {
-            // per 1024-splat block: its pairs per low tile-id digit (the first sort pass's histogram) and in total
-            if (!hist_ready) rc = tf_hist_launch(ctx, range32, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->blocksums, b->d_total + 1);
-            if (rc != SPLAT_OK) return rc;
+            // (tf_hist: per 1024-splat block its pairs per low tile-id digit, the first sort pass's histogram)
             rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, BIN_BLOCK), 1u << tf_lo_bits);
             if (rc != SPLAT_OK) return rc;
         } else if (range32)

@@ -163,8 +163,6 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
                const uint32_t *n_sorted_dev = nullptr, const uint32_t *depth_keys = nullptr);
 int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-tile and per-position buffers
 // tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
-int tf_hist_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t ntx, uint32_t mask, uint32_t *hist,
-                   uint32_t *blocksums, uint32_t *overflow_flag);
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
                       uint2 *out_val);

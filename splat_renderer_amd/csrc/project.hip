@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
 
 // Tile-first frame path: 1024 splats per workgroup (the binner's block), and while each splat's tile
 // rectangle is in registers the block's pairs are counted per low tile-id digit — the histogram the
-// first pass of the tile-id sort needs (tile_first.hip, k_tf_hist does the same from range32 when the
-// ranges come from elsewhere).  The kernel is HBM-bound; the LDS counting hides under the stores.
+// first pass of the tile-id sort needs (tile_first.hip; k_band_prepare_tf in frame.hip does the same for
+// the gathered records of a multi-GPU band).  The kernel is HBM-bound; the LDS counting hides under the stores.
 __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                       uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,

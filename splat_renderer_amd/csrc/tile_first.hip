@@ -13,10 +13,10 @@
 // through the 2-pass tile-id sort, and the depth order is established inside each tile by one
 // workgroup sorting a few thousand elements in LDS.
 //
-//   k_tf_count      pairs per 1024-index block                     N*4 B read
-//   (scan)          block bases + pair total (device side)
-//   k_tf_expand     (tile id) + (key, index) per pair              N*8 B read, P*12 B written
-//   radix_sort_wide stable by tile id, 2 passes                    P*(4 + 12 + 12) B per pass
+//   (projector)     per 1024-splat block: pairs per low tile-id digit (first-pass histogram)
+//   k_radix_rowscan digit rows -> block bases, digit totals
+//   k_tf_scatter    expansion fused with the first sort pass      N*8 B read, P*12 B written
+//   radix_sort_wide second (high digit) pass, 8-byte payload      P*(4 + 12 + 12) B
 //   k_tile_offsets / k_tile_counts
 //   k_tile_sort     per tile: LSD radix on (key - tile min key)    P*8 B read, P*4 B written
 #include "common.h"
@@ -110,43 +110,15 @@ __device__ __forceinline__ uint32_t ts_scan256(uint32_t *wave_sums, uint32_t v, 
 
 // ---------------------------------------------------------------------------------------------
 // The pairs are never written in expansion order: a 1024-splat block IS a partition of the tile-id
-// sort's first pass.  k_tf_hist counts the block's pairs per low tile-id digit (the upsweep's
-// histogram, straight from the ranges); k_tf_scatter expands the block into LDS, ranks the pairs by
+// sort's first pass.  The projector (project.hip: k_project_hist; frame.hip: k_band_prepare_tf for a
+// multi-GPU band) counts the block's pairs per low tile-id digit while the tile rectangle is in
+// registers (the upsweep's histogram); k_tf_scatter expands the block into LDS, ranks the pairs by
 // that digit and scatters (tile id | depth key, index) to their first-pass positions (the downsweep).
 // Saved per frame: the expanded array's write and two reads (12 + 4 + 12 B per pair).
 //
 // Order inside a block: ascending splat index, then row-major over the splat's tile rectangle; the
 // stable passes keep it inside each tile, so equal depth keys still resolve by ascending index.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TF_THREADS) void k_tf_hist(const uint32_t *__restrict__ range32, uint32_t n, uint32_t ntx,
-                                                        uint32_t mask, uint32_t num_parts, uint32_t *__restrict__ hist,
-                                                        uint32_t *__restrict__ blocksums, uint32_t *__restrict__ overflow_flag) {
-    __shared__ uint32_t lh[4][256];
-    __shared__ uint32_t wsum[4];
-    const uint32_t tid = threadIdx.x, w = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) *overflow_flag = 0; // set by k_tf_scatter of this frame if the pairs do not fit
-    for (uint32_t i = tid; i < 4 * 256; i += TF_THREADS) (&lh[0][0])[i] = 0;
-    __syncthreads();
-    uint32_t local = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) {
-        const uint32_t i = blockIdx.x * TF_BLOCK + k * TF_THREADS + tid;
-        if (i >= n) continue;
-        const uint32_t r = range32[i];
-        const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
-        if (tx0 > tx1 || ty0 > ty1) continue;
-        for (uint32_t ty = ty0; ty <= ty1; ++ty)
-            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * ntx + tx) & mask], 1u);
-        local += (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
-    if ((tid & 63) == 0) wsum[w] = local;
-    __syncthreads();
-    if (tid <= mask) hist[(size_t)tid * num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
-    if (tid == 0) blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
 constexpr uint32_t TFS_ITEMS = TF_STAGE / TF_THREADS; // 16 staged pairs per thread and round
 
 struct TfScatterShared {
@@ -500,16 +472,8 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     return SPLAT_OK;
 }
 
-int tf_hist_launch(splat_ctx *ctx, const uint32_t *range32, uint32_t n, uint32_t ntx, uint32_t mask, uint32_t *hist,
-                   uint32_t *blocksums, uint32_t *overflow_flag) {
-    const uint32_t parts = div_up(n, TF_BLOCK);
-    hipLaunchKernelGGL(k_tf_hist, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, n, ntx, mask, parts, hist, blocksums,
-                       overflow_flag);
-    LAUNCH_CHECK(ctx, "k_tf_hist");
-    return SPLAT_OK;
-}
-
-// hist: k_tf_hist's output after radix_rowscan_launch (rows scanned in place, digit totals behind them)
+// hist: the digit histogram the projector (k_project_hist) or the band prepare kernel counted, after
+// radix_rowscan_launch (rows scanned in place, digit totals behind them)
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
                       uint2 *out_val) {
