@@ -40,6 +40,7 @@ int ctx_ensure_scan_ws(splat_ctx *ctx, size_t bytes);
 int ctx_ensure_pinned(splat_ctx *ctx, size_t bytes);
 void stage_begin(splat_ctx *ctx, int stage);
 void stage_end(splat_ctx *ctx, int stage);
+bool stage_event_pair(splat_ctx *ctx, int stage, hipEvent_t *start, hipEvent_t *stop);
 
 #define HIP_TRY(ctx, expr)                                                   \
     do {                                                                     \

@@ -24,6 +24,8 @@
 // Compiled with -ffp-contract=fast; compared with the oracle within a stated tolerance.
 #include "common.h"
 
+#include <hip/hip_ext.h>
+
 constexpr int CT = 16;        // tile edge (pixels)
 constexpr int CBATCH = 256;   // list entries staged per round
 
@@ -311,16 +313,23 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.out_rgba32f = (float4 *)out_rgba32f;
     p.consumed = (unsigned long long *)consumed_dptr;
     dim3 grid(ntx, r1 - r0), block(256);
-    stage_begin(ctx, SPLAT_STAGE_COMPOSITE);
     const bool eo = cfg->early_out != 0;
+    // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool timed = stage_event_pair(ctx, SPLAT_STAGE_COMPOSITE, &ev0, &ev1);
+#define SPLAT_COMPOSITE_LAUNCH(MODE, EO)                                                                       \
+    do {                                                                                                       \
+        if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
+        else hipLaunchKernelGGL((k_composite<MODE, EO>), grid, block, 0, ctx->stream, p);                     \
+    } while (0)
     if (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
-        if (eo) hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_FRONT_TO_BACK, true>), grid, block, 0, ctx->stream, p);
-        else    hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_FRONT_TO_BACK, false>), grid, block, 0, ctx->stream, p);
+        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true);
+        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false);
     } else {
-        if (eo) hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_REFERENCE_LITERAL, true>), grid, block, 0, ctx->stream, p);
-        else    hipLaunchKernelGGL((k_composite<SPLAT_COMPOSITE_REFERENCE_LITERAL, false>), grid, block, 0, ctx->stream, p);
+        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, true);
+        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, false);
     }
+#undef SPLAT_COMPOSITE_LAUNCH
     LAUNCH_CHECK(ctx, "k_composite");
-    stage_end(ctx, SPLAT_STAGE_COMPOSITE);
     return SPLAT_OK;
 }

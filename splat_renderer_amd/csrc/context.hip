@@ -60,6 +60,24 @@ void stage_begin(splat_ctx *ctx, int stage) {
     (void)hipEventRecord(t.beg[t.used], ctx->stream);
 }
 
+// For a stage that is ONE kernel: the event pair to attach to the launch itself (hipExtLaunchKernelGGL
+// takes the kernel's own start/stop timestamps, with no marker packets around it in the queue — a
+// hipEventRecord pair costs ~6 us of idle GPU per launch).  False when the stage is not being timed.
+bool stage_event_pair(splat_ctx *ctx, int stage, hipEvent_t *start, hipEvent_t *stop) {
+    if (!ctx->timing || !((ctx->timing_mask >> stage) & 1u)) return false;
+    StageTimer &t = ctx->timers[stage];
+    if (t.used == t.beg.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+        t.beg.push_back(a);
+        t.end.push_back(b);
+    }
+    *start = t.beg[t.used];
+    *stop = t.end[t.used];
+    ++t.used;
+    return true;
+}
+
 void stage_end(splat_ctx *ctx, int stage) {
     if (!ctx->timing || !((ctx->timing_mask >> stage) & 1u)) return;
     StageTimer &t = ctx->timers[stage];
