@@ -265,7 +265,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
             pay[i] = pay_in ? pay_in[base + q] : (base + q); // no payload array: the payload is the element's index
         }
     }
-    if (!ONESWEEP) __syncthreads(); // wave_hist zeroed
+    // (rowscan mode: the barrier that makes the zeroed wave_hist visible is folded into the vote below)
 
     // ---- rank, phase A: per item, the mask of lanes of this wave holding the same digit: 8 ballots,
     // each folded in with one v_bitop3 per mask half (peers &= ~(ballot ^ mybit)).  The lowest lane
@@ -283,6 +283,8 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     if (RANK_ATOMIC && !ONESWEEP) {
         const uint32_t next = tid > mask ? 0u : (part + 1 < num_parts) ? scanned_hist[(size_t)tid * num_parts + part + 1] : digit_total;
         use_atomic = !__syncthreads_or((next - row_prefix) > PART_KEYS / 4); // some digit holds > 25 % of the partition
+    } else if (!ONESWEEP) {
+        __syncthreads(); // wave_hist zeroed
     }
     if (use_atomic) {
         // Measured property of gfx950 (splat_probe_lds_atomic_order, run once per context; the ballot
