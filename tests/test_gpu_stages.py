@@ -761,3 +761,28 @@ def test_band_frame_from_compact_records_matches_frame_from_projected_records(de
     assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
     for o in (pbuf, nbuf, rec16, rec32):
         o.destroy()
+
+
+def test_switching_frame_order_between_frames_on_one_renderer(device):
+    """The two orders of work share the binner's buffers and its sync-free bookkeeping: alternating them
+    frame by frame (and changing the resolution in between) must keep giving the oracle's lists."""
+    n = 25000
+    props, normals, _ = make_case(n, 320, 200, 17, 1.5)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    sequence = [("tileFirst", 320, 200), ("sortFirst", 320, 200), ("tileFirst", 320, 200), ("tileFirst", 480, 272),
+                ("sortFirst", 480, 272), ("sortFirst", 160, 96), ("tileFirst", 160, 96), ("tileFirst", 320, 200)]
+    refs = {}
+    for order, w, h in sequence:
+        _, _, u = make_case(n, w, h, 17, 1.5)
+        if (w, h) not in refs:
+            refs[(w, h)] = oracle_pipeline(props, normals, u, w, h)
+        ref = refs[(w, h)]
+        r.binner.setFrameOrder(order)
+        r.render(u, pbuf, nbuf, None, w, h)
+        total = ref["indices"].shape[0]
+        assert r.finish() == total, (order, w, h)
+        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"]), (order, w, h)
+        assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), (order, w, h)
+    for o in (r, pbuf, nbuf):
+        o.destroy()
