@@ -222,7 +222,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         frame()
     br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # bands changed: let the sync-free bounds re-learn
     stages.overflows = 0
-    stages.consumed = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stages.consumed = torch.zeros(ntx * nty, dtype=torch.int64, device="cuda")  # per tile (no atomics in the kernel)
     stages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
     torch.cuda.synchronize()
     td.barrier()
@@ -240,7 +240,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # outside the timed region: proves no sync-free frame overflowed
     assert stages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
     comp_ms = stages.stage_avg_ms(_lib.STAGE_COMPOSITE)
-    p_used = int(stages.consumed[0].item()) / args.steps
+    p_used = int(stages.consumed.sum().item()) / args.steps
     stages.set_timing(False)
     r0, r1 = br.pixel_rows()
     info = torch.tensor([stages.kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6)], dtype=torch.int64, device="cuda")

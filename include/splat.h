@@ -83,7 +83,7 @@ int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);
 int splat_stage_time_stats(splat_ctx *ctx, int stage, uint32_t *samples, double *total_ms);
 /* List entries staged by splat_render_frame's composite since timing was last enabled (P_used of
  * SURVEY §8d, at the kernel's 256-entry batch granularity); synchronises. */
-int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries);
+int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries); /* summed over tiles and timed frames; synchronises */
 
 /* ---- buffers (GPUBuffer equivalent: device.createBuffer / queue.writeBuffer / mapAsync) --- */
 int splat_buf_alloc(splat_ctx *ctx, size_t bytes, void **dptr);
@@ -208,8 +208,9 @@ typedef struct splat_composite_cfg {
 } splat_composite_cfg;
 /* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
  * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;
- * only pixels of the rendered tile rows are written.  consumed_dptr (optional, u64) is
- * incremented by the number of list entries staged before each tile saturated (P_used). */
+ * only pixels of the rendered tile rows are written.  consumed_dptr (optional): u64[ceil(W/16) *
+ * ceil(H/16)], one counter per tile; a rendered tile's counter is incremented by the number of its
+ * list entries staged before the tile saturated (their sum over tiles is P_used). */
 int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity,
                     uint32_t color_stride_vec4, const void *normals, uint32_t normal_stride_vec4,
                     const void *projected, const void *tile_indices, const void *tile_counts,

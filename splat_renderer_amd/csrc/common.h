@@ -29,7 +29,8 @@ struct splat_ctx {
     // scratch for the generic scan (block sums) and for small device scalars
     void *scan_ws = nullptr;
     size_t scan_ws_bytes = 0;
-    unsigned long long *d_consumed = nullptr; // list entries staged by the composite while timing is on
+    unsigned long long *d_consumed = nullptr; // per tile: list entries staged by the composite while timing is on
+    uint32_t consumed_tiles = 0;              // entries allocated in d_consumed
     // pinned host staging for uploads / tiny readbacks
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -38,6 +39,7 @@ struct splat_ctx {
 int ctx_fail(splat_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 int ctx_ensure_scan_ws(splat_ctx *ctx, size_t bytes);
 int ctx_ensure_pinned(splat_ctx *ctx, size_t bytes);
+int ctx_ensure_consumed(splat_ctx *ctx, uint32_t tiles); // per-tile counters for timed frames (zeroed when (re)allocated)
 void stage_begin(splat_ctx *ctx, int stage);
 void stage_end(splat_ctx *ctx, int stage);
 bool stage_event_pair(splat_ctx *ctx, int stage, hipEvent_t *start, hipEvent_t *stop);

@@ -159,9 +159,7 @@ int splat_set_timing(splat_ctx *ctx, int enabled) {
     if (ctx->timing) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (auto &t : ctx->timers) t.used = 0; // start a new sample set
-        if (!ctx->d_consumed && hipMalloc((void **)&ctx->d_consumed, 16) != hipSuccess)
-            return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counter hipMalloc");
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, 16, ctx->stream));
+        if (ctx->d_consumed) HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, (size_t)ctx->consumed_tiles * 8, ctx->stream));
     }
     return SPLAT_OK;
 }
@@ -172,13 +170,36 @@ int splat_set_timing_stages(splat_ctx *ctx, uint32_t stage_mask) {
     return SPLAT_OK;
 }
 
+} // extern "C"
+
+int ctx_ensure_consumed(splat_ctx *ctx, uint32_t tiles) {
+    if (tiles <= ctx->consumed_tiles) return SPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (grown mid-run: counts gathered so far at the old size are kept)
+    unsigned long long *bigger = nullptr;
+    if (hipMalloc((void **)&bigger, (size_t)tiles * 8) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counters hipMalloc");
+    HIP_TRY(ctx, hipMemset(bigger, 0, (size_t)tiles * 8));
+    if (ctx->d_consumed) {
+        HIP_TRY(ctx, hipMemcpy(bigger, ctx->d_consumed, (size_t)ctx->consumed_tiles * 8, hipMemcpyDeviceToDevice));
+        (void)hipFree(ctx->d_consumed);
+    }
+    ctx->d_consumed = bigger;
+    ctx->consumed_tiles = tiles;
+    return SPLAT_OK;
+}
+
+extern "C" {
+
 int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, entries != nullptr);
-    if (!ctx->d_consumed) return ctx_fail(ctx, SPLAT_ERR_STATE, "timing was never enabled");
-    unsigned long long v = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_consumed, 8, hipMemcpyDeviceToHost, ctx->stream));
+    *entries = 0;
+    if (!ctx->d_consumed) return SPLAT_OK; // no timed frame has run
+    std::vector<unsigned long long> host(ctx->consumed_tiles);
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->d_consumed, (size_t)ctx->consumed_tiles * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long v = 0;
+    for (unsigned long long c : host) v += c;
     *entries = v;
     return SPLAT_OK;
 }

@@ -448,6 +448,10 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
     void *counts = binner->counts, *offsets = binner->offsets;
     void *indices = binner->pairs.result_in_primary ? binner->pairs.payload : binner->pairs.payload_b;
     const char *color = (const char *)props + 16; // second vec4 of each interleaved record
+    if (ctx->timing) {
+        rc = ctx_ensure_consumed(ctx, ntx * nty);
+        if (rc != SPLAT_OK) return rc;
+    }
     return splat_composite(ctx, cfg, color, 2, normals, 1, projected, indices, counts, offsets, width, height, out_rgba8,
                            out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
 }

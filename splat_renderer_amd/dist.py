@@ -93,7 +93,7 @@ class HipStages:
         self.mode, self.early_out = mode, early_out
         self.pairs = 0
         self.overflows = 0
-        self.consumed = None  # optional torch int64[1]: list entries staged by the composite
+        self.consumed = None  # optional torch int64[tiles]: per tile, list entries staged by the composite
 
     def set_timing(self, enabled, stage_mask=0xFFFFFFFF):
         check(self.lib.splat_set_timing_stages(self.ctx, stage_mask), self.ctx)
