@@ -93,8 +93,10 @@ __device__ __forceinline__ void fetch_record(const CompositeParams &p, uint32_t 
 
 template <int MODE, bool EARLY_OUT>
 __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
-    __shared__ float4 s_geo[CBATCH];     // centre.x, centre.y, exp2 scale, lit blue   (one ds_read_b128)
-    __shared__ float2 s_col[CBATCH];     // lit red, lit green                         (one ds_read_b64)
+    // per entry one 32-byte record {centre.x, centre.y, exp2 scale, lit blue | lit red, lit green, -, -}: both
+    // halves are read off ONE address register (ds_read_b128 + ds_read_b64 offset:16), and forming an LDS
+    // address from the scalar entry index costs a VALU move per register
+    __shared__ float4 s_par[CBATCH][2];
     __shared__ uint2 s_mask[4][CBATCH];  // per quadrant: which of its 64 pixels the entry's box covers
     __shared__ uint32_t s_wave_done[4];
 
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 }
             }
             if (tid < CBATCH) {
-                s_geo[tid] = geo;
-                s_col[tid] = col;
+                s_par[tid][0] = geo;
+                s_par[tid][1] = make_float4(col.x, col.y, 0.0f, 0.0f);
                 s_mask[0][tid] = quadrant_mask(xm & 0xffu, ym & 0xffu);
                 s_mask[1][tid] = quadrant_mask(xm >> 8, ym & 0xffu);
                 s_mask[2][tid] = quadrant_mask(xm & 0xffu, ym >> 8);
@@ -220,8 +222,9 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 unsigned long long cover1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j1) << 32) |
                                             (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j1);
                 if (!two) cover1 = 0;
-                const float4 G0 = s_geo[c0 + j0], G1 = s_geo[c0 + j1]; // wave-uniform addresses: LDS broadcasts
-                const float2 C0 = s_col[c0 + j0], C1 = s_col[c0 + j1];
+                const float4 G0 = s_par[c0 + j0][0], G1 = s_par[c0 + j1][0]; // wave-uniform addresses: LDS broadcasts
+                const float2 C0 = *reinterpret_cast<const float2 *>(&s_par[c0 + j0][1]),
+                             C1 = *reinterpret_cast<const float2 *>(&s_par[c0 + j1][1]);
                 const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
                 float g0 = __builtin_amdgcn_exp2f((dx0 * dx0 + dy0 * dy0) * G0.z);
                 float g1 = __builtin_amdgcn_exp2f((dx1 * dx1 + dy1 * dy1) * G1.z);
