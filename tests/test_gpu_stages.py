@@ -786,3 +786,32 @@ def test_switching_frame_order_between_frames_on_one_renderer(device):
         assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), (order, w, h)
     for o in (r, pbuf, nbuf):
         o.destroy()
+
+
+def test_tile_first_random_scenes(device):
+    """Seeded sweep over sizes, aspect ratios, splat scales and camera distances (screens down to a
+    single tile, splats from sub-pixel to screen-filling): tile lists against the oracle, and the image
+    of every third case against the sort-first order bit for bit."""
+    rng = np.random.default_rng(20260301)
+    for case in range(24):
+        n = int(rng.integers(1, 6000))
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        rs = float(rng.choice([0.05, 0.3, 1.0, 2.5, 8.0]))
+        cam = dict(distance=float(rng.uniform(1.2, 6.0)), azimuth=float(rng.uniform(0, 6.28)), elevation=float(rng.uniform(-1.2, 1.2)))
+        props, normals, u = make_case(n, w, h, 1000 + case, rs, camera=cam)
+        ref = oracle_pipeline(props, normals, u, w, h)
+        r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h)
+        total = ref["indices"].shape[0]
+        tag = (case, n, w, h, rs)
+        assert r.binner.getTotalIndices() == total, tag
+        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"]), tag
+        if total:
+            assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), tag
+        if case % 3 == 0:
+            got = r.readPixelsFloat()
+            r2 = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
+            r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+            assert np.array_equal(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32)), tag
+            r2.destroy()
+        for o in (r, pbuf, nbuf):
+            o.destroy()
