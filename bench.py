@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=sorted(sr.scene.CONFIGS))
+    ap.add_argument("--layout", default="planes", choices=["planes", "interleaved"],
+                    help="splat properties as two vec4 planes (native) or the reference's interleaved 32-byte records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -121,7 +123,10 @@ def main():
 def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload):
     dev = sr.Device(0)
     lib, ctx = dev.lib, dev.ctx
-    pbuf = dev.createBufferFrom(props)
+    pm = sr.SplatPropertyManager(dev, n)
+    pm.setFromArrays(props)
+    # the native layout (two vec4 planes, what updatePlanesFromCurvature writes) unless asked for the reference's records
+    pbuf = pm.getPropertyPlanes() if args.layout == "planes" else pm.getPropertyBuffer()
     nbuf = dev.createBufferFrom(normals)
     r = sr.Renderer(dev, None, "rgba8unorm", n, tile)
 
@@ -172,6 +177,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
                    "pairs_P": pairs, "pairs_consumed_P_used": round(p_used), "parallelism": "1 GPU",
+                   "property_layout": "two vec4 planes (pos,radius | rgb,opacity)" if args.layout == "planes" else "interleaved 32-byte records (reference layout)",
                    "frame_order": os.environ.get("SPLAT_FRAME_ORDER", "tile-first (bin, then depth-sort per tile; library default)"),
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -192,7 +198,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                                              "pixels_off_by_more_than_1": int((diff.max(axis=2) > 1).sum())}
         result["cpu_baseline"] = cb
     r.destroy()
-    pbuf.destroy()
+    pm.destroy()
     nbuf.destroy()
     dev.destroy()
     return result

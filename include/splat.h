@@ -96,6 +96,11 @@ int splat_buf_zero(splat_ctx *ctx, void *dptr, size_t bytes);
 /* positions, curvature: vec4 per splat; props: 32-byte interleaved records. */
 int splat_update_props(splat_ctx *ctx, const void *positions, const void *curvature, uint32_t n,
                        void *props);
+/* The same update writing two planes (vec4(pos, radius) | vec4(rgb, opacity)) — SURVEY §8f row 1 — and the
+ * one-off conversion of interleaved records into planes. */
+int splat_update_props_planes(splat_ctx *ctx, const void *positions, const void *curvature, uint32_t n,
+                              void *pos_radius, void *color_opacity);
+int splat_props_to_planes(splat_ctx *ctx, const void *props, uint32_t n, void *pos_radius, void *color_opacity);
 
 /* ---- SplatProjector.project  (src/SplatProjector.ts:64-132,174-194) ----------------------- */
 /* uniforms: 22 host floats = VP column-major [0..15], eye [16..18], time [19], screenW [20],
@@ -222,6 +227,14 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
                        const splat_composite_cfg *cfg, const float *uniforms, const void *props,
                        const void *normals, uint32_t n, uint32_t width, uint32_t height,
                        void *projected, void *out_rgba8, void *out_rgba32f);
+/* The same frame from the MI355X-native property layout: two planes of vec4 per splat instead of the
+ * reference's interleaved 32-byte records (the projector then reads 16 useful bytes per 16 fetched
+ * instead of per 32).  splat_update_props_planes / splat_props_to_planes produce them. */
+int splat_render_frame_planes(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
+                              const splat_composite_cfg *cfg, const float *uniforms,
+                              const void *pos_radius, const void *color_opacity, const void *normals,
+                              uint32_t n, uint32_t width, uint32_t height, void *projected,
+                              void *out_rgba8, void *out_rgba32f);
 
 /* ---- multi-GPU band path (no reference equivalent — the reference is single-device) */
 /* Projects splats [first, first+count) of the scene into projected_slice[0..count) with

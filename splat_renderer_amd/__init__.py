@@ -9,5 +9,5 @@ from ._lib import (MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL, STAGE_BIN, STAGE_
                    STAGE_PROJECT, STAGE_SORT, CompositeCfg, SplatError)
 from .camera import Camera  # noqa: F401
 from .host import (Buffer, CommandEncoder, ComputeShaderRenderer, DepthKeyExtractor, Device, GPUTileBinner,  # noqa: F401
-                   PerTileSorter, PointManager, PrefixSumScanner, RadixSorter, Renderer, SequentialRenderer, SplatProjector,
-                   SplatPropertyManager, TileRenderer)
+                   PerTileSorter, PointManager, PrefixSumScanner, PropertyPlanes, RadixSorter, Renderer, SequentialRenderer,
+                   SplatProjector, SplatPropertyManager, TileRenderer)

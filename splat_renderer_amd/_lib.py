@@ -53,6 +53,8 @@ SIGNATURES = {
     "splat_buf_download": (_i, [_vp, _vp, _vp, _sz]),
     "splat_buf_zero": (_i, [_vp, _vp, _sz]),
     "splat_update_props": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "splat_update_props_planes": (_i, [_vp, _vp, _vp, _u32, _vp, _vp]),
+    "splat_props_to_planes": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "splat_project": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _vp, _vp, _vp, _u32]),
     "splat_extract_keys": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "splat_sort_create": (_i, [_vp, _u32, _pvp]),
@@ -82,6 +84,8 @@ SIGNATURES = {
                              _vp, _vp, _vp]),
     "splat_render_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), C.POINTER(C.c_float), _vp, _vp, _u32, _u32,
                                 _u32, _vp, _vp, _vp]),
+    "splat_render_frame_planes": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), C.POINTER(C.c_float), _vp, _vp, _vp, _u32,
+                                       _u32, _u32, _vp, _vp, _vp]),
     "splat_project_slice": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
     "splat_project_slice_compact": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
     "splat_expand_compact": (_i, [_vp, _vp, _u32, _u32, _vp]),
@@ -94,6 +98,15 @@ SIGNATURES = {
 _lib = None
 
 
+class _Bound:
+    """Only the functions SIGNATURES declares, with their argument types bound.  (A raw CDLL hands out any
+    exported symbol with C's default int arguments, which truncates 64-bit device pointers: calling a
+    function that was added to splat.h but not to SIGNATURES must fail here, not fault on the GPU.)"""
+
+    def __getattr__(self, name):
+        raise AttributeError(f"libsplat_hip: {name} is not declared in splat_renderer_amd._lib.SIGNATURES")
+
+
 def load():
     """Load libsplat_hip.so; raises (never falls back) if it has not been built."""
     global _lib
@@ -103,11 +116,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). splat_renderer_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    dll = C.CDLL(LIB_PATH)
+    lib = _Bound()
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = the .so does not export what splat.h declares
+        fn = getattr(dll, name)  # AttributeError here = the .so does not export what splat.h declares
         fn.restype = res
         fn.argtypes = args
+        setattr(lib, name, fn)
+    lib._dll = dll
     _lib = lib
     return lib
 

@@ -392,11 +392,16 @@ int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host)
     return SPLAT_OK;
 }
 
-int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, const splat_composite_cfg *cfg,
-                       const float *uniforms, const void *props, const void *normals, uint32_t n, uint32_t width,
-                       uint32_t height, void *projected, void *out_rgba8, void *out_rgba32f) {
+} // extern "C"
+
+// pos_radius / color_opacity: vec4 per splat, *_stride float4s apart (2 and 2 with color = props + 16 bytes for the
+// reference's interleaved records; 1 and 1 for separate planes)
+static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, const splat_composite_cfg *cfg,
+                             const float *uniforms, const void *props, uint32_t pos_stride, const void *color,
+                             uint32_t color_stride, const void *normals, uint32_t n, uint32_t width, uint32_t height,
+                             void *projected, void *out_rgba8, void *out_rgba32f) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && normals && projected);
+    ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && color && normals && projected);
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner));
     if (n > splat_sort_capacity(sorter)) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_render_frame: n exceeds the sorter's capacity");
     ARG_CHECK(ctx, width >= 1 && height >= 1);
@@ -425,7 +430,7 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
         ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, 1024)};
     }
     // (the payload array is not written: payload = splat index)
-    rc = project_launch(ctx, uniforms, props, 2, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
+    rc = project_launch(ctx, uniforms, props, pos_stride, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
                         tile_first ? &ho : nullptr);
     if (rc != SPLAT_OK) return rc;
     binner->tf_hist_ready = tile_first;
@@ -447,13 +452,29 @@ int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binne
     // (fields, not the public getters: those wait for a sync-free frame's pair total to come back)
     void *counts = binner->counts, *offsets = binner->offsets;
     void *indices = binner->pairs.result_in_primary ? binner->pairs.payload : binner->pairs.payload_b;
-    const char *color = (const char *)props + 16; // second vec4 of each interleaved record
     if (ctx->timing) {
         rc = ctx_ensure_consumed(ctx, ntx * nty);
         if (rc != SPLAT_OK) return rc;
     }
-    return splat_composite(ctx, cfg, color, 2, normals, 1, projected, indices, counts, offsets, width, height, out_rgba8,
+    return splat_composite(ctx, cfg, color, color_stride, normals, 1, projected, indices, counts, offsets, width, height, out_rgba8,
                            out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
+}
+
+extern "C" {
+
+int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, const splat_composite_cfg *cfg,
+                       const float *uniforms, const void *props, const void *normals, uint32_t n, uint32_t width,
+                       uint32_t height, void *projected, void *out_rgba8, void *out_rgba32f) {
+    // the reference's interleaved records: colour is the second vec4 of each
+    return render_frame_impl(ctx, sorter, binner, cfg, uniforms, props, 2, props ? (const char *)props + 16 : nullptr, 2, normals, n,
+                             width, height, projected, out_rgba8, out_rgba32f);
+}
+
+int splat_render_frame_planes(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, const splat_composite_cfg *cfg,
+                              const float *uniforms, const void *pos_radius, const void *color_opacity, const void *normals,
+                              uint32_t n, uint32_t width, uint32_t height, void *projected, void *out_rgba8, void *out_rgba32f) {
+    return render_frame_impl(ctx, sorter, binner, cfg, uniforms, pos_radius, 1, color_opacity, 1, normals, n, width, height, projected,
+                             out_rgba8, out_rgba32f);
 }
 
 } // extern "C"

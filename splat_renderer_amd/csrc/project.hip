@@ -180,6 +180,25 @@ __global__ __launch_bounds__(256) void k_update_props(const float4 *__restrict__
     props[(size_t)i * 2 + 1] = make_float4(fabsf(c.x) * 0.8f + 0.2f, fabsf(c.y) * 0.8f + 0.2f, fabsf(c.z) * 0.8f + 0.2f, 1.0f); // :97-101
 }
 
+// the same update into two planes (the projector reads the first, the composite gathers from the second)
+__global__ __launch_bounds__(256) void k_update_props_planes(const float4 *__restrict__ positions,
+                                                             const float4 *__restrict__ curvature, uint32_t n,
+                                                             float4 *__restrict__ pos_radius, float4 *__restrict__ color_opacity) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = positions[i], c = curvature[i];
+    pos_radius[i] = make_float4(p.x, p.y, p.z, 0.04f);                                                                    // :94
+    color_opacity[i] = make_float4(fabsf(c.x) * 0.8f + 0.2f, fabsf(c.y) * 0.8f + 0.2f, fabsf(c.z) * 0.8f + 0.2f, 1.0f); // :97-101
+}
+
+__global__ __launch_bounds__(256) void k_props_to_planes(const float4 *__restrict__ props, uint32_t n,
+                                                         float4 *__restrict__ pos_radius, float4 *__restrict__ color_opacity) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    pos_radius[i] = props[(size_t)i * 2];
+    color_opacity[i] = props[(size_t)i * 2 + 1];
+}
+
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
                    const BinParams *bp, const TfHistOut *hist_out) {
@@ -282,6 +301,28 @@ int splat_update_props(splat_ctx *ctx, const void *positions, const void *curvat
     hipLaunchKernelGGL(k_update_props, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (const float4 *)positions,
                        (const float4 *)curvature, n, (float4 *)props);
     LAUNCH_CHECK(ctx, "k_update_props");
+    return SPLAT_OK;
+}
+
+int splat_update_props_planes(splat_ctx *ctx, const void *positions, const void *curvature, uint32_t n, void *pos_radius,
+                              void *color_opacity) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, n == 0 || (positions && curvature && pos_radius && color_opacity));
+    if (n == 0) return SPLAT_OK;
+    hipLaunchKernelGGL(k_update_props_planes, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (const float4 *)positions,
+                       (const float4 *)curvature, n, (float4 *)pos_radius, (float4 *)color_opacity);
+    LAUNCH_CHECK(ctx, "k_update_props_planes");
+    return SPLAT_OK;
+}
+
+int splat_props_to_planes(splat_ctx *ctx, const void *props, uint32_t n, void *pos_radius, void *color_opacity) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, n == 0 || (props && pos_radius && color_opacity));
+    ARG_CHECK(ctx, (((uintptr_t)props | (uintptr_t)pos_radius | (uintptr_t)color_opacity) & 15) == 0);
+    if (n == 0) return SPLAT_OK;
+    hipLaunchKernelGGL(k_props_to_planes, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (const float4 *)props, n, (float4 *)pos_radius,
+                       (float4 *)color_opacity);
+    LAUNCH_CHECK(ctx, "k_props_to_planes");
     return SPLAT_OK;
 }
 

@@ -185,6 +185,17 @@ class PointManager:
             b.destroy()
 
 
+class PropertyPlanes:
+    """Two device planes of vec4 per splat: (pos, radius) and (rgb, opacity)."""
+
+    def __init__(self, posRadius, colorOpacity):
+        self.posRadius, self.colorOpacity = posRadius, colorOpacity
+
+    def destroy(self):
+        self.posRadius.destroy()
+        self.colorOpacity.destroy()
+
+
 class SplatPropertyManager:
     """src/SplatPropertyManager.ts:13-181 — owns the 32 B/splat interleaved property buffer."""
 
@@ -196,21 +207,49 @@ class SplatPropertyManager:
         data[:, 4:7] = 1.0
         data[:, 7] = 0.7
         self.propertyBuffer.write(data)
+        self._planes, self._planes_valid = None, False
 
     def updateFromCurvature(self, commandEncoder, positionBuffer, curvatureBuffer):  # :153-173
         d = self.device
         check(d.lib.splat_update_props(d.ctx, positionBuffer.ptr, curvatureBuffer.ptr, self.numSplats,
                                        self.propertyBuffer.ptr), d.ctx)
+        self._planes_valid = False
 
     def setFromArrays(self, props):
         """Synthetic scenes: upload (n,8) interleaved records directly."""
         self.propertyBuffer.write(np.ascontiguousarray(props, np.float32))
+        self._planes_valid = False
 
     def getPropertyBuffer(self):  # :175-177
         return self.propertyBuffer
 
+    def getPropertyPlanes(self):
+        """The MI355X-native layout of the same properties: (vec4(pos, radius) plane, vec4(rgb, opacity)
+        plane), converted on the device when the interleaved buffer changed.
+        Renderer.render accepts the pair in place of the interleaved buffer."""
+        d = self.device
+        if getattr(self, "_planes", None) is None:
+            self._planes = PropertyPlanes(d.createBuffer(self.numSplats * 16), d.createBuffer(self.numSplats * 16))
+            self._planes_valid = False
+        if not self._planes_valid:
+            check(d.lib.splat_props_to_planes(d.ctx, self.propertyBuffer.ptr, self.numSplats, self._planes.posRadius.ptr,
+                                              self._planes.colorOpacity.ptr), d.ctx)
+            self._planes_valid = True
+        return self._planes
+
+    def updatePlanesFromCurvature(self, commandEncoder, positionBuffer, curvatureBuffer):
+        """updateFromCurvature writing the two planes directly (no interleaved copy is touched)."""
+        d = self.device
+        planes = self.getPropertyPlanes()
+        check(d.lib.splat_update_props_planes(d.ctx, positionBuffer.ptr, curvatureBuffer.ptr, self.numSplats,
+                                              planes.posRadius.ptr, planes.colorOpacity.ptr), d.ctx)
+        return planes
+
     def destroy(self):  # :179-181
         self.propertyBuffer.destroy()
+        if getattr(self, "_planes", None) is not None:
+            self._planes.destroy()
+            self._planes = None
 
 
 class SplatProjector:
@@ -566,14 +605,18 @@ class Renderer:
         if wantFloat and self.outputFloat is None:
             self.outputFloat = d.createBuffer(width * height * 16)
         cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1])
-        args = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)), propertyBuffer.ptr,
-                normalsBuffer.ptr, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
+        tail = (normalsBuffer.ptr, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
                 self.outputFloat.ptr if wantFloat else None)
-        self._last = (args, u, cfg)  # keeps u/cfg alive; finish() may have to render this frame again
-        rc = d.lib.splat_render_frame(*args)
+        head = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)))
+        if isinstance(propertyBuffer, PropertyPlanes):  # the native layout: SplatPropertyManager.getPropertyPlanes()
+            fn, args = d.lib.splat_render_frame_planes, head + (propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr) + tail
+        else:  # the reference's interleaved records
+            fn, args = d.lib.splat_render_frame, head + (propertyBuffer.ptr,) + tail
+        self._last = (fn, args, u, cfg)  # keeps u/cfg alive; finish() may have to render this frame again
+        rc = fn(*args)
         if rc == -4:  # SPLAT_ERR_CAPACITY: the PREVIOUS (sync-free) frame outgrew its pair limit; room was made
             self.previousFrameOverflowed = True
-            rc = d.lib.splat_render_frame(*args)
+            rc = fn(*args)
         check(rc, d.ctx)
         self.binner._tiles = -(-width // self.tileSize) * -(-height // self.tileSize)
         return self.output
@@ -587,7 +630,7 @@ class Renderer:
         rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
         if rc == -4 and self._last is not None:
             self.previousFrameOverflowed = True
-            check(d.lib.splat_render_frame(*self._last[0]), d.ctx)
+            check(self._last[0](*self._last[1]), d.ctx)
             rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
         check(rc, d.ctx)
         return int(t.value)

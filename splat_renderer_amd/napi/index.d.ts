@@ -13,7 +13,8 @@ export class Camera {
   setAspect(aspect: number): void; rotate(deltaAzimuth: number, deltaElevation: number): void; zoom(deltaDistance: number): void;
   getViewProjectionMatrix(): Float32Array; getPosition(): Float32Array; uniforms(width: number, height: number, time?: number): Float32Array;
 }
-export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; destroy(): void; }
+export interface PropertyPlanes { posRadius: Buffer; colorOpacity: Buffer; isPlanes: true; }
+export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; updatePlanesFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): PropertyPlanes; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; getPropertyPlanes(): PropertyPlanes; destroy(): void; }
 export class SplatProjector { constructor(device: Device, numSplats: number); project(enc: CommandEncoder | null, uniformBuffer: Buffer | Float32Array, splatPropertyBuffer: Buffer, keysBuffer?: Buffer | null, payloadBuffer?: Buffer | null, paddedSize?: number): void; getProjectedBuffer(): Buffer; destroy(): void; }
 export class DepthKeyExtractor { constructor(device: Device); extract(enc: CommandEncoder | null, projectedBuffer: Buffer, keysBuffer: Buffer, payloadBuffer: Buffer, numSplats: number, paddedSize: number): void; cleanupTempBuffers(): void; }
 export class RadixSorter { constructor(device: Device, numSplats: number); readonly paddedSize: number; sort(numKeys?: number, bitBegin?: number, bitEnd?: number): void; getSortedIndicesBuffer(): Buffer; getKeysBuffer(): Buffer; getPayloadBuffer(): Buffer; cleanupTempBuffers(): void; destroy(): void; }
@@ -23,5 +24,5 @@ export class PerTileSorter { constructor(device: Device, validate?: boolean); vi
 export class SequentialRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numSplats?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, splatPropertyBuffer: Buffer, sortedIndexBuffer: Buffer, curvatureBuffer: Buffer, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
 export class ComputeShaderRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean }); render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
 export class TileRenderer extends ComputeShaderRenderer { bindTileData(projectedBuffer: Buffer, tileCountsBuffer: Buffer, tileOffsetsBuffer: Buffer): void; }
-export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
+export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer | PropertyPlanes, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
 export const MODE_FRONT_TO_BACK: 0; export const MODE_REFERENCE_LITERAL: 1;

@@ -66,10 +66,25 @@ class SplatPropertyManager {
   }
   updateFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) { // :153-173
     native.update_props(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, this.propertyBuffer.ptr);
+    this.planesValid = false;
   }
-  setFromArrays(props) { this.propertyBuffer.write(props); }
+  setFromArrays(props) { this.propertyBuffer.write(props); this.planesValid = false; }
   getPropertyBuffer() { return this.propertyBuffer; } // :175-177
-  destroy() { this.propertyBuffer.destroy(); }          // :179-181
+  // the MI355X-native layout: two vec4 planes {posRadius, colorOpacity}; Renderer.render takes either
+  getPropertyPlanes() {
+    if (!this.planes) this.planes = { posRadius: this.device.createBuffer(this.numSplats * 16), colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true };
+    if (!this.planesValid) { native.props_to_planes(this.device.ctx, this.propertyBuffer.ptr, this.numSplats, this.planes.posRadius.ptr, this.planes.colorOpacity.ptr); this.planesValid = true; }
+    return this.planes;
+  }
+  updatePlanesFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) {
+    const p = this.getPropertyPlanes();
+    native.update_props_planes(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, p.posRadius.ptr, p.colorOpacity.ptr);
+    return p;
+  }
+  destroy() { // :179-181
+    this.propertyBuffer.destroy();
+    if (this.planes) { this.planes.posRadius.destroy(); this.planes.colorOpacity.destroy(); this.planes = null; }
+  }
 }
 
 /** src/SplatProjector.ts:5-203 */
@@ -221,8 +236,14 @@ class Renderer {
     let u = uniformFloats(uniformData);
     if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
     if (this.width !== width || this.height !== height) { if (this.output) this.output.destroy(); this.output = this.device.createBuffer(width * height * 4); this.width = width; this.height = height; }
-    native.render_frame(this.device.ctx, this.sorter.handle, this.binner.handle, [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX], u,
-      propertyBuffer.ptr, normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
+    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX];
+    if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
+      native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,
+        normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
+    } else {
+      native.render_frame(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u,
+        propertyBuffer.ptr, normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
+    }
     this.binner.numTiles = Math.ceil(width / this.tileSize) * Math.ceil(height / this.tileSize);
     return this.output;
   }

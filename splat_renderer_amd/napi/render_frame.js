@@ -1,10 +1,10 @@
 'use strict';
-// node render_frame.js <props.f32> <normals.f32> <n> <W> <H> <out.rgba8> [<order.u32> <counts.u32> <indices.u32>]
+// node render_frame.js <props.f32> <normals.f32> <n> <W> <H> <out.rgba8> [<order.u32> <counts.u32> <indices.u32> [<frame.rgba8>]]
 // Renders one frame through the JS host classes (stage by stage, like the reference's call order)
 // and writes the raw outputs for tests/test_napi.py to compare with the oracle.
 const fs = require('fs');
 const sr = require('./index.js');
-const [propsPath, normalsPath, nStr, wStr, hStr, outPath, orderPath, countsPath, indicesPath] = process.argv.slice(2);
+const [propsPath, normalsPath, nStr, wStr, hStr, outPath, orderPath, countsPath, indicesPath, framePath] = process.argv.slice(2);
 const n = +nStr, W = +wStr, H = +hStr;
 const f32 = (p) => { const b = fs.readFileSync(p); return new Float32Array(b.buffer, b.byteOffset, b.length / 4); };
 const device = new sr.Device(0);
@@ -33,5 +33,13 @@ if (!threw) throw new Error('getter before binSplats did not throw');
   if (orderPath) fs.writeFileSync(orderPath, Buffer.from(sorter.getSortedIndicesBuffer().read(new Uint32Array(n)).buffer));
   if (countsPath) fs.writeFileSync(countsPath, Buffer.from(binner.getTileCountsBuffer().read(new Uint32Array(binner.numTiles)).buffer));
   if (indicesPath) fs.writeFileSync(indicesPath, Buffer.from(binner.getTileIndicesBuffer().read(new Uint32Array(binner.getTotalIndices())).buffer));
-  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), uniforms: Array.from(uniforms) }));
+  let framePairs = -1;
+  if (framePath) { // the whole-frame facade (tile-first order inside), fed the native two-plane property layout, twice (2nd: sync-free)
+    const whole = new sr.Renderer(device, null, 'rgba8unorm', n, 16);
+    whole.binner.setFrameOrder('tileFirst');
+    for (let k = 0; k < 2; k++) whole.render(uniforms, props.getPropertyPlanes(), normals, null, W, H);
+    fs.writeFileSync(framePath, Buffer.from(whole.readPixels().buffer));
+    framePairs = whole.binner.getTotalIndices();
+  }
+  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, uniforms: Array.from(uniforms) }));
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -167,6 +167,16 @@ FN(update_props) {
     uint32_t n = (uint32_t)arg_number(&c, 3); void *props = arg_dptr(&c, 4); BAIL;
     return check(env, x, splat_update_props(x, pos, cur, n, props), mk_undefined(env));
 }
+FN(update_props_planes) { /* (ctx, positions, curvature, n, posRadius, colorOpacity) */
+    ARGS(6); splat_ctx *x = arg_external(&c, 0); void *pos = arg_dptr(&c, 1), *cur = arg_dptr(&c, 2);
+    uint32_t n = (uint32_t)arg_number(&c, 3); void *pr = arg_dptr(&c, 4), *co = arg_dptr(&c, 5); BAIL;
+    return check(env, x, splat_update_props_planes(x, pos, cur, n, pr, co), mk_undefined(env));
+}
+FN(props_to_planes) { /* (ctx, props, n, posRadius, colorOpacity) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); void *props = arg_dptr(&c, 1); uint32_t n = (uint32_t)arg_number(&c, 2);
+    void *pr = arg_dptr(&c, 3), *co = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_props_to_planes(x, props, n, pr, co), mk_undefined(env));
+}
 FN(project) { /* (ctx, Float32Array(22), posRadius, strideVec4, n, projected, keys|null, payload|null, nPadded) */
     ARGS(9); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
     void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3), n = (uint32_t)arg_number(&c, 4);
@@ -263,15 +273,25 @@ FN(render_frame) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), props, nor
     return check(env, x, splat_render_frame(x, s, b, &cfg, u, props, nrm, n, w, h, proj, o8, of), mk_undefined(env));
 }
 
+FN(render_frame_planes) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), posRadius, colorOpacity, normals, n, W, H, projected, out8|null, outF|null) */
+    ARGS(14); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); splat_binner *b = arg_external(&c, 2);
+    splat_composite_cfg cfg; fill_cfg(&c, 3, &cfg); size_t ub = 0; float *u = arg_hostbuf(&c, 4, &ub);
+    void *pr = arg_dptr(&c, 5), *co = arg_dptr(&c, 6), *nrm = arg_dptr(&c, 7);
+    uint32_t n = (uint32_t)arg_number(&c, 8), w = (uint32_t)arg_number(&c, 9), h = (uint32_t)arg_number(&c, 10);
+    void *proj = arg_dptr(&c, 11), *o8 = arg_dptr(&c, 12), *of = arg_dptr(&c, 13); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_render_frame_planes(x, s, b, &cfg, u, pr, co, nrm, n, w, h, proj, o8, of), mk_undefined(env));
+}
+
 static napi_value init(napi_env env, napi_value exports) {
 #define EXPORT(name) { #name, NULL, name, NULL, NULL, NULL, napi_enumerable, NULL }
     napi_property_descriptor d[] = {
         EXPORT(abi_version), EXPORT(ctx_create), EXPORT(ctx_destroy), EXPORT(sync), EXPORT(set_timing), EXPORT(stage_time_ms),
-        EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props),
+        EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props), EXPORT(update_props_planes), EXPORT(props_to_planes),
         EXPORT(project), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
-        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame),
+        EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

@@ -815,3 +815,41 @@ def test_tile_first_random_scenes(device):
             r2.destroy()
         for o in (r, pbuf, nbuf):
             o.destroy()
+
+
+def test_property_planes_give_the_same_frame_as_interleaved_records(device):
+    """SplatPropertyManager's native layout (two vec4 planes) through splat_render_frame_planes: same
+    records, lists and image, bit for bit, as the reference's interleaved buffer; and
+    updatePlanesFromCurvature writes what updateFromCurvature writes."""
+    n, w, h = 40000, 400, 240
+    props, normals, u = make_case(n, w, h, 23, 1.5)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    a = sr.Renderer(device, None, "rgba8unorm", n)
+    b = sr.Renderer(device, None, "rgba8unorm", n)
+    a.render(u, pm.getPropertyBuffer(), nbuf, None, w, h, wantFloat=True)
+    planes = pm.getPropertyPlanes()
+    assert np.array_equal(planes.posRadius.read(np.float32).reshape(n, 4), props[:, :4])
+    assert np.array_equal(planes.colorOpacity.read(np.float32).reshape(n, 4), props[:, 4:])
+    for _ in range(3):  # also as sync-free frames
+        b.render(u, planes, nbuf, None, w, h, wantFloat=True)
+    total = a.finish()
+    assert b.finish() == total
+    assert np.array_equal(a.projector.getProjectedBuffer().read(np.uint32), b.projector.getProjectedBuffer().read(np.uint32))
+    assert np.array_equal(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total))
+    assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    # K12 into planes == K12 into interleaved records
+    rng = np.random.default_rng(5)
+    pos = rng.standard_normal((n, 4)).astype(np.float32)
+    cur = rng.standard_normal((n, 4)).astype(np.float32)
+    posb, curb = device.createBufferFrom(pos), device.createBufferFrom(cur)
+    pm.updateFromCurvature(None, posb, curb)
+    want = pm.getPropertyBuffer().read(np.float32).reshape(n, 8).copy()
+    assert np.array_equal(want, O.update_props(pos, cur))
+    pm.setFromArrays(props)  # scramble, then update the planes only
+    planes = pm.updatePlanesFromCurvature(None, posb, curb)
+    assert np.array_equal(planes.posRadius.read(np.float32).reshape(n, 4), want[:, :4])
+    assert np.array_equal(planes.colorOpacity.read(np.float32).reshape(n, 4), want[:, 4:])
+    for o in (a, b, pm, nbuf, posb, curb):
+        o.destroy()

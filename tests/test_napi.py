@@ -76,7 +76,8 @@ def test_js_frame_matches_oracle(tmp_path):
     normals.tofile(tmp_path / "normals.f32")
     r = subprocess.run([NODE, "render_frame.js", str(tmp_path / "props.f32"), str(tmp_path / "normals.f32"), str(n), str(w),
                         str(h), str(tmp_path / "out.rgba8"), str(tmp_path / "order.u32"), str(tmp_path / "counts.u32"),
-                        str(tmp_path / "indices.u32")], cwd=NAPI, capture_output=True, text=True, timeout=300)
+                        str(tmp_path / "indices.u32"), str(tmp_path / "frame.rgba8")], cwd=NAPI, capture_output=True, text=True,
+                       timeout=300)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert np.array_equal(np.array(info["uniforms"], np.float32).view(np.uint32), u.view(np.uint32))
@@ -87,3 +88,7 @@ def test_js_frame_matches_oracle(tmp_path):
     got8 = np.fromfile(tmp_path / "out.rgba8", np.uint8).reshape(h, w, 4)
     assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 3
     assert (np.abs(got8.astype(int) - want8.astype(int)).max(axis=2) > 1).mean() <= 2e-3
+    # the whole-frame facade from JS: Renderer.render on the two-plane property layout, tile-first order
+    assert info["framePairs"] == ref["indices"].shape[0]
+    frame8 = np.fromfile(tmp_path / "frame.rgba8", np.uint8).reshape(h, w, 4)
+    assert np.array_equal(frame8, got8)  # same lists, same composite: same bytes as the staged path
