@@ -260,19 +260,23 @@ int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected,
                     uint32_t width, uint32_t height, uint32_t tile_size, uint32_t tile_row0,
                     uint32_t tile_row1, uint32_t *n_kept_host);
 
-/* One rank's frame after the exchange, without a host round trip: band filter (the kept count stays
- * on the device) -> depth sort -> bin -> composite of tile rows [cfg->tile_row0, cfg->tile_row1).
- * records: n_records ProjectedSplat records whose originalIndex is the global splat index (the
- * all-gathered shards); props/normals: the full scene in the reference's layouts. */
+/* One rank's frame after the exchange, without a host round trip: tile rows [cfg->tile_row0,
+ * cfg->tile_row1) binned, depth-sorted and composited from the gathered records.  Tile-first order
+ * (default): one pass over the records gives depth keys and tile ranges clamped to the band — a splat
+ * outside it has an empty range — then the frame's binner and per-tile sort; sort-first order: band
+ * filter (kept count on the device) -> depth sort -> bin.  records: n_records records in
+ * cfg->record_format whose position is the global splat index (the all-gathered shards);
+ * props/normals: the full scene in the reference's layouts (props = interleaved records). */
 int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                      const splat_composite_cfg *cfg, const void *props, const void *normals,
                      const void *records, uint32_t n_records, uint32_t width, uint32_t height,
                      void *out_rgba8, void *out_rgba32f, void *consumed_dptr);
-/* After the first frame splat_band_frame sizes its sort/bin grids from the PREVIOUS frame's kept count
- * and pair total (x1.125) and learns its own asynchronously; a frame that outgrew those bounds is
- * reported by the next splat_band_frame / splat_band_settle call with SPLAT_ERR_CAPACITY (render it
- * again; the bounds have been raised).  splat_band_settle waits for the last frame's readbacks, so
- * on SPLAT_OK that frame's image is final; it returns its kept count and pair total. */
+/* After the first frame splat_band_frame sizes its grids from the PREVIOUS frame's pair total (and, in
+ * the sort-first order, kept count), x1.125, and learns its own asynchronously; a frame that outgrew
+ * those bounds is reported by the next splat_band_frame / splat_band_settle call with
+ * SPLAT_ERR_CAPACITY (render it again; the bounds have been raised).  splat_band_settle waits for the
+ * last frame's readback, so on SPLAT_OK that frame's image is final; it returns the number of splats
+ * with a tile in the band and the pair total. */
 int splat_band_settle(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner, uint32_t *n_kept_host,
                       uint64_t *pairs_host);
 /* Number of splats the last splat_band_frame / splat_band_keys kept (synchronises). */
