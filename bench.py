@@ -71,6 +71,26 @@ def cpu_baseline(name, props, normals, u, width, height):
             "frame_u8": rn["out_u8"]}
 
 
+def measured_copy_ceiling(dev):
+    """the box's own device-to-device copy rate (read + write bytes per second), as a second
+    denominator next to the 8 TB/s specification."""
+    nbytes = 1 << 30
+    a, b = dev.createBuffer(nbytes), dev.createBuffer(nbytes)
+    a.zero()
+    for _ in range(2):
+        _lib.check(dev.lib.splat_buf_copy(dev.ctx, b.ptr, a.ptr, nbytes), dev.ctx)
+    dev.sync()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        _lib.check(dev.lib.splat_buf_copy(dev.ctx, b.ptr, a.ptr, nbytes), dev.ctx)
+    dev.sync()
+    dt = time.perf_counter() - t0
+    a.destroy()
+    b.destroy()
+    return 2.0 * nbytes * reps / dt / 1e9
+
+
 def load_traffic(config):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
@@ -166,6 +186,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     dev.setTiming(False)
     pairs = r.binner.getTotalIndices()
 
+    copy_gbs = measured_copy_ceiling(dev)
     comp_bytes = composite_alg_bytes(p_used, width, height)
     comp_s = stage_ms["composite"] / 1e3
     achieved = comp_bytes / comp_s / 1e9
@@ -182,11 +203,13 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name),
+                     "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                      "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"]},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                            "achieved_GBps": frame_bytes / (dt / args.steps) / 1e9,
-                           "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                           "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_measured_copy": frame_bytes / (dt / args.steps) / 1e9 / copy_gbs},
     }
     if not args.no_cpu_baseline:
         cb = cpu_baseline(name, props, normals, u, width, height)

@@ -91,6 +91,7 @@ int splat_buf_free(splat_ctx *ctx, void *dptr);
 int splat_buf_upload(splat_ctx *ctx, void *dst_dptr, const void *src_host, size_t bytes);   /* async on the stream, src is staged */
 int splat_buf_download(splat_ctx *ctx, void *dst_host, const void *src_dptr, size_t bytes); /* synchronous */
 int splat_buf_zero(splat_ctx *ctx, void *dptr, size_t bytes);
+int splat_buf_copy(splat_ctx *ctx, void *dst_dptr, const void *src_dptr, size_t bytes); /* copyBufferToBuffer: device to device, async on the stream */
 
 /* ---- SplatPropertyManager.updateFromCurvature  (src/SplatPropertyManager.ts:82-107,153-173) */
 /* positions, curvature: vec4 per splat; props: 32-byte interleaved records. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "splat_buf_upload": (_i, [_vp, _vp, _vp, _sz]),
     "splat_buf_download": (_i, [_vp, _vp, _vp, _sz]),
     "splat_buf_zero": (_i, [_vp, _vp, _sz]),
+    "splat_buf_copy": (_i, [_vp, _vp, _vp, _sz]),
     "splat_update_props": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_update_props_planes": (_i, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "splat_props_to_planes": (_i, [_vp, _vp, _u32, _vp, _vp]),

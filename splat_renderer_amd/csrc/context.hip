@@ -275,4 +275,12 @@ int splat_buf_zero(splat_ctx *ctx, void *dptr, size_t bytes) {
     return SPLAT_OK;
 }
 
+int splat_buf_copy(splat_ctx *ctx, void *dst_dptr, const void *src_dptr, size_t bytes) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, bytes == 0 || (dst_dptr && src_dptr));
+    if (bytes == 0) return SPLAT_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst_dptr, src_dptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPLAT_OK;
+}
+
 } // extern "C"
