@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(sr.scene.CONFIGS))
     ap.add_argument("--layout", default="planes", choices=["planes", "interleaved"],
                     help="splat properties as two vec4 planes (native) or the reference's interleaved 32-byte records")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -250,6 +252,10 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     for _ in range(max(args.warmup - 1, 1)):
         frame()
     br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # bands changed: let the sync-free bounds re-learn
+    pipe = None if args.no_pipeline else dist.FramePipeline(torch, br, local_rank)
+    if pipe is not None:  # warm the second buffer pair, stream and ctx outside the timed region
+        pipe.run(2, lambda k: u, pt.data_ptr(), nt.data_ptr())
+        torch.cuda.synchronize()
     stages.overflows = 0
     stages.consumed = torch.zeros(ntx * nty, dtype=torch.int64, device="cuda")  # per tile (no atomics in the kernel)
     stages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
@@ -257,8 +263,12 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
+    if pipe is not None:
+        # two frames in flight: frame k+1's projection + all-gather (second stream) under frame k's band work
+        pipe.run(args.steps, lambda k: u, pt.data_ptr(), nt.data_ptr())
+    else:
+        for _ in range(args.steps):
+            frame()
     torch.cuda.synchronize()
     td.barrier()
     torch.cuda.synchronize()
@@ -288,7 +298,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
                    "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * 16} B "
-                                  f"shards per frame",
+                                  f"shards per frame" + ("" if args.no_pipeline else "; 2 frames in flight: the next frame's projection + "
+                                                          "all-gather run on a second stream under this frame's band work"),
                    "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
                                  "composite_ms": i[4] / 1e6} for i in infos],
                    "composite": "front-to-back, early-out at alpha>=0.99"},
@@ -298,6 +309,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         "cpu_baseline": None,  # reported at N=1 only
     }
     td.barrier()
+    if pipe is not None:
+        pipe.destroy()
     stages.destroy()
     td.destroy_process_group()
     return result

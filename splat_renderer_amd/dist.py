@@ -15,6 +15,9 @@ Per-tile lists are the global stable order restricted to the tile, so the stitch
 bit-identical to the single-GPU frame (tests/test_gpu_stages.py::test_band_rendering... on one GPU,
 tests/test_dist_cpu.py for the sharding logic under gloo).
 
+Process set-up: import torch BEFORE the first splat ctx is created (before libsplat_hip.so is loaded).  torch
+bundles its own HIP runtime, and the one loaded first serves the whole process.
+
 `stages` is the object that runs device work; the product always uses HipStages (below).  The
 gloo CPU tests inject a checker-backed stand-in to exercise THIS file's slicing / gathering /
 banding logic without a GPU — that stand-in lives under tests/, never here.
@@ -206,3 +209,75 @@ class BandRenderer:
 
     def pixel_rows(self):
         return self.row0 * self.tile, min(self.row1 * self.tile, self.height)
+
+
+class ProjectStage:
+    """The projector alone, on its own splat ctx bound to a second stream: the exchange side of a
+    pipelined multi-GPU frame loop (FramePipeline)."""
+
+    def __init__(self, torch, device_ordinal, stream):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        check(self.lib.splat_ctx_create_on_stream(device_ordinal, C.c_void_p(stream.cuda_stream), C.byref(p)))
+        self.ctx = p
+
+    def project_slice(self, uniforms, props_ptr, first, count, out_records):
+        u = np.ascontiguousarray(uniforms, np.float32)
+        check(self.lib.splat_project_slice_compact(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
+                                                   out_records.data_ptr()), self.ctx)
+
+    def destroy(self):
+        self.lib.splat_ctx_destroy(self.ctx)
+
+
+class FramePipeline:
+    """Two frames in flight on one rank: while the band of frame k is binned, sorted and composited on the
+    main stream, frame k+1's slice is projected and all-gathered on a second stream (RCCL overlapped with
+    compute).  Frames are unchanged; throughput becomes 1 / max(exchange, band work) instead of
+    1 / (exchange + band work).  Two (shard, gathered) buffer pairs alternate; two events per pair order
+    the streams: `ready` (exchange done -> the band frame may read) and `free` (band frame done -> the next
+    exchange may overwrite)."""
+
+    def __init__(self, torch, br, device_ordinal):
+        self.torch, self.br = torch, br
+        self.main = torch.cuda.current_stream()
+        self.comm = torch.cuda.Stream()
+        self.proj = ProjectStage(torch, device_ordinal, self.comm)
+        st = br.stages
+        self.shards = [br.shard, st.new_records(br.per, fill_nan=True)]
+        self.gathered = [br.gathered, st.new_records(br.per * br.world) if br.world > 1 else self.shards[1]]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [torch.cuda.Event(), torch.cuda.Event()]
+        self.used = [False, False]
+
+    def exchange(self, k, uniforms, props_ptr):
+        """Project and all-gather frame k's records (asynchronous, on the second stream)."""
+        s, br = k & 1, self.br
+        with self.torch.cuda.stream(self.comm):
+            if self.used[s]:
+                self.comm.wait_event(self.free[s])  # the band frame that read this pair has finished
+            self.proj.project_slice(uniforms, props_ptr, br.first, br.count, self.shards[s])
+            if br.world > 1:
+                br.all_gather(self.gathered[s], self.shards[s])
+            self.ready[s].record(self.comm)
+
+    def band(self, k, props_ptr, normals_ptr, settle=False):
+        """Frame k's band from its gathered records (main stream)."""
+        s, br = k & 1, self.br
+        self.main.wait_event(self.ready[s])
+        br.stages.band_frame(self.gathered[s], br.per * br.world, props_ptr, normals_ptr, br.row0, br.row1, br.image, settle)
+        self.free[s].record(self.main)
+        self.used[s] = True
+        return br.image
+
+    def run(self, frames, uniforms_of, props_ptr, normals_ptr):
+        """frames frames; uniforms_of(k) gives frame k's uniform block."""
+        self.exchange(0, uniforms_of(0), props_ptr)
+        for k in range(frames):
+            if k + 1 < frames:
+                self.exchange(k + 1, uniforms_of(k + 1), props_ptr)
+            self.band(k, props_ptr, normals_ptr)
+
+    def destroy(self):
+        self.torch.cuda.synchronize()
+        self.proj.destroy()

@@ -15,6 +15,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def device():
     """One splat ctx for the whole GPU session (a ctx is one device + one stream)."""
+    # torch bundles its own HIP runtime: in a process that uses both, torch's must be the one that gets
+    # loaded (libsplat_hip then binds to it); the other order leaves torch with "No HIP GPUs are available"
+    import torch  # noqa: F401
     import splat_renderer_amd as sr
     dev = sr.Device(0)
     yield dev

@@ -853,3 +853,33 @@ def test_property_planes_give_the_same_frame_as_interleaved_records(device):
     assert np.array_equal(planes.colorOpacity.read(np.float32).reshape(n, 4), want[:, 4:])
     for o in (a, b, pm, nbuf, posb, curb):
         o.destroy()
+
+
+def test_frame_pipeline_keeps_frames_apart(device):
+    """dist.FramePipeline (two frames in flight: the next frame's projection + exchange on a second stream
+    under this frame's band work) with a camera that moves every frame: every band image must be the
+    one the unpipelined BandRenderer gives for that frame's camera."""
+    import torch
+    from splat_renderer_amd import dist
+    n, w, h = 60000, 480, 272
+    props, normals, _ = make_case(n, w, h, 29, 1.5)
+    cams = [make_case(n, w, h, 29, 1.5, camera=dict(azimuth=0.5 + 0.3 * k, elevation=0.5 - 0.1 * k))[2] for k in range(5)]
+    pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+    stages = dist.HipStages(torch, 0, n, w, h)
+    br = dist.BandRenderer(stages, n, w, h, 0, 1, None)
+    want = []
+    for u in cams:
+        br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
+        torch.cuda.synchronize()
+        want.append(br.image.cpu().numpy().copy())
+    assert not np.array_equal(want[0], want[1])
+    pipe = dist.FramePipeline(torch, br, 0)
+    pipe.exchange(0, cams[0], pt.data_ptr())
+    for k in range(len(cams)):
+        if k + 1 < len(cams):
+            pipe.exchange(k + 1, cams[k + 1], pt.data_ptr())
+        img = pipe.band(k, pt.data_ptr(), nt.data_ptr(), settle=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(img.cpu().numpy(), want[k]), k
+    pipe.destroy()
+    stages.destroy()
