@@ -252,10 +252,19 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     for _ in range(max(args.warmup - 1, 1)):
         frame()
     br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # bands changed: let the sync-free bounds re-learn
-    pipe = None if args.no_pipeline else dist.FramePipeline(torch, br, local_rank)
-    if pipe is not None:  # warm the second buffer pair, stream and ctx outside the timed region
-        pipe.run(2, lambda k: u, pt.data_ptr(), nt.data_ptr())
-        torch.cuda.synchronize()
+    pipe = None
+    if not args.no_pipeline:
+        try:  # warm the second buffer pair, stream and ctx outside the timed region
+            pipe = dist.FramePipeline(torch, br, local_rank)
+            pipe.run(2, lambda k: u, pt.data_ptr(), nt.data_ptr())
+            torch.cuda.synchronize()
+            ok = torch.ones(1, device="cuda")
+        except Exception as e:  # (every rank must take the same loop: agree below)
+            print(f"[rank {rank}] frame pipeline unavailable ({e!r}); serial loop", file=sys.stderr)
+            pipe, ok = None, torch.zeros(1, device="cuda")
+        td.all_reduce(ok, op=td.ReduceOp.MIN)
+        if ok.item() < 1:
+            pipe = None
     stages.overflows = 0
     stages.consumed = torch.zeros(ntx * nty, dtype=torch.int64, device="cuda")  # per tile (no atomics in the kernel)
     stages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
@@ -298,7 +307,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
                    "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * 16} B "
-                                  f"shards per frame" + ("" if args.no_pipeline else "; 2 frames in flight: the next frame's projection + "
+                                  f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
                                                           "all-gather run on a second stream under this frame's band work"),
                    "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
                                  "composite_ms": i[4] / 1e6} for i in infos],
