@@ -883,3 +883,43 @@ def test_frame_pipeline_keeps_frames_apart(device):
         assert np.array_equal(img.cpu().numpy(), want[k]), k
     pipe.destroy()
     stages.destroy()
+
+
+def test_new_entry_points_reject_bad_arguments(device):
+    """Error behaviour of the frame-level entry points: invalid arguments come back as SPLAT_ERR_INVALID with a
+    message, nothing is launched."""
+    lib, ctx = device.lib, device.ctx
+    n, w, h = 1000, 64, 64
+    props, normals, u = make_case(n, w, h, 3, 1.0)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    with pytest.raises(KeyError):
+        r.binner.setFrameOrder("depthFirst")
+    assert lib.splat_bin_set_frame_order(r.binner._b, 7) == -1
+    assert b"argument check failed" in lib.splat_last_error(ctx)
+    out = device.createBuffer(w * h * 4)
+    uf = np.ascontiguousarray(u, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    planes = pm.getPropertyPlanes()
+    cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF)
+    proj = r.projector.getProjectedBuffer().ptr
+    # a missing colour plane
+    assert lib.splat_render_frame_planes(ctx, r.sorter._s, r.binner._b, C.byref(cfg), uf, planes.posRadius.ptr, None, nbuf.ptr, n, w, h,
+                                         proj, out.ptr, None) == -1
+    # the composite only implements 16-pixel tiles, and the cfg must agree with the binner
+    bad = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 32, 0, 0xFFFFFFFF)
+    assert lib.splat_render_frame_planes(ctx, r.sorter._s, r.binner._b, C.byref(bad), uf, planes.posRadius.ptr,
+                                         planes.colorOpacity.ptr, nbuf.ptr, n, w, h, proj, out.ptr, None) == -1
+    # more splats than the sorter was created for
+    assert lib.splat_render_frame_planes(ctx, r.sorter._s, r.binner._b, C.byref(cfg), uf, planes.posRadius.ptr,
+                                         planes.colorOpacity.ptr, nbuf.ptr, 10 * n + 100000, w, h, proj, out.ptr, None) == -4
+    # an unknown record format for the band frame / the composite
+    badfmt = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, 9)
+    assert lib.splat_band_frame(ctx, r.sorter._s, r.binner._b, C.byref(badfmt), pm.getPropertyBuffer().ptr, nbuf.ptr, proj, n, w, h,
+                                out.ptr, None, None) == -1
+    # and after all that a good frame still renders
+    r.render(u, planes, nbuf, None, w, h)
+    assert r.finish() == oracle_pipeline(props, normals, u, w, h)["indices"].shape[0]
+    for o in (r, pm, nbuf, out):
+        o.destroy()
