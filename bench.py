@@ -265,6 +265,27 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         td.all_reduce(ok, op=td.ReduceOp.MIN)
         if ok.item() < 1:
             pipe = None
+    loop_ms = {}
+    if pipe is not None:
+        # which loop is faster on THIS node and rank count is measured, not assumed (a few frames of each,
+        # slowest rank decides, all ranks take the same one): with a cheap exchange the second stream's
+        # events cost more than the overlap returns
+        def timed(fn):
+            torch.cuda.synchronize()
+            td.barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            v = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+            td.all_reduce(v, op=td.ReduceOp.MAX)
+            return float(v.item())
+        trial = 8
+        loop_ms["serial"] = timed(lambda: [frame() for _ in range(trial)]) / trial * 1e3
+        loop_ms["two_frames_in_flight"] = timed(lambda: pipe.run(trial, lambda k: u, pt.data_ptr(), nt.data_ptr())) / trial * 1e3
+        if loop_ms["serial"] <= loop_ms["two_frames_in_flight"]:
+            pipe.destroy()
+            pipe = None
     stages.overflows = 0
     stages.consumed = torch.zeros(ntx * nty, dtype=torch.int64, device="cuda")  # per tile (no atomics in the kernel)
     stages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
@@ -309,6 +330,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
                    "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * 16} B "
                                   f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
                                                           "all-gather run on a second stream under this frame's band work"),
+                   "frame_loop_trial_ms": {k: round(v, 4) for k, v in loop_ms.items()},
                    "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
                                  "composite_ms": i[4] / 1e6} for i in infos],
                    "composite": "front-to-back, early-out at alpha>=0.99"},
