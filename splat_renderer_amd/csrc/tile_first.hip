@@ -145,8 +145,24 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     __shared__ uint32_t s_key[TF_BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t first = blockIdx.x * TF_BLOCK;
-    // digit starts = exclusive scan of the digit totals; their sum is this frame's pair total
+    // every global load of the prologue is issued before anything waits on one: the block's ranges and
+    // keys, the digit totals, and this block's row of scanned histogram (measured per phase, a workgroup
+    // spent 15 % of its life on the totals alone when they were loaded, scanned and waited for first)
+    static_assert(TF_PER_THREAD == 4, "uint4 loads");
+    const uint32_t i0 = first + tid * 4; // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
+    uint4 rr = make_uint4(1u, 1u, 1u, 1u), kk = make_uint4(0, 0, 0, 0); // 1 = empty range
+    if (i0 + 3 < n) {
+        rr = reinterpret_cast<const uint4 *>(range32)[i0 >> 2];
+        kk = reinterpret_cast<const uint4 *>(depth_keys)[i0 >> 2];
+    } else {
+        if (i0 < n) { rr.x = range32[i0]; kk.x = depth_keys[i0]; }
+        if (i0 + 1 < n) { rr.y = range32[i0 + 1]; kk.y = depth_keys[i0 + 1]; }
+        if (i0 + 2 < n) { rr.z = range32[i0 + 2]; kk.z = depth_keys[i0 + 2]; }
+    }
     const uint32_t digit_total = totals[tid];
+    const uint32_t row_prefix = tid <= mask ? scanned_hist[(size_t)tid * num_parts + blockIdx.x] : 0u;
+
+    // digit starts = exclusive scan of the digit totals; their sum is this frame's pair total
     uint32_t gincl = digit_total;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -165,25 +181,11 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     if (all_pairs > pair_limit) return;
     __syncthreads(); // wave_sums is reused below
 
-    // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
-    static_assert(TF_PER_THREAD == 4, "uint4 loads");
     uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
-    {
-        const uint32_t i0 = first + tid * 4;
-        uint4 rr = make_uint4(1u, 1u, 1u, 1u), kk = make_uint4(0, 0, 0, 0); // 1 = empty range
-        if (i0 + 3 < n) {
-            rr = reinterpret_cast<const uint4 *>(range32)[i0 >> 2];
-            kk = reinterpret_cast<const uint4 *>(depth_keys)[i0 >> 2];
-        } else {
-            if (i0 < n) { rr.x = range32[i0]; kk.x = depth_keys[i0]; }
-            if (i0 + 1 < n) { rr.y = range32[i0 + 1]; kk.y = depth_keys[i0 + 1]; }
-            if (i0 + 2 < n) { rr.z = range32[i0 + 2]; kk.z = depth_keys[i0 + 2]; }
-        }
-        reinterpret_cast<uint4 *>(s_key)[tid] = kk;
-        r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
+    reinterpret_cast<uint4 *>(s_key)[tid] = kk;
+    r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
 #pragma unroll
-        for (uint32_t k = 0; k < TF_PER_THREAD; ++k) h[k] = range32_hits(r[k]);
-    }
+    for (uint32_t k = 0; k < TF_PER_THREAD; ++k) h[k] = range32_hits(r[k]);
     // offsets of every splat's pairs inside the block, in ascending splat index: one block scan of the
     // per-thread totals, then the thread's own running sum
     uint32_t off[TF_PER_THREAD];
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     const uint32_t total = carry;
     if (total == 0) return;
     // where this block's pairs of digit tid start: digit start + the earlier blocks' share
-    sh.global_base[tid] = gprefix + gincl - digit_total + (tid <= mask ? scanned_hist[(size_t)tid * num_parts + blockIdx.x] : 0u);
+    sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix;
     // rounds of TF_STAGE pairs (one round unless the block's splats are unusually large)
     for (uint32_t c0 = 0; c0 < total; c0 += TF_STAGE) {
         const uint32_t cnt = (total - c0 < TF_STAGE) ? total - c0 : TF_STAGE;
