@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplat_hip.so")
+# SPLAT_LIB_PATH: another build of the library (developer hook for same-box A/B runs of two kernel versions)
+LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 
 OK = 0
 ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -6: "NO_DEVICE", -7: "COMM"}
