@@ -104,10 +104,8 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
             range32[i] = pack_range32(ok, tx0, tx1, ty0, ty1);
             keys_by_idx[i] = depth_key_of(depth);
             if (ok) {
-                for (uint32_t ty = ty0; ty <= ty1; ++ty)
-                    for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * bp.ntx + tx) & ho.mask], 1u);
                 kept += 1u;
-                pairs += (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                pairs += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
             }
         }
     }

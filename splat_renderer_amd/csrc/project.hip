@@ -143,9 +143,7 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
         const uint32_t r = project_one<true, true>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
-        for (uint32_t ty = ty0; ty <= ty1; ++ty)
-            for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&lh[w][(ty * bp.ntx + tx) & ho.mask], 1u);
-        local += (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+        local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
@@ -199,13 +197,17 @@ __global__ __launch_bounds__(256) void k_props_to_planes(const float4 *__restric
     color_opacity[i] = props[(size_t)i * 2 + 1];
 }
 
+static void load_uniforms(FrameUniforms &u, const float *uniforms) {
+    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
+    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
+    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
+}
+
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
                    const BinParams *bp, const TfHistOut *hist_out) {
     FrameUniforms u;
-    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
-    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
-    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
+    load_uniforms(u, uniforms);
     const uint32_t work = keys ? n_padded : n;
     if (work == 0) return SPLAT_OK;
     BinParams none = {0, 0, 1, 0, 0, 0, 0};
@@ -251,11 +253,6 @@ int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_r
                           nullptr, nullptr);
 }
 
-static void load_uniforms(FrameUniforms &u, const float *uniforms) {
-    for (int i = 0; i < 16; ++i) u.m[i] = uniforms[i];
-    u.eye[0] = uniforms[16]; u.eye[1] = uniforms[17]; u.eye[2] = uniforms[18];
-    u.time = uniforms[19]; u.w = uniforms[20]; u.h = uniforms[21];
-}
 
 int splat_project_slice_compact(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4,
                                 uint32_t first, uint32_t count, void *records16_slice) {

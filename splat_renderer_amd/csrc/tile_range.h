@@ -42,3 +42,12 @@ __device__ __forceinline__ bool tile_range(float4 bounds, uint32_t width, uint32
 __device__ __forceinline__ uint32_t pack_range32(bool ok, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1) {
     return ok ? (tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24)) : 1u;
 }
+
+// First sort pass's histogram (tile_first.hip): one count per tile of the rectangle, keyed by the low
+// tile-id digit, into a wave-private 256-counter LDS histogram.  Returns the number of tiles.
+__device__ __forceinline__ uint32_t hist_add_rect(uint32_t *wave_hist, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1,
+                                                  uint32_t ntx, uint32_t mask) {
+    for (uint32_t ty = ty0; ty <= ty1; ++ty)
+        for (uint32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&wave_hist[(ty * ntx + tx) & mask], 1u);
+    return (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+}
