@@ -28,16 +28,17 @@ from splat_renderer_amd import _lib, dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
 
 
-def composite_alg_bytes(p_used, width, height):
+def composite_alg_bytes(p_used, width, height, prelit=False):
     """per consumed list entry 4 (idx) + 32 (ProjectedSplat) + 16 (colour vec4) +
-    16 (normal vec4) = 68 B, plus 4 B per rgba8 pixel written."""
-    return 68 * p_used + 4 * width * height
+    16 (normal vec4) = 68 B, plus 4 B per rgba8 pixel written.  With a pre-lit colour plane the normal
+    is not read: 52 B per entry (the kernel is credited only with what it moves)."""
+    return (52 if prelit else 68) * p_used + 4 * width * height
 
 
-def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height):
+def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height, prelit=False):
     """SURVEY §8d whole-frame model: project+key 56N, sort 68Np, count 20N, scan 8T, fill 20N+4P,
-    composite 68 P_used + 4WH."""
-    return 56 * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height)
+    composite (68 or 52) P_used + 4WH."""
+    return 56 * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height, prelit)
 
 
 def cpu_baseline(name, props, normals, u, width, height):
@@ -147,9 +148,10 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     lib, ctx = dev.lib, dev.ctx
     pm = sr.SplatPropertyManager(dev, n)
     pm.setFromArrays(props)
-    # the native layout (two vec4 planes, what updatePlanesFromCurvature writes) unless asked for the reference's records
-    pbuf = pm.getPropertyPlanes() if args.layout == "planes" else pm.getPropertyBuffer()
     nbuf = dev.createBufferFrom(normals)
+    # the native layout unless asked for the reference's records: two vec4 planes (what updatePlanesFromCurvature
+    # writes), the colour plane carrying the reference's shading (once per property update, not per list entry)
+    pbuf = pm.getLitPlanes(nbuf) if args.layout == "planes" else pm.getPropertyBuffer()
     r = sr.Renderer(dev, None, "rgba8unorm", n, tile)
 
     def frame():
@@ -189,10 +191,11 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     pairs = r.binner.getTotalIndices()
 
     copy_gbs = measured_copy_ceiling(dev)
-    comp_bytes = composite_alg_bytes(p_used, width, height)
+    prelit = args.layout == "planes"
+    comp_bytes = composite_alg_bytes(p_used, width, height, prelit)
     comp_s = stage_ms["composite"] / 1e3
     achieved = comp_bytes / comp_s / 1e9
-    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height)
+    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, prelit)
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
         "frames_per_s": args.steps / dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -200,7 +203,8 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
                    "pairs_P": pairs, "pairs_consumed_P_used": round(p_used), "parallelism": "1 GPU",
-                   "property_layout": "two vec4 planes (pos,radius | rgb,opacity)" if args.layout == "planes" else "interleaved 32-byte records (reference layout)",
+                   "property_layout": ("two vec4 planes (pos,radius | lit rgb,opacity): shading kd(normal) applied once per property update"
+                                       if args.layout == "planes" else "interleaved 32-byte records (reference layout), shading in the composite"),
                    "frame_order": os.environ.get("SPLAT_FRAME_ORDER", "tile-first (bin, then depth-sort per tile; library default)"),
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -240,6 +244,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     pt = torch.from_numpy(props).cuda()
     nt = torch.from_numpy(normals).cuda()
     br = dist.BandRenderer(stages, n, width, height, rank, world, td.all_gather_into_tensor, tile)
+    if args.layout == "planes":  # as at N=1: shading applied once per property update, not per staged list entry
+        stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
 
     def frame():
         br.render(u, pt.data_ptr(), nt.data_ptr())
@@ -319,7 +325,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     # roofline of the dominant kernel on the slowest rank's composite (per launch = per band)
     slow = max(range(world), key=lambda k: infos[k][4])
     rows_px = min(infos[slow][2] * tile, height) - infos[slow][1] * tile
-    comp_bytes = composite_alg_bytes(infos[slow][3], width, rows_px)
+    comp_bytes = composite_alg_bytes(infos[slow][3], width, rows_px, stages.lit is not None)
     achieved = comp_bytes / (infos[slow][4] / 1e9) / 1e9 if infos[slow][4] else 0.0
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",

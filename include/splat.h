@@ -210,13 +210,20 @@ typedef struct splat_composite_cfg {
     uint32_t record_format; /* what `projected` / `records` point at: SPLAT_RECORDS_PROJECTED (32-byte
                              * ProjectedSplat, the reference's struct) or SPLAT_RECORDS_COMPACT (16-byte
                              * exchange records, see splat_project_slice_compact) */
-    uint32_t reserved[2];
+    uint32_t prelit;        /* 1 = color_opacity holds LIT colours (splat_lit_colors): the composite then gathers two
+                             * lines per staged entry instead of three and does not read normals (may be NULL) */
+    uint32_t reserved[1];
 } splat_composite_cfg;
 /* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
  * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;
  * only pixels of the rendered tile rows are written.  consumed_dptr (optional): u64[ceil(W/16) *
  * ceil(H/16)], one counter per tile; a rendered tile's counter is incremented by the number of its
  * list entries staged before the tile saturated (their sum over tiles is P_used). */
+/* The reference shades every splat with kd = 0.85 + 0.15 * max(dot(normal, (1,1,1)/sqrt 3), 0)
+ * (src/ComputeShaderRenderer.ts:143-145).  lit[i] = vec4(rgb * kd, opacity): computed once per property
+ * update instead of once per staged entry; the same bits either way (explicitly rounded operations). */
+int splat_lit_colors(splat_ctx *ctx, const void *color_opacity, uint32_t color_stride_vec4,
+                     const void *normals, uint32_t normal_stride_vec4, uint32_t n, void *lit);
 int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity,
                     uint32_t color_stride_vec4, const void *normals, uint32_t normal_stride_vec4,
                     const void *projected, const void *tile_indices, const void *tile_counts,
@@ -267,7 +274,8 @@ int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected,
  * outside it has an empty range — then the frame's binner and per-tile sort; sort-first order: band
  * filter (kept count on the device) -> depth sort -> bin.  records: n_records records in
  * cfg->record_format whose position is the global splat index (the all-gathered shards);
- * props/normals: the full scene in the reference's layouts (props = interleaved records). */
+ * props/normals: the full scene in the reference's layouts (props = interleaved records); with
+ * cfg->prelit, props is the plane of lit colours (splat_lit_colors) and normals may be NULL. */
 int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                      const splat_composite_cfg *cfg, const void *props, const void *normals,
                      const void *records, uint32_t n_records, uint32_t width, uint32_t height,

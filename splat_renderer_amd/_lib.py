@@ -29,7 +29,7 @@ class SplatError(RuntimeError):
 class CompositeCfg(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("early_out", C.c_uint32), ("tile_size", C.c_uint32),
                 ("tile_row0", C.c_uint32), ("tile_row1", C.c_uint32), ("record_format", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("prelit", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 # name -> (restype, argtypes); the single source of truth checked against include/splat.h by
@@ -82,6 +82,7 @@ SIGNATURES = {
     "splat_bin_set_frame_order": (_i, [_vp, _i]),
     "splat_bin_dims": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "splat_validate_tile_order": (_i, [_vp, _vp, _vp, _u32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "splat_lit_colors": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, _vp]),
     "splat_composite": (_i, [_vp, C.POINTER(CompositeCfg), _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _u32,
                              _vp, _vp, _vp]),
     "splat_render_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), C.POINTER(C.c_float), _vp, _vp, _u32, _u32,

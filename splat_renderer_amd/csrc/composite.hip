@@ -34,6 +34,7 @@ struct CompositeParams {
     const float4 *normals; uint32_t normal_stride; // vec4(normal, scaleFactor)
     const float4 *projected;                       // 2 x float4 per splat (ProjectedSplat), or 1 x float4 (compact exchange record)
     uint32_t compact;
+    uint32_t prelit;                               // color holds lit colours (k_lit_colors): normals are not read
     const uint32_t *indices, *counts, *offsets;
     uint32_t width, height, ntx, tile_row0;
     uint32_t *out_rgba8;
@@ -76,14 +77,38 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+// The reference's shading of one splat (ComputeShaderRenderer.ts:143-145): colour scaled by
+// kd = 0.85 + 0.15 * max(dot(normal, normalize(1,1,1)), 0).  Contraction is switched off for this function:
+// one IEEE operation per operator, so the bits are the oracle's, and the same whether it runs per staged
+// entry in the composite or once per splat in k_lit_colors (the rest of this file is compiled with
+// contraction on, and two call sites would otherwise be free to fuse differently).
+__device__ __forceinline__ float4 lit_color(float4 c, float4 nrm) {
+#pragma clang fp contract(off) // (HIP's __fmul_rn / __fadd_rn are plain operators and would be contracted like any other)
+    const float k = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
+    const float ndl = (nrm.x * k + nrm.y * k) + nrm.z * k;
+    const float kd = 0.85f + 0.15f * fmaxf(ndl, 0.0f); // :144-145
+    return make_float4(c.x * kd, c.y * kd, c.z * kd, c.w);
+}
+
+// The lit colours of all splats as a plane: when the composite is given this plane (cfg->prelit) it
+// gathers two lines per staged entry (record, lit colour) instead of three (record, colour, normal) —
+// the gathers, not the arithmetic, are what a staged entry costs (108 -> 93 us at C2 for one line less).
+__global__ __launch_bounds__(256) void k_lit_colors(const float4 *__restrict__ color, uint32_t color_stride,
+                                                    const float4 *__restrict__ normals, uint32_t normal_stride, uint32_t n,
+                                                    float4 *__restrict__ lit) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) lit[i] = lit_color(color[(size_t)i * color_stride], normals[(size_t)i * normal_stride]);
+}
+
 // bounds and screen radius of splat idx.  Compact exchange records (multi-GPU frame) carry {centre x,
 // y, radius, depth}: the bounds are rebuilt exactly as the projector forms them (SplatProjector.ts:
-// 119-121) — with explicitly rounded operations, because this file is compiled with contraction on.
+// 119-121) — with contraction switched off for this function (the file is compiled with it on).
 __device__ __forceinline__ void fetch_record(const CompositeParams &p, uint32_t idx, float4 &bounds, float &radius) {
+#pragma clang fp contract(off) // the bounds must be the projector's: one rounding per operation
     if (p.compact) {
         const float4 c = p.projected[idx];
-        const float padded = __fmul_rn(c.z, 1.5f);
-        bounds = make_float4(__fsub_rn(c.x, padded), __fsub_rn(c.y, padded), __fadd_rn(c.x, padded), __fadd_rn(c.y, padded));
+        const float padded = c.z * 1.5f;
+        bounds = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
         radius = c.z;
     } else {
         bounds = p.projected[(size_t)idx * 2];
@@ -117,7 +142,6 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     unsigned long long live = uniform64(__ballot(pixel_ok));
     if (tid < 4) s_wave_done[tid] = 0;
 
-    const float inv_sqrt3 = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
     uint32_t staged = 0;
 
     // ---- list-entry fetch, split from its use (issue early / write LDS late).  Almost every tile
@@ -150,20 +174,17 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 if (f_idx != 0xffffffffu) {
                     fetch_record(p, f_idx, f_b, f_r);
                     f_c = p.color[(size_t)f_idx * p.color_stride];
-                    f_n = p.normals[(size_t)f_idx * p.normal_stride];
+                    if (!p.prelit) f_n = p.normals[(size_t)f_idx * p.normal_stride];
                 }
             }
             if (f_idx != 0xffffffffu) {
                 const float4 b = f_b;
                 const float r = f_r;
                 if (!(r < 0.5f)) { // :127-129 "too small"
-                    const float4 c = f_c;
-                    const float4 nrm = f_n;
-                    const float ndl = (nrm.x * inv_sqrt3 + nrm.y * inv_sqrt3) + nrm.z * inv_sqrt3;
-                    const float kd = 0.85f + 0.15f * fmaxf(ndl, 0.0f); // :144-145
-                    col = make_float2(c.x * kd, c.y * kd);
+                    const float4 c = p.prelit ? f_c : lit_color(f_c, f_n);
+                    col = make_float2(c.x, c.y);
                     // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(dist^2 * scale)
-                    geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), c.z * kd); // :124
+                    geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), c.z); // :124
                     xm = span_mask16(b.x, b.z, tile_cx);
                     ym = span_mask16(b.y, b.w, tile_cy);
                 }
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     if (f_idx != 0xffffffffu) {
                         fetch_record(p, f_idx, f_b, f_r);
                         f_c = p.color[(size_t)f_idx * p.color_stride];
-                        f_n = p.normals[(size_t)f_idx * p.normal_stride];
+                        if (!p.prelit) f_n = p.normals[(size_t)f_idx * p.normal_stride];
                     }
                     f_ready = true;
                 }
@@ -282,6 +303,19 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     }
 }
 
+extern "C" int splat_lit_colors(splat_ctx *ctx, const void *color_opacity, uint32_t color_stride_vec4, const void *normals,
+                                uint32_t normal_stride_vec4, uint32_t n, void *lit) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, n == 0 || (color_opacity && normals && lit));
+    ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
+    ARG_CHECK(ctx, (((uintptr_t)color_opacity | (uintptr_t)normals | (uintptr_t)lit) & 15) == 0);
+    if (n == 0) return SPLAT_OK;
+    hipLaunchKernelGGL(k_lit_colors, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, (const float4 *)color_opacity, color_stride_vec4,
+                       (const float4 *)normals, normal_stride_vec4, n, (float4 *)lit);
+    LAUNCH_CHECK(ctx, "k_lit_colors");
+    return SPLAT_OK;
+}
+
 extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity,
                                uint32_t color_stride_vec4, const void *normals, uint32_t normal_stride_vec4,
                                const void *projected, const void *tile_indices, const void *tile_counts,
@@ -293,10 +327,11 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     ARG_CHECK(ctx, cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK || cfg->mode == SPLAT_COMPOSITE_REFERENCE_LITERAL);
     ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_COMPACT);
     ARG_CHECK(ctx, width >= 1 && height >= 1 && width <= 65535u * CT && height <= 65535u * CT);
-    ARG_CHECK(ctx, color_opacity && normals && projected && tile_indices && tile_counts && tile_offsets);
+    ARG_CHECK(ctx, color_opacity && (normals || cfg->prelit) && projected && tile_indices && tile_counts && tile_offsets);
     ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
     ARG_CHECK(ctx, out_rgba8 || out_rgba32f);
     ARG_CHECK(ctx, (((uintptr_t)color_opacity | (uintptr_t)normals | (uintptr_t)projected | (uintptr_t)out_rgba32f) & 15) == 0);
+    ARG_CHECK(ctx, cfg->prelit <= 1);
     const uint32_t ntx = div_up(width, CT), nty = div_up(height, CT);
     uint32_t r0 = cfg->tile_row0, r1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (r0 >= r1) return SPLAT_OK;
@@ -307,6 +342,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.normal_stride = normal_stride_vec4;
     p.projected = (const float4 *)projected;
     p.compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
+    p.prelit = cfg->prelit != 0;
     p.indices = (const uint32_t *)tile_indices;
     p.counts = (const uint32_t *)tile_counts;
     p.offsets = (const uint32_t *)tile_offsets;

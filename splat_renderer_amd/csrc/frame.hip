@@ -229,8 +229,11 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                      const void *props, const void *normals, const void *records, uint32_t n_records, uint32_t width,
                      uint32_t height, void *out_rgba8, void *out_rgba32f, void *consumed_dptr) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ARG_CHECK(ctx, sorter && binner && cfg && props && normals && (n_records == 0 || records));
+    ARG_CHECK(ctx, sorter && binner && cfg && props && (normals || cfg->prelit) && (n_records == 0 || records));
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner) && width >= 1 && height >= 1);
+    // colours: the second vec4 of the reference's interleaved records, or (cfg->prelit) `props` IS the plane of lit colours
+    const void *band_color = cfg->prelit ? props : (const void *)((const char *)props + 16);
+    const uint32_t band_color_stride = cfg->prelit ? 1u : 2u;
     const uint32_t tile = cfg->tile_size, nty = div_up(height, tile);
     uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (row0 > row1) row0 = row1;
@@ -285,7 +288,7 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         splat_composite_cfg c2 = *cfg;
         c2.tile_row0 = row0;
         c2.tile_row1 = row1;
-        return splat_composite(ctx, &c2, (const char *)props + 16, 2, normals, 1, records, binner->pairs.payload, binner->counts,
+        return splat_composite(ctx, &c2, band_color, band_color_stride, normals, 1, records, binner->pairs.payload, binner->counts,
                                binner->offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr);
     }
     sorter->kept_blocks = 0;
@@ -350,7 +353,7 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     splat_composite_cfg c2 = *cfg;
     c2.tile_row0 = row0;
     c2.tile_row1 = row1;
-    return splat_composite(ctx, &c2, (const char *)props + 16, 2, normals, 1, records, indices, binner->counts, binner->offsets, width,
+    return splat_composite(ctx, &c2, band_color, band_color_stride, normals, 1, records, indices, binner->counts, binner->offsets, width,
                            height, out_rgba8, out_rgba32f, consumed_dptr);
 }
 
@@ -399,7 +402,7 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
                              uint32_t color_stride, const void *normals, uint32_t n, uint32_t width, uint32_t height,
                              void *projected, void *out_rgba8, void *out_rgba32f) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && color && normals && projected);
+    ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && color && (normals || cfg->prelit) && projected);
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner));
     if (n > splat_sort_capacity(sorter)) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_render_frame: n exceeds the sorter's capacity");
     ARG_CHECK(ctx, width >= 1 && height >= 1);

@@ -97,6 +97,14 @@ class HipStages:
         self.pairs = 0
         self.overflows = 0
         self.consumed = None  # optional torch int64[tiles]: per tile, list entries staged by the composite
+        self.lit = None       # optional torch float32[n,4]: lit colour plane (set_lit); band_frame then ignores props/normals
+
+    def set_lit(self, props_ptr, normals_ptr, n):
+        """Shade every splat once (kd from its normal) into a colour plane: the composite then gathers two
+        lines per staged entry instead of three.  Call again when properties or normals change."""
+        if self.lit is None or self.lit.shape[0] != n:
+            self.lit = self.torch.empty((n, 4), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
+        check(self.lib.splat_lit_colors(self.ctx, props_ptr + 16, 2, normals_ptr, 1, n, self.lit.data_ptr()), self.ctx)
 
     def set_timing(self, enabled, stage_mask=0xFFFFFFFF):
         check(self.lib.splat_set_timing_stages(self.ctx, stage_mask), self.ctx)
@@ -134,7 +142,10 @@ class HipStages:
         """settle=False (frame loops): sync-free; a frame whose pairs outgrew 1.5x the previous frame's
         is only noticed at the next call (which then has room).  settle=True: wait for this frame's pair
         total and render it again if it overflowed — results are final on return."""
-        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1, _lib.RECORDS_COMPACT)
+        prelit = self.lit is not None
+        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1, _lib.RECORDS_COMPACT, int(prelit))
+        if prelit:
+            props_ptr, normals_ptr = self.lit.data_ptr(), None
         args = (self.ctx, self.sorter, self.binner, C.byref(cfg), props_ptr, normals_ptr, records.data_ptr(), n_records,
                 self.width, self.height, out_image.data_ptr(), None,
                 self.consumed.data_ptr() if self.consumed is not None else None)

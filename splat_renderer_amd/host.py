@@ -186,13 +186,15 @@ class PointManager:
 
 
 class PropertyPlanes:
-    """Two device planes of vec4 per splat: (pos, radius) and (rgb, opacity)."""
+    """Two device planes of vec4 per splat: (pos, radius) and (rgb, opacity).  prelit: the colour plane
+    already carries the reference's shading (SplatPropertyManager.getLitPlanes)."""
 
-    def __init__(self, posRadius, colorOpacity):
-        self.posRadius, self.colorOpacity = posRadius, colorOpacity
+    def __init__(self, posRadius, colorOpacity, prelit=False, ownsPosRadius=True):
+        self.posRadius, self.colorOpacity, self.prelit, self._owns_pos = posRadius, colorOpacity, prelit, ownsPosRadius
 
     def destroy(self):
-        self.posRadius.destroy()
+        if self._owns_pos:
+            self.posRadius.destroy()
         self.colorOpacity.destroy()
 
 
@@ -208,17 +210,20 @@ class SplatPropertyManager:
         data[:, 7] = 0.7
         self.propertyBuffer.write(data)
         self._planes, self._planes_valid = None, False
+        self._lit, self._lit_valid, self._lit_normals = None, False, None
 
     def updateFromCurvature(self, commandEncoder, positionBuffer, curvatureBuffer):  # :153-173
         d = self.device
         check(d.lib.splat_update_props(d.ctx, positionBuffer.ptr, curvatureBuffer.ptr, self.numSplats,
                                        self.propertyBuffer.ptr), d.ctx)
         self._planes_valid = False
+        self._lit_valid = False
 
     def setFromArrays(self, props):
         """Synthetic scenes: upload (n,8) interleaved records directly."""
         self.propertyBuffer.write(np.ascontiguousarray(props, np.float32))
         self._planes_valid = False
+        self._lit_valid = False
 
     def getPropertyBuffer(self):  # :175-177
         return self.propertyBuffer
@@ -237,16 +242,40 @@ class SplatPropertyManager:
             self._planes_valid = True
         return self._planes
 
+    def getLitPlanes(self, normalsBuffer):
+        """The planes with the colour plane already lit by `normalsBuffer` — kd = 0.85 + 0.15 max(n.l, 0)
+        (src/ComputeShaderRenderer.ts:143-145) applied once per property update instead of once per staged
+        list entry: the composite then gathers two lines per entry (record, lit colour) instead of three.
+        Same bits as shading in the composite.  Recomputed when the properties or the normals buffer change
+        (call invalidateLighting() after rewriting the normals in place)."""
+        d = self.device
+        planes = self.getPropertyPlanes()
+        if getattr(self, "_lit", None) is None:
+            self._lit = PropertyPlanes(planes.posRadius, d.createBuffer(self.numSplats * 16), prelit=True, ownsPosRadius=False)
+            self._lit_valid = False
+        if not self._lit_valid or self._lit_normals != normalsBuffer.ptr:
+            check(d.lib.splat_lit_colors(d.ctx, planes.colorOpacity.ptr, 1, normalsBuffer.ptr, 1, self.numSplats,
+                                         self._lit.colorOpacity.ptr), d.ctx)
+            self._lit_valid, self._lit_normals = True, normalsBuffer.ptr
+        return self._lit
+
+    def invalidateLighting(self):
+        self._lit_valid = False
+
     def updatePlanesFromCurvature(self, commandEncoder, positionBuffer, curvatureBuffer):
         """updateFromCurvature writing the two planes directly (no interleaved copy is touched)."""
         d = self.device
         planes = self.getPropertyPlanes()
         check(d.lib.splat_update_props_planes(d.ctx, positionBuffer.ptr, curvatureBuffer.ptr, self.numSplats,
                                               planes.posRadius.ptr, planes.colorOpacity.ptr), d.ctx)
+        self._lit_valid = False
         return planes
 
     def destroy(self):  # :179-181
         self.propertyBuffer.destroy()
+        if getattr(self, "_lit", None) is not None:
+            self._lit.destroy()
+            self._lit = None
         if getattr(self, "_planes", None) is not None:
             self._planes.destroy()
             self._planes = None
@@ -604,8 +633,9 @@ class Renderer:
             self._wh = (width, height)
         if wantFloat and self.outputFloat is None:
             self.outputFloat = d.createBuffer(width * height * 16)
-        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1])
-        tail = (normalsBuffer.ptr, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
+        prelit = isinstance(propertyBuffer, PropertyPlanes) and propertyBuffer.prelit
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], 0, int(prelit))
+        tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
                 self.outputFloat.ptr if wantFloat else None)
         head = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)))
         if isinstance(propertyBuffer, PropertyPlanes):  # the native layout: SplatPropertyManager.getPropertyPlanes()

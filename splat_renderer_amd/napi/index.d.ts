@@ -13,8 +13,8 @@ export class Camera {
   setAspect(aspect: number): void; rotate(deltaAzimuth: number, deltaElevation: number): void; zoom(deltaDistance: number): void;
   getViewProjectionMatrix(): Float32Array; getPosition(): Float32Array; uniforms(width: number, height: number, time?: number): Float32Array;
 }
-export interface PropertyPlanes { posRadius: Buffer; colorOpacity: Buffer; isPlanes: true; }
-export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; updatePlanesFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): PropertyPlanes; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; getPropertyPlanes(): PropertyPlanes; destroy(): void; }
+export interface PropertyPlanes { posRadius: Buffer; colorOpacity: Buffer; isPlanes: true; prelit?: boolean; }
+export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; updatePlanesFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): PropertyPlanes; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; getPropertyPlanes(): PropertyPlanes; getLitPlanes(normalsBuffer: Buffer): PropertyPlanes; destroy(): void; }
 export class SplatProjector { constructor(device: Device, numSplats: number); project(enc: CommandEncoder | null, uniformBuffer: Buffer | Float32Array, splatPropertyBuffer: Buffer, keysBuffer?: Buffer | null, payloadBuffer?: Buffer | null, paddedSize?: number): void; getProjectedBuffer(): Buffer; destroy(): void; }
 export class DepthKeyExtractor { constructor(device: Device); extract(enc: CommandEncoder | null, projectedBuffer: Buffer, keysBuffer: Buffer, payloadBuffer: Buffer, numSplats: number, paddedSize: number): void; cleanupTempBuffers(): void; }
 export class RadixSorter { constructor(device: Device, numSplats: number); readonly paddedSize: number; sort(numKeys?: number, bitBegin?: number, bitEnd?: number): void; getSortedIndicesBuffer(): Buffer; getKeysBuffer(): Buffer; getPayloadBuffer(): Buffer; cleanupTempBuffers(): void; destroy(): void; }

@@ -66,15 +66,26 @@ class SplatPropertyManager {
   }
   updateFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) { // :153-173
     native.update_props(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, this.propertyBuffer.ptr);
-    this.planesValid = false;
+    this.planesValid = false; this.litValid = false;
   }
-  setFromArrays(props) { this.propertyBuffer.write(props); this.planesValid = false; }
+  setFromArrays(props) { this.propertyBuffer.write(props); this.planesValid = false; this.litValid = false; }
   getPropertyBuffer() { return this.propertyBuffer; } // :175-177
   // the MI355X-native layout: two vec4 planes {posRadius, colorOpacity}; Renderer.render takes either
   getPropertyPlanes() {
     if (!this.planes) this.planes = { posRadius: this.device.createBuffer(this.numSplats * 16), colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true };
     if (!this.planesValid) { native.props_to_planes(this.device.ctx, this.propertyBuffer.ptr, this.numSplats, this.planes.posRadius.ptr, this.planes.colorOpacity.ptr); this.planesValid = true; }
     return this.planes;
+  }
+  // the planes with the colour plane already lit by the given normals (kd = 0.85 + 0.15 max(n.l, 0), once per
+  // property update instead of once per staged list entry): the frame then gathers one line less per entry
+  getLitPlanes(normalsBuffer) {
+    const p = this.getPropertyPlanes();
+    if (!this.lit) this.lit = { posRadius: p.posRadius, colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true, prelit: true };
+    if (!this.litValid || this.litNormals !== normalsBuffer.ptr) {
+      native.lit_colors(this.device.ctx, p.colorOpacity.ptr, 1, normalsBuffer.ptr, 1, this.numSplats, this.lit.colorOpacity.ptr);
+      this.litValid = true; this.litNormals = normalsBuffer.ptr;
+    }
+    return this.lit;
   }
   updatePlanesFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) {
     const p = this.getPropertyPlanes();
@@ -84,6 +95,7 @@ class SplatPropertyManager {
   destroy() { // :179-181
     this.propertyBuffer.destroy();
     if (this.planes) { this.planes.posRadius.destroy(); this.planes.colorOpacity.destroy(); this.planes = null; }
+    if (this.lit) { this.lit.colorOpacity.destroy(); this.lit = null; }
   }
 }
 
@@ -236,7 +248,7 @@ class Renderer {
     let u = uniformFloats(uniformData);
     if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
     if (this.width !== width || this.height !== height) { if (this.output) this.output.destroy(); this.output = this.device.createBuffer(width * height * 4); this.width = width; this.height = height; }
-    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX];
+    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, 0, propertyBuffer.prelit ? 1 : 0];
     if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
       native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,
         normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);

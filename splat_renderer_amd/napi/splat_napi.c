@@ -177,6 +177,11 @@ FN(props_to_planes) { /* (ctx, props, n, posRadius, colorOpacity) */
     void *pr = arg_dptr(&c, 3), *co = arg_dptr(&c, 4); BAIL;
     return check(env, x, splat_props_to_planes(x, props, n, pr, co), mk_undefined(env));
 }
+FN(lit_colors) { /* (ctx, colorOpacity, cStride, normals, nStride, n, lit) */
+    ARGS(7); splat_ctx *x = arg_external(&c, 0); void *col = arg_dptr(&c, 1); uint32_t cs = (uint32_t)arg_number(&c, 2);
+    void *nrm = arg_dptr(&c, 3); uint32_t ns = (uint32_t)arg_number(&c, 4), n = (uint32_t)arg_number(&c, 5); void *lit = arg_dptr(&c, 6); BAIL;
+    return check(env, x, splat_lit_colors(x, col, cs, nrm, ns, n, lit), mk_undefined(env));
+}
 FN(project) { /* (ctx, Float32Array(22), posRadius, strideVec4, n, projected, keys|null, payload|null, nPadded) */
     ARGS(9); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
     void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3), n = (uint32_t)arg_number(&c, 4);
@@ -244,18 +249,19 @@ FN(validate_tile_order) { /* (ctx, projected, offsets, numTiles, indices, totalP
     uint64_t v = 0; int rc = splat_validate_tile_order(x, proj, off, nt, idx, total, &v);
     return check(env, x, rc, mk_number(env, (double)v));
 }
-static void fill_cfg(call_t *c, size_t i, splat_composite_cfg *cfg) { /* [mode, earlyOut, tile, row0, row1] */
+static void fill_cfg(call_t *c, size_t i, splat_composite_cfg *cfg) { /* [mode, earlyOut, tile, row0, row1, recordFormat?, prelit?] */
     memset(cfg, 0, sizeof *cfg);
-    uint32_t v[5] = {0, 1, 16, 0, 0xffffffffu};
+    uint32_t v[7] = {0, 1, 16, 0, 0xffffffffu, 0, 0};
     bool is = false;
     napi_is_array(c->env, c->argv[i], &is);
     if (is)
-        for (uint32_t k = 0; k < 5; ++k) {
+        for (uint32_t k = 0; k < 7; ++k) {
             napi_value e;
             double d;
             if (napi_get_element(c->env, c->argv[i], k, &e) == napi_ok && napi_get_value_double(c->env, e, &d) == napi_ok) v[k] = (uint32_t)d;
         }
     cfg->mode = v[0]; cfg->early_out = v[1]; cfg->tile_size = v[2]; cfg->tile_row0 = v[3]; cfg->tile_row1 = v[4];
+    cfg->record_format = v[5]; cfg->prelit = v[6];
 }
 FN(composite) { /* (ctx, cfg[5], color, cStride, normals, nStride, projected, indices, counts, offsets, W, H, out8|null, outF|null) */
     ARGS(14); splat_ctx *x = arg_external(&c, 0); splat_composite_cfg cfg; fill_cfg(&c, 1, &cfg);
@@ -287,7 +293,7 @@ static napi_value init(napi_env env, napi_value exports) {
 #define EXPORT(name) { #name, NULL, name, NULL, NULL, NULL, napi_enumerable, NULL }
     napi_property_descriptor d[] = {
         EXPORT(abi_version), EXPORT(ctx_create), EXPORT(ctx_destroy), EXPORT(sync), EXPORT(set_timing), EXPORT(stage_time_ms),
-        EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props), EXPORT(update_props_planes), EXPORT(props_to_planes),
+        EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props), EXPORT(update_props_planes), EXPORT(props_to_planes), EXPORT(lit_colors),
         EXPORT(project), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),

@@ -360,6 +360,8 @@ def test_virtual_ranks_band_frame_matches_single_gpu(device, world):
     pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
     per = dist.shard_size(n, world)
     stages = dist.HipStages(torch, 0, per * world, w, h)
+    if world == 4:  # one of the two cases with the colour plane pre-lit (as bench.py runs the multi-GPU frame)
+        stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
     renderers = [dist.BandRenderer(stages, n, w, h, r, world, None) for r in range(world)]
     for br in renderers:  # phase 1: every rank projects its slice
         stages.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
@@ -922,4 +924,45 @@ def test_new_entry_points_reject_bad_arguments(device):
     r.render(u, planes, nbuf, None, w, h)
     assert r.finish() == oracle_pipeline(props, normals, u, w, h)["indices"].shape[0]
     for o in (r, pm, nbuf, out):
+        o.destroy()
+
+
+def test_prelit_colour_plane_gives_the_same_image_bit_for_bit(device):
+    """Shading applied once per splat (splat_lit_colors, SplatPropertyManager.getLitPlanes) instead of once
+    per staged list entry: the same float image bit for bit (the lighting arithmetic is explicitly rounded
+    in both places), in both composite modes, and the plane follows property and normal updates."""
+    n, w, h = 40000, 400, 240
+    props, normals, u = make_case(n, w, h, 37, 1.5)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    # the plane itself against the oracle's shading
+    lit = pm.getLitPlanes(nbuf).colorOpacity.read(np.float32).reshape(n, 4)
+    ndl = (normals[:, 0] * np.float32(0.577350269189625764) + normals[:, 1] * np.float32(0.577350269189625764)) \
+        + normals[:, 2] * np.float32(0.577350269189625764)
+    kd = np.float32(0.85) + np.float32(0.15) * np.maximum(ndl, np.float32(0))
+    assert np.array_equal(lit[:, :3], props[:, 4:7] * kd[:, None]) and np.array_equal(lit[:, 3], props[:, 7])
+    for mode in (sr.MODE_FRONT_TO_BACK, sr.MODE_REFERENCE_LITERAL):
+        a = sr.Renderer(device, None, "rgba8unorm", n, mode=mode)
+        b = sr.Renderer(device, None, "rgba8unorm", n, mode=mode)
+        a.render(u, pm.getPropertyPlanes(), nbuf, None, w, h, wantFloat=True)
+        b.render(u, pm.getLitPlanes(nbuf), None, None, w, h, wantFloat=True)  # no normals needed
+        assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+        a.destroy()
+        b.destroy()
+    # new normals in a new buffer, then new properties: the cached plane follows
+    normals2 = np.roll(normals, 1, axis=0).copy()
+    nbuf2 = device.createBufferFrom(normals2)
+    a = sr.Renderer(device, None, "rgba8unorm", n)
+    b = sr.Renderer(device, None, "rgba8unorm", n)
+    a.render(u, pm.getPropertyBuffer(), nbuf2, None, w, h, wantFloat=True)
+    b.render(u, pm.getLitPlanes(nbuf2), None, None, w, h, wantFloat=True)
+    assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    props2 = props.copy()
+    props2[:, 4:7] = props[::-1, 4:7]
+    pm.setFromArrays(props2)
+    a.render(u, pm.getPropertyBuffer(), nbuf2, None, w, h, wantFloat=True)
+    b.render(u, pm.getLitPlanes(nbuf2), None, None, w, h, wantFloat=True)
+    assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    for o in (a, b, pm, nbuf, nbuf2):
         o.destroy()

@@ -23,6 +23,7 @@ pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
 for world in worlds:
     per = dist.shard_size(n, world)
     st = dist.HipStages(torch, 0, per * world, w, h)
+    st.set_lit(pt.data_ptr(), nt.data_ptr(), n)  # shading once per property update (as bench.py does)
     brs = [dist.BandRenderer(st, n, w, h, r, world, None) for r in range(world)]
     for br in brs:
         st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)

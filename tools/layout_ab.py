@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Frame time with the reference's interleaved property records vs the two-plane layout, alternating on
+"""Frame time with the reference's interleaved property records vs the two-plane layout vs planes with the colour
+plane pre-lit, alternating on
 one renderer (same box, same clocks): python tools/layout_ab.py [C2]"""
 import os
 import sys
@@ -19,7 +20,7 @@ pm = sr.SplatPropertyManager(dev, n)
 pm.setFromArrays(props)
 nbuf = dev.createBufferFrom(normals)
 r = sr.Renderer(dev, None, "rgba8unorm", n)
-for label, pb in (("interleaved", pm.getPropertyBuffer()), ("planes", pm.getPropertyPlanes())) * 2:
+for label, pb in (("interleaved", pm.getPropertyBuffer()), ("planes", pm.getPropertyPlanes()), ("planes, colour pre-lit", pm.getLitPlanes(nbuf))) * 2:
     for _ in range(5):
         r.render(u, pb, nbuf, None, w, h)
     dev.sync()
