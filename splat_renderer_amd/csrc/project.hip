@@ -41,7 +41,10 @@ __device__ __forceinline__ float4 project_centre(const FrameUniforms &u, float4 
     float depth = sqrtf((dx * dx + dy * dy) + dz * dz); // SplatProjector.ts:77
     float scx, scy;
     to_screen(u, x, y, z, scx, scy);
-    float max_r = 0.0f;
+    // max_k sqrt(d2_k) == sqrt(max_k d2_k) bit for bit: a correctly rounded square root is monotone, d2 >= +0,
+    // and fmaxf drops a NaN operand either way — one square root per splat instead of six (the kernel is
+    // VALU-bound: SQ counters show the vector ALUs 89 % busy, IEEE divides and square roots being most of it)
+    float max_d2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) { // :93-113, same offset order as the shader
         float ox = (k == 0) ? radius : (k == 1) ? -radius : 0.0f;
@@ -50,8 +53,9 @@ __device__ __forceinline__ float4 project_centre(const FrameUniforms &u, float4 
         float sx, sy;
         to_screen(u, x + ox, y + oy, z + oz, sx, sy);
         float ex = scx - sx, ey = scy - sy;
-        max_r = fmaxf(max_r, sqrtf(ex * ex + ey * ey));
+        max_d2 = fmaxf(max_d2, ex * ex + ey * ey);
     }
+    const float max_r = sqrtf(max_d2);
     return make_float4(scx, scy, max_r, depth);
 }
 
