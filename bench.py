@@ -35,10 +35,11 @@ def composite_alg_bytes(p_used, width, height, prelit=False):
     return (52 if prelit else 68) * p_used + 4 * width * height
 
 
-def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height, prelit=False):
+def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height, prelit=False, disc=False):
     """SURVEY §8d whole-frame model: project+key 56N, sort 68Np, count 20N, scan 8T, fill 20N+4P,
-    composite (68 or 52) P_used + 4WH."""
-    return 56 * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height, prelit)
+    composite (68 or 52) P_used + 4WH.  The oriented-disc projector also reads the normal (16) and writes
+    the disc record (32): 104N."""
+    return (104 if disc else 56) * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height, prelit)
 
 
 def cpu_baseline(name, props, normals, u, width, height):
@@ -60,9 +61,10 @@ def cpu_baseline(name, props, normals, u, width, height):
     keys, pay = O.extract_keys(proj)
     _, order = O.sort_pairs(keys, pay)
     t0 = time.perf_counter()
-    O.sequential(u, props, normals, order[::-1].copy(), width, height)
+    _, seq8 = O.sequential(u, props, normals, order[::-1].copy(), width, height)
     tb = time.perf_counter() - t0
-    return {"value": n / t1 / 1e6, "unit": "Msplats/s", "cores": 1, "kind": "port",
+    return {"sequential_u8": seq8,
+            "value": n / t1 / 1e6, "unit": "Msplats/s", "cores": 1, "kind": "port",
             "sample": f"1 full frame of {name} (N={n}, {width}x{height}), oracle/oracle.c model A, 1 thread",
             "seconds": round(t1, 3), "stage_ms": [round(x, 1) for x in r1["stage_ms"]],
             "all_cores": {"value": n / tn / 1e6, "cores": cores, "seconds": round(tn, 3),
@@ -111,6 +113,9 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(sr.scene.CONFIGS))
     ap.add_argument("--layout", default="planes", choices=["planes", "interleaved"],
                     help="splat properties as two vec4 planes (native) or the reference's interleaved 32-byte records")
+    ap.add_argument("--footprint", default="isotropic", choices=["isotropic", "disc"],
+                    help="isotropic: ComputeShaderRenderer's screen-space Gaussian (SURVEY §8a contract 3, the headline); "
+                         "disc: SequentialRenderer's oriented disc (parity vs the CPU rasteriser of SequentialRenderer.ts), N=1 only")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,6 +140,8 @@ def main():
     u = cam.uniforms(width, height)
     workload = f"{name}: {n} synthetic Gaussians @{width}x{height}, {tile}x{tile} tiles"
 
+    if args.footprint == "disc" and not (world == 1 and "RANK" not in os.environ):
+        raise SystemExit("--footprint disc: the band exchange carries the isotropic footprint's records (single GPU only for now)")
     if world == 1 and "RANK" not in os.environ:
         result = run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload)
     else:
@@ -152,7 +159,8 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     # the native layout unless asked for the reference's records: two vec4 planes (what updatePlanesFromCurvature
     # writes), the colour plane carrying the reference's shading (once per property update, not per list entry)
     pbuf = pm.getLitPlanes(nbuf) if args.layout == "planes" else pm.getPropertyBuffer()
-    r = sr.Renderer(dev, None, "rgba8unorm", n, tile)
+    disc = args.footprint == "disc"
+    r = sr.Renderer(dev, None, "rgba8unorm", n, tile, footprint=args.footprint)
 
     def frame():
         r.render(u, pbuf, nbuf, None, width, height)
@@ -195,7 +203,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     comp_bytes = composite_alg_bytes(p_used, width, height, prelit)
     comp_s = stage_ms["composite"] / 1e3
     achieved = comp_bytes / comp_s / 1e9
-    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, prelit)
+    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, prelit, disc)
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
         "frames_per_s": args.steps / dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -206,6 +214,8 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    "property_layout": ("two vec4 planes (pos,radius | lit rgb,opacity): shading kd(normal) applied once per property update"
                                        if args.layout == "planes" else "interleaved 32-byte records (reference layout), shading in the composite"),
                    "frame_order": os.environ.get("SPLAT_FRAME_ORDER", "tile-first (bin, then depth-sort per tile; library default)"),
+                   "footprint": ("oriented disc (SequentialRenderer.ts:91-142), inverse homography per pixel" if disc else
+                                 "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147)"),
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name),
@@ -220,6 +230,16 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     if not args.no_cpu_baseline:
         cb = cpu_baseline(name, props, normals, u, width, height)
         ref8 = cb.pop("frame_u8")
+        seq8 = cb.pop("sequential_u8")
+        if disc:
+            # this footprint IS SequentialRenderer's: the baseline beside it is the oracle's restatement of that
+            # renderer (its raster + the projector / key / sort stages it is fed by), the parity image its output
+            t = (sum(cb["stage_ms"][:3]) / 1e3) + cb["model_b_sequential_raster"]["seconds"]
+            cb.update(value=n / t / 1e6, seconds=round(t, 3),
+                      sample=f"1 full frame of {name} (N={n}, {width}x{height}), oracle/oracle.c: project + keys + sort, then the "
+                             "software rasteriser of SequentialRenderer.ts (one oriented quad per splat, back to front), 1 thread")
+            cb.pop("all_cores")
+            ref8 = seq8
         if not args.no_parity:
             got8 = r.readPixels()
             diff = np.abs(got8.astype(np.int16) - ref8.astype(np.int16))

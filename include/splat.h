@@ -201,6 +201,8 @@ int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void 
 #define SPLAT_COMPOSITE_REFERENCE_LITERAL 1 /* src/ComputeShaderRenderer.ts:175-190 as written */
 #define SPLAT_RECORDS_PROJECTED 0
 #define SPLAT_RECORDS_COMPACT 1
+#define SPLAT_FOOTPRINT_ISOTROPIC 0
+#define SPLAT_FOOTPRINT_DISC 1
 typedef struct splat_composite_cfg {
     uint32_t mode;       /* SPLAT_COMPOSITE_* */
     uint32_t early_out;  /* 1 = stop a pixel at alpha >= 0.99 (reference :187-190) */
@@ -212,7 +214,11 @@ typedef struct splat_composite_cfg {
                              * exchange records, see splat_project_slice_compact) */
     uint32_t prelit;        /* 1 = color_opacity holds LIT colours (splat_lit_colors): the composite then gathers two
                              * lines per staged entry instead of three and does not read normals (may be NULL) */
-    uint32_t reserved[1];
+    uint32_t footprint;     /* SPLAT_FOOTPRINT_ISOTROPIC: ComputeShaderRenderer's screen-space Gaussian (default).
+                             * SPLAT_FOOTPRINT_DISC: SequentialRenderer's / TileRenderer's oriented disc —
+                             * `projected` then points at the 32-byte DISC records of splat_project_disc, mode must
+                             * be FRONT_TO_BACK and record_format PROJECTED; in splat_render_frame* the projector
+                             * used is splat_project_disc (normals are required even when prelit) */
 } splat_composite_cfg;
 /* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
  * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;
@@ -245,6 +251,20 @@ int splat_render_frame_planes(splat_ctx *ctx, splat_sorter *sorter, splat_binner
                               void *out_rgba8, void *out_rgba32f);
 
 /* ---- multi-GPU band path (no reference equivalent — the reference is single-device) */
+/* The oriented-disc projector (src/SequentialRenderer.ts:68-71,91-112): the splat is the disc
+ * p + r*(t*u + b*v), u^2+v^2 <= 1, in the tangent plane of its normal (t = normalize(cross(up, n)), b =
+ * cross(n, t)).  Per splat it writes
+ *   discs[i]     = 8 floats {c.x, c.y, B00, B01, B10, B11, q0, q1}: the inverse of the disc's plane-to-screen
+ *                  homography about its screen centre c — (u,v) = B*d / (1 - q.d), d = pixel centre - c —
+ *                  which is what the rasteriser's perspective-correct interpolation evaluates; all zeros when
+ *                  the quad has a corner at w <= 0 or is seen edge-on;
+ *   projected[i] = a ProjectedSplat whose bounds are the disc's exact screen extent (a pure function of the
+ *                  disc record), depth as splat_project, screenRadius = half the larger extent;
+ * and keys / payload exactly as splat_project.  Sort and bin as usual with `projected`; composite with
+ * cfg.footprint = SPLAT_FOOTPRINT_DISC and `discs` as the records.  Bit-exact against the oracle. */
+int splat_project_disc(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4,
+                       const void *normals, uint32_t normal_stride_vec4, uint32_t n, void *projected, void *discs,
+                       void *keys, void *payload, uint32_t n_padded);
 /* Projects splats [first, first+count) of the scene into projected_slice[0..count) with
  * originalIndex = global index: the per-rank share of the projector before the all-gather. */
 int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius,

@@ -192,6 +192,90 @@ def composite(mode, early_out, color_opacity, normals, projected, indices, count
     return out
 
 
+# ---- oriented-disc footprint (src/SequentialRenderer.ts:68-71, 91-112, 125-141) ------------------
+# The rasteriser's perspective-correct uv over the planar quad p + r*(t*u + b*v) is the inverse of the
+# plane-to-screen homography; about the screen centre c it is (u,v) = B*d / (1 - q.d).
+def project_disc(u, pos_radius, normals):
+    """Vectorised float32 twin of oracle.c's disc_record / orc_disc_bounds / orc_project_disc."""
+    with np.errstate(all="ignore"):
+        m = np.asarray(u, np.float32)
+        p = np.asarray(pos_radius, np.float32)
+        nr = np.asarray(normals, np.float32)
+        n = p.shape[0]
+        x, y, z, r = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+        n0, n1, n2 = nr[:, 0], nr[:, 1], nr[:, 2]
+        steep = np.abs(n1) > F(0.9)  # :69
+        u0 = np.where(steep, F(1), F(0)).astype(np.float32)
+        u1 = np.where(steep, F(0), F(1)).astype(np.float32)
+        u2 = np.zeros(n, np.float32)
+        t0, t1, t2 = u1 * n2 - u2 * n1, u2 * n0 - u0 * n2, u0 * n1 - u1 * n0  # cross(up, normal)
+        tl = np.sqrt((t0 * t0 + t1 * t1) + t2 * t2)
+        t0, t1, t2 = t0 / tl, t1 / tl, t2 / tl  # :70
+        b0, b1, b2 = n1 * t2 - n2 * t1, n2 * t0 - n0 * t2, n0 * t1 - n1 * t0  # :96 cross(normal, tangent)
+        e0 = (t0 * r, t1 * r, t2 * r)
+        e1 = (b0 * r, b1 * r, b2 * r)
+
+        def lin(row, e):
+            return (m[row] * e[0] + m[4 + row] * e[1]) + m[8 + row] * e[2]
+
+        ctx, cty, ctw = lin(0, e0), lin(1, e0), lin(3, e0)
+        cbx, cby, cbw = lin(0, e1), lin(1, e1), lin(3, e1)
+        cpx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12]
+        cpy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13]
+        cpw = ((m[3] * x + m[7] * y) + m[11] * z) + m[15]
+        front = (cpw - (np.abs(ctw) + np.abs(cbw))) > F(0)
+        hw, hh = F(0.5) * m[20], F(0.5) * m[21]
+        m00, m01, m02 = hw * (ctx + ctw), hw * (cbx + cbw), hw * (cpx + cpw)
+        m10, m11, m12 = hh * (ctw - cty), hh * (cbw - cby), hh * (cpw - cpy)
+        scx, scy = m02 / cpw, m12 / cpw
+        a00, a01 = m00 - scx * ctw, m01 - scx * cbw
+        a10, a11 = m10 - scy * ctw, m11 - scy * cbw
+        det = a00 * a11 - a01 * a10
+        ok = front & (np.abs(det) > F(0))
+        k, idet = cpw / det, F(1) / det
+        rec = np.stack([scx, scy, a11 * k, (-a01) * k, (-a10) * k, a00 * k,
+                        (a11 * ctw - a10 * cbw) * idet, (a00 * cbw - a01 * ctw) * idet], axis=1).astype(np.float32)
+        ok &= np.isfinite(rec).all(axis=1)
+        rec[~ok] = 0
+        bounds, _ = disc_bounds(rec)
+        proj = np.zeros((n, 8), np.float32)
+        proj[:, :4] = bounds
+        dx, dy, dz = x - m[16], y - m[17], z - m[18]
+        proj[:, 4] = np.sqrt((dx * dx + dy * dy) + dz * dz)
+        proj[:, 5] = F(0.5) * np.maximum(bounds[:, 2] - bounds[:, 0], bounds[:, 3] - bounds[:, 1])
+        proj[:, 6] = np.arange(n, dtype=np.uint32).view(np.float32)
+        return proj, rec
+
+
+def disc_bounds(rec):
+    """Exact screen extent of the projected unit circle from the record (dual conic M diag(1,1,-1) M^T)."""
+    with np.errstate(all="ignore"):
+        rec = np.asarray(rec, np.float32).reshape(-1, 8)
+        cx, cy, b00, b01, b10, b11, q0, q1 = (rec[:, i] for i in range(8))
+        detb = b00 * b11 - b01 * b10
+        inv = F(1) / detb
+        a00, a01, a10, a11 = b11 * inv, (-b01) * inv, (-b10) * inv, b00 * inv
+        g0, g1 = a00 * q0 + a10 * q1, a01 * q0 + a11 * q1
+        q00, q11 = a00 * a00 + a01 * a01, a10 * a10 + a11 * a11
+        q22 = (g0 * g0 + g1 * g1) - F(1)
+        q02, q12 = a00 * g0 + a01 * g1, a10 * g0 + a11 * g1
+        sx, sy = np.sqrt(q02 * q02 - q00 * q22), np.sqrt(q12 * q12 - q11 * q22)
+        iq = F(1) / q22
+        out = np.stack([cx + (q02 + sx) * iq, cy + (q12 + sy) * iq, cx + (q02 - sx) * iq, cy + (q12 - sy) * iq],
+                       axis=1).astype(np.float32)
+        ok = (q22 < F(0)) & np.isfinite(out).all(axis=1)
+        out[~ok] = 0
+        return out, ok
+
+
+def disc_uv(rec, px, py):
+    """(u, v) of pixel centre (px, py) on the disc of one record — float64, for checking the float32 paths."""
+    r = np.asarray(rec, np.float64)
+    dx, dy = px - r[0], py - r[1]
+    den = 1.0 - (r[6] * dx + r[7] * dy)
+    return (r[2] * dx + r[3] * dy) / den, (r[4] * dx + r[5] * dy) / den
+
+
 def unorm8(img):
     v = np.clip(np.nan_to_num(img, nan=0.0), 0.0, 1.0).astype(np.float32)
     return (v * F(255.0) + F(0.5)).astype(np.uint8)

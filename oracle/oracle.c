@@ -519,6 +519,166 @@ void orc_sequential(const float uniforms[22], const float *pos_radius, size_t pr
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Oriented-disc footprint — SequentialRenderer's splat, evaluated per pixel from tile lists    */
+/* (closes I6).                                                               */
+/*                                                                                              */
+/* The vertex shader places a quad p + r*(t*u + b*v), (u,v) in [-1,1]^2, in the tangent plane of */
+/* the normal (:91-112); the rasteriser interpolates (u,v) perspective-correctly; the fragment  */
+/* shader keeps u^2+v^2 <= 1 (:126-130).  Perspective-correct interpolation over a planar quad */
+/* IS the plane-to-screen homography inverted, so the same footprint can be evaluated at any    */
+/* pixel without a rasteriser:  [X, Y, w] = M * [u, v, 1] with X = W/2*(cx+cw), Y = H/2*(cw-cy), */
+/* and relative to the screen centre c = (X/w, Y/w) at (0,0):                                   */
+/*      (u, v) = B*d / (1 - q.d),   d = pixel - c,                                              */
+/* B = w_c * A^-1 with A the 2x2 Jacobian numerators, q = A^-T g with g the w-row of M (the      */
+/* perspective term; q = 0 gives the affine "EWA" footprint).  The 8-float record is             */
+/* {c.x, c.y, B00, B01, B10, B11, q0, q1}.  Its screen bounding box — what the binner bins by — */
+/* is the exact extent of the projected unit circle (tangent lines of the dual conic             */
+/* M*diag(1,1,-1)*M^T), computed FROM THE RECORD so that it is a pure function of it.            */
+/* All of it in binary32, one rounding per operator, in the order written (the HIP projector     */
+/* follows the same order with contraction off: records and bounds are compared bit for bit).    */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int finite4(float a, float b, float c, float d) {
+    float s = ((a - a) + (b - b)) + ((c - c) + (d - d)); /* 0 iff all finite, NaN otherwise */
+    return s == 0.0f;
+}
+
+/* bounds = {min.x, min.y, max.x, max.y} of the disc a record describes; all zero (bins nowhere:
+ * TileBinner.ts:437 skips min >= max) when the record is degenerate.  Returns 1 when valid. */
+int orc_disc_bounds(const float *rec, float out[4]) {
+    float detb = rec[2] * rec[5] - rec[3] * rec[4];
+    float inv = 1.0f / detb;
+    float a00 = rec[5] * inv, a01 = (-rec[3]) * inv, a10 = (-rec[4]) * inv, a11 = rec[2] * inv; /* A / w_c */
+    float g0 = a00 * rec[6] + a10 * rec[7], g1 = a01 * rec[6] + a11 * rec[7];                   /* g / w_c */
+    float q00 = a00 * a00 + a01 * a01, q11 = a10 * a10 + a11 * a11;
+    float q22 = (g0 * g0 + g1 * g1) - 1.0f;
+    float q02 = a00 * g0 + a01 * g1, q12 = a10 * g0 + a11 * g1;
+    float sx = sqrtf(q02 * q02 - q00 * q22), sy = sqrtf(q12 * q12 - q11 * q22);
+    float iq = 1.0f / q22;
+    float x0 = rec[0] + (q02 + sx) * iq, x1 = rec[0] + (q02 - sx) * iq;
+    float y0 = rec[1] + (q12 + sy) * iq, y1 = rec[1] + (q12 - sy) * iq;
+    if (q22 < 0.0f && finite4(x0, y0, x1, y1)) {
+        out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1;
+        return 1;
+    }
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    return 0;
+}
+
+static void disc_record(const float *u, const float *p, const float *n, float *rec) {
+    const float *m = u;
+    for (int k = 0; k < ORC_DISC_FLOATS; ++k) rec[k] = 0.0f;
+    /* computeTangent :68-71, bitangent :96 */
+    float up[3] = {0.0f, 1.0f, 0.0f};
+    if (fabsf(n[1]) > 0.9f) { up[0] = 1.0f; up[1] = 0.0f; }
+    float t[3], b[3];
+    cross3(up, n, t);
+    float tl = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+    t[0] /= tl; t[1] /= tl; t[2] /= tl;
+    cross3(n, t, b);
+    /* half-axes of the quad in world space (:107-109), then their clip-space images (x, y, w rows) */
+    float r = p[3];
+    float e0[3] = {t[0] * r, t[1] * r, t[2] * r}, e1[3] = {b[0] * r, b[1] * r, b[2] * r};
+    float ctx = (m[0] * e0[0] + m[4] * e0[1]) + m[8] * e0[2];
+    float cty = (m[1] * e0[0] + m[5] * e0[1]) + m[9] * e0[2];
+    float ctw = (m[3] * e0[0] + m[7] * e0[1]) + m[11] * e0[2];
+    float cbx = (m[0] * e1[0] + m[4] * e1[1]) + m[8] * e1[2];
+    float cby = (m[1] * e1[0] + m[5] * e1[1]) + m[9] * e1[2];
+    float cbw = (m[3] * e1[0] + m[7] * e1[1]) + m[11] * e1[2];
+    float cpx, cpy, cpz, cpw;
+    vp_mul(m, p[0], p[1], p[2], &cpx, &cpy, &cpz, &cpw);
+    (void)cpz;
+    /* a corner at w <= 0: the quad is skipped (orc_sequential does the same; no clipper) */
+    if (!(cpw - (fabsf(ctw) + fabsf(cbw)) > 0.0f)) return;
+    float hw = 0.5f * u[20], hh = 0.5f * u[21];
+    float m00 = hw * (ctx + ctw), m01 = hw * (cbx + cbw), m02 = hw * (cpx + cpw);
+    float m10 = hh * (ctw - cty), m11 = hh * (cbw - cby), m12 = hh * (cpw - cpy);
+    float scx = m02 / cpw, scy = m12 / cpw;
+    float a00 = m00 - scx * ctw, a01 = m01 - scx * cbw;
+    float a10 = m10 - scy * ctw, a11 = m11 - scy * cbw;
+    float det = a00 * a11 - a01 * a10;
+    if (!(fabsf(det) > 0.0f)) return; /* edge-on (or NaN): covers no pixel */
+    float k = cpw / det, idet = 1.0f / det;
+    rec[0] = scx; rec[1] = scy;
+    rec[2] = a11 * k; rec[3] = (-a01) * k; rec[4] = (-a10) * k; rec[5] = a00 * k;
+    rec[6] = (a11 * ctw - a10 * cbw) * idet;
+    rec[7] = (a00 * cbw - a01 * ctw) * idet;
+    if (!finite4(rec[2], rec[3], rec[4], rec[5]) || !finite4(rec[0], rec[1], rec[6], rec[7]))
+        for (int j = 0; j < ORC_DISC_FLOATS; ++j) rec[j] = 0.0f;
+}
+
+void orc_project_disc(const float uniforms[22], const float *pos_radius, size_t pr_stride, const float *normals,
+                      size_t normal_stride, uint32_t n, float *projected, float *discs) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *p = pos_radius + (size_t)i * pr_stride;
+        float *rec = discs + (size_t)i * ORC_DISC_FLOATS, *o = projected + (size_t)i * ORC_PROJ_FLOATS;
+        disc_record(uniforms, p, normals + (size_t)i * normal_stride, rec);
+        orc_disc_bounds(rec, o);
+        float dx = p[0] - uniforms[16], dy = p[1] - uniforms[17], dz = p[2] - uniforms[18];
+        o[4] = sqrtf((dx * dx + dy * dy) + dz * dz); /* same depth, same order as SplatProjector.ts:77 */
+        o[5] = 0.5f * fmaxf(o[2] - o[0], o[3] - o[1]);
+        memcpy(&o[6], &i, 4);
+        o[7] = 0.0f;
+    }
+}
+
+/* The per-pixel loop over tile lists (nearest first, C += c*g*T, T *= 1-g: the "over" operator of the
+ * blend state :189-200 applied back to front, re-associated) with SequentialRenderer's fragment
+ * (:125-141).  rim (may be NULL): set to 1 for pixels where some evaluated entry has |d2 - 1| <= 1e-3 —
+ * the discard at d2 > 1 is a step of exp(-3.125) = 0.044 in alpha, so on those pixels (and only
+ * those) two correct evaluations that round differently may differ by up to 0.044. */
+uint64_t orc_composite_disc(int early_out, const float *lit_or_color, size_t color_stride, const float *normals,
+                            size_t normal_stride, const float *discs, const uint32_t *indices, const uint32_t *counts,
+                            const uint32_t *offsets, uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
+                            uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8, uint8_t *rim) {
+    const float inv_sqrt3 = 1.0f / sqrtf(3.0f);
+    uint64_t consumed = 0;
+    if (row1 > height) row1 = height;
+    for (uint32_t py = row0; py < row1; ++py) {
+        for (uint32_t px = 0; px < width; ++px) {
+            uint32_t tile_idx = (py / tile) * ntx + (px / tile);
+            float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+            uint32_t off = offsets[tile_idx], cnt = counts[tile_idx];
+            float cr = 0.0f, cg = 0.0f, cb = 0.0f, trans = 1.0f;
+            int on_rim = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                uint32_t s = indices[off + i];
+                ++consumed;
+                const float *rec = discs + (size_t)s * ORC_DISC_FLOATS;
+                float bnd[4];
+                if (!orc_disc_bounds(rec, bnd)) continue;
+                float dx = pxf - rec[0], dy = pyf - rec[1];
+                float den = 1.0f - (rec[6] * dx + rec[7] * dy);
+                float nu = rec[2] * dx + rec[3] * dy, nv = rec[4] * dx + rec[5] * dy;
+                float uu = nu / den, vv = nv / den;
+                float d2 = uu * uu + vv * vv; /* :126 */
+                if (fabsf(d2 - 1.0f) <= 1e-3f) on_rim = 1;
+                if (pxf < bnd[0] || pxf > bnd[2] || pyf < bnd[1] || pyf > bnd[3]) continue;
+                if (!(d2 <= 1.0f)) continue; /* :128-130 discard */
+                float g = expf((-0.5f * d2) / (0.4f * 0.4f)); /* :132-133 */
+                const float *c = lit_or_color + (size_t)s * color_stride;
+                float k = 1.0f;
+                if (normals) {
+                    const float *nrm = normals + (size_t)s * normal_stride;
+                    float ndl = (nrm[0] * inv_sqrt3 + nrm[1] * inv_sqrt3) + nrm[2] * inv_sqrt3;
+                    k = 0.85f + 0.15f * fmaxf(ndl, 0.0f); /* :135-137 */
+                }
+                float w = trans * g;
+                cr = cr + (c[0] * k) * w; cg = cg + (c[1] * k) * w; cb = cb + (c[2] * k) * w;
+                trans = trans * (1.0f - g);
+                if (early_out && (1.0f - trans) >= 0.99f) break;
+            }
+            float fr = cr + 0.05f * trans, fg = cg + 0.05f * trans, fb = cb + 0.1f * trans; /* clear colour :251 */
+            size_t o = ((size_t)py * width + px) * 4;
+            if (out_f32) { out_f32[o] = fr; out_f32[o + 1] = fg; out_f32[o + 2] = fb; out_f32[o + 3] = 1.0f; }
+            if (out_u8) { out_u8[o] = orc_unorm8(fr); out_u8[o + 1] = orc_unorm8(fg); out_u8[o + 2] = orc_unorm8(fb); out_u8[o + 3] = 255; }
+            if (rim) rim[(size_t)py * width + px] = (uint8_t)on_rim;
+        }
+    }
+    return consumed;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* SplatPropertyManager update kernel (src/SplatPropertyManager.ts:82-107)                     */
 /* ------------------------------------------------------------------------------------------ */
 

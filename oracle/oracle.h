@@ -101,6 +101,23 @@ void orc_sequential(const float uniforms[22], const float *pos_radius, size_t pr
                     size_t normal_stride, const uint32_t *order, uint32_t n_order,
                     uint32_t width, uint32_t height, float *out_f32, uint8_t *out_u8);
 
+/* Oriented-disc footprint: SequentialRenderer's quad + fragment (src/SequentialRenderer.ts:
+ * 68-71, 91-142) evaluated per pixel through the inverse of the quad's plane-to-screen homography.
+ * Disc record: 8 floats {centre.x, centre.y, B00, B01, B10, B11, q0, q1}: (u,v) = B*d / (1 - q.d), d = pixel -
+ * centre; all zeros = culled.  orc_project_disc writes, per splat, the disc record and a ProjectedSplat whose
+ * bounds are the disc's exact screen extent (orc_disc_bounds of the record), depth as orc_project, screenRadius =
+ * half the larger extent. */
+#define ORC_DISC_FLOATS 8
+int orc_disc_bounds(const float *disc_record, float bounds_out[4]);
+void orc_project_disc(const float uniforms[22], const float *pos_radius, size_t pr_stride, const float *normals,
+                      size_t normal_stride, uint32_t n, float *projected, float *discs);
+/* normals == NULL: lit_or_color already holds lit colours.  rim: optional width*height bytes, 1 where a
+ * pixel lies within 1e-3 (in d2) of some disc's rim (see oracle.c). */
+uint64_t orc_composite_disc(int early_out, const float *lit_or_color, size_t color_stride, const float *normals,
+                            size_t normal_stride, const float *discs, const uint32_t *indices, const uint32_t *counts,
+                            const uint32_t *offsets, uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
+                            uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8, uint8_t *rim);
+
 /* SplatPropertyManager update kernel (src/SplatPropertyManager.ts:82-107). positions and
  * curvature are vec4 arrays; props is the interleaved 8-float record. */
 void orc_update_props(const float *positions, const float *curvature, uint32_t n, float *props);

@@ -53,6 +53,12 @@ def lib():
         L.orc_sequential.argtypes = [fp, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, u32p,
                                      C.c_uint32, C.c_uint32, C.c_uint32, fp, u8p]
         L.orc_update_props.argtypes = [fp, fp, C.c_uint32, fp]
+        L.orc_disc_bounds.argtypes = [fp, fp]
+        L.orc_disc_bounds.restype = C.c_int
+        L.orc_project_disc.argtypes = [fp, fp, C.c_size_t, fp, C.c_size_t, C.c_uint32, fp, fp]
+        L.orc_composite_disc.argtypes = [C.c_int, fp, C.c_size_t, fp, C.c_size_t, fp, u32p, u32p, u32p, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, fp, u8p, u8p]
+        L.orc_composite_disc.restype = C.c_uint64
         L.orc_frame.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_int, fp, u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.orc_frame.restype = C.c_int
@@ -205,6 +211,50 @@ def sequential(u, props, normals, order, width, height):
                          C.cast(base + 16, C.POINTER(C.c_float)), 8, _f(normals), normals.shape[1],
                          _u(order), order.shape[0], width, height, _f(out), _b(out8))
     return out, out8
+
+
+def project_disc(u, props, normals):
+    """Oriented-disc footprint: returns ((n,8) ProjectedSplat records with the disc's exact bounds, (n,8) disc records)."""
+    props = _c32(props)
+    normals = _c32(normals)
+    n, stride = props.shape
+    proj = np.zeros((n, 8), np.float32)
+    discs = np.zeros((n, 8), np.float32)
+    lib().orc_project_disc(_f(_c32(u)), _f(props), stride, _f(normals), normals.shape[1], n, _f(proj), _f(discs))
+    return proj, discs
+
+
+def disc_bounds(rec):
+    rec = _c32(rec)
+    out = np.zeros(4, np.float32)
+    ok = lib().orc_disc_bounds(_f(rec), _f(out))
+    return bool(ok), out
+
+
+def composite_disc(early_out, color_opacity, normals, discs, indices, counts, offsets, width, height, tile=16,
+                   rows=None):
+    """normals=None: color_opacity holds lit colours.  Returns (f32 image, u8 image, consumed, rim mask)."""
+    color_opacity = np.asarray(color_opacity, dtype=np.float32)
+    cs = color_opacity.strides[0] // 4
+    discs = _c32(discs)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    if indices.shape[0] == 0:
+        indices = np.zeros(1, np.uint32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    ntx = -(-width // tile)
+    r0, r1 = (0, height) if rows is None else rows
+    out = np.zeros((height, width, 4), np.float32)
+    out8 = np.zeros((height, width, 4), np.uint8)
+    rim = np.zeros((height, width), np.uint8)
+    cptr = C.cast(color_opacity.ctypes.data, C.POINTER(C.c_float))
+    if normals is not None:
+        normals = _c32(normals)
+    consumed = lib().orc_composite_disc(int(early_out), cptr, cs, _f(normals) if normals is not None else None,
+                                        normals.shape[1] if normals is not None else 0, _f(discs), _u(indices),
+                                        _u(counts), _u(offsets), tile, ntx, width, height, r0, r1, _f(out), _b(out8),
+                                        _b(rim))
+    return out, out8, int(consumed), rim
 
 
 def update_props(positions, curvature):

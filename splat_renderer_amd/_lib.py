@@ -17,6 +17,7 @@ STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2,
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
 MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
 RECORDS_PROJECTED, RECORDS_COMPACT = 0, 1
+FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC = 0, 1
 U32_MAX = 0xFFFFFFFF
 
 
@@ -29,7 +30,7 @@ class SplatError(RuntimeError):
 class CompositeCfg(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("early_out", C.c_uint32), ("tile_size", C.c_uint32),
                 ("tile_row0", C.c_uint32), ("tile_row1", C.c_uint32), ("record_format", C.c_uint32),
-                ("prelit", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("prelit", C.c_uint32), ("footprint", C.c_uint32)]
 
 
 # name -> (restype, argtypes); the single source of truth checked against include/splat.h by
@@ -58,6 +59,7 @@ SIGNATURES = {
     "splat_update_props_planes": (_i, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "splat_props_to_planes": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "splat_project": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _vp, _vp, _vp, _u32]),
+    "splat_project_disc": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32]),
     "splat_extract_keys": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "splat_sort_create": (_i, [_vp, _u32, _pvp]),
     "splat_sort_destroy": (None, [_vp]),

@@ -522,6 +522,7 @@ void splat_bin_destroy(splat_binner *b) {
     if (b->wide_a) (void)hipFree(b->wide_a);
     if (b->wide_b) (void)hipFree(b->wide_b);
     if (b->expanded) (void)hipFree(b->expanded);
+    if (b->discs) (void)hipFree(b->discs);
     if (b->pinned) (void)hipHostFree(b->pinned);
     if (b->readback_done) (void)hipEventDestroy(b->readback_done);
     delete b;

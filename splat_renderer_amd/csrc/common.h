@@ -118,6 +118,8 @@ struct splat_binner {
     int frame_order = -1;                           // splat_bin_set_frame_order
     void *expanded = nullptr;                       // band frame: ProjectedSplat records rebuilt from compact exchange records
     uint32_t expanded_cap = 0;
+    void *discs = nullptr;                          // frame path, oriented-disc footprint: the projector's 32-byte disc records
+    uint32_t discs_cap = 0;
     bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
     uint64_t total = 0;
     bool ran = false;
@@ -178,4 +180,5 @@ int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_
 // project.hip internal: the projector with the optional per-index tile range output
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
-                   const BinParams *bp, const TfHistOut *hist_out = nullptr);
+                   const BinParams *bp, const TfHistOut *hist_out = nullptr, const void *normals = nullptr,
+                   uint32_t normal_stride_vec4 = 1, void *discs = nullptr); // discs != NULL: the oriented-disc footprint (disc.h)

@@ -23,6 +23,7 @@
 //
 // Compiled with -ffp-contract=fast; compared with the oracle within a stated tolerance.
 #include "common.h"
+#include "disc.h"
 
 #include <hip/hip_ext.h>
 
@@ -34,6 +35,7 @@ struct CompositeParams {
     const float4 *normals; uint32_t normal_stride; // vec4(normal, scaleFactor)
     const float4 *projected;                       // 2 x float4 per splat (ProjectedSplat), or 1 x float4 (compact exchange record)
     uint32_t compact;
+    uint32_t disc;                                 // projected holds 32-byte disc records (disc.h): the oriented-disc footprint
     uint32_t prelit;                               // color holds lit colours (k_lit_colors): normals are not read
     const uint32_t *indices, *counts, *offsets;
     uint32_t width, height, ntx, tile_row0;
@@ -116,12 +118,20 @@ __device__ __forceinline__ void fetch_record(const CompositeParams &p, uint32_t 
     }
 }
 
-template <int MODE, bool EARLY_OUT>
+// exp(-0.5 * d2 / (0.4 * 0.4)) = exp2(d2 * this)   (SequentialRenderer.ts:132-133)
+constexpr float DISC_EXP2_SCALE = -4.508422002777011f;
+
+// DISC: the footprint is SequentialRenderer's oriented disc (disc.h) — per entry the 32-byte disc record and
+// the lit colour are staged, a pixel is inside when u^2 + v^2 <= 1 with (u,v) = B*d / (1 - q.d); the
+// coverage masks come from the disc's exact bounds, as the binner's tile ranges do.
+template <int MODE, bool EARLY_OUT, bool DISC>
 __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     // per entry one 32-byte record {centre.x, centre.y, exp2 scale, lit blue | lit red, lit green, -, -}: both
     // halves are read off ONE address register (ds_read_b128 + ds_read_b64 offset:16), and forming an LDS
     // address from the scalar entry index costs a VALU move per register
-    __shared__ float4 s_par[CBATCH][2];
+    // (DISC: {centre.x, centre.y, B00, B01 | B10, B11, q0, q1 | lit red, green, blue, -})
+    constexpr int PAR = DISC ? 3 : 2;
+    __shared__ float4 s_par[CBATCH][PAR];
     __shared__ uint2 s_mask[4][CBATCH];  // per quadrant: which of its 64 pixels the entry's box covers
     __shared__ uint32_t s_wave_done[4];
 
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     // are issued before the current batch is consumed, so the ~3 us dependent-load chain (index, then
     // record / colour / normal) overlaps the arithmetic instead of preceding it.
     uint32_t f_idx = 0xffffffffu;              // splat index of the entry this thread stages
-    float4 f_b = make_float4(0, 0, 0, 0), f_c = f_b, f_n = f_b;
+    float4 f_b = make_float4(0, 0, 0, 0), f_c = f_b, f_n = f_b, f_b2 = f_b;
     float f_r = 0.0f;
     bool f_ready = false;                      // f_* already hold this thread's entry of the batch about to be staged
     uint32_t n_idx = 0xffffffffu;              // index of this thread's entry one batch further on (the gathers depend on it)
@@ -166,18 +176,37 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
         // ---- stage: one entry per thread, everything per-entry is computed here, once per tile ----
         {
             const uint32_t e = base + tid;
-            float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 geo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), geo2 = geo;
             float2 col = make_float2(0.0f, 0.0f);
+            float col_b = 0.0f;
             uint32_t xm = 0, ym = 0;
             if (!f_ready) { // the first three batches of a tile: fetch now
                 f_idx = (tid < CBATCH && e < count) ? p.indices[off + e] : 0xffffffffu;
                 if (f_idx != 0xffffffffu) {
-                    fetch_record(p, f_idx, f_b, f_r);
+                    if constexpr (DISC) {
+                        f_b = p.projected[(size_t)f_idx * 2];
+                        f_b2 = p.projected[(size_t)f_idx * 2 + 1];
+                    } else {
+                        fetch_record(p, f_idx, f_b, f_r);
+                    }
                     f_c = p.color[(size_t)f_idx * p.color_stride];
                     if (!p.prelit) f_n = p.normals[(size_t)f_idx * p.normal_stride];
                 }
             }
-            if (f_idx != 0xffffffffu) {
+            if (DISC && f_idx != 0xffffffffu) {
+                const DiscRecord rec = {f_b, f_b2};
+                float4 bnd;
+                if (disc_bounds(rec, bnd)) { // (a culled splat's record is all zeros and is in no list anyway)
+                    const float4 c = p.prelit ? f_c : lit_color(f_c, f_n);
+                    col = make_float2(c.x, c.y);
+                    col_b = c.z;
+                    geo = f_b;
+                    geo2 = f_b2;
+                    xm = span_mask16(bnd.x, bnd.z, tile_cx);
+                    ym = span_mask16(bnd.y, bnd.w, tile_cy);
+                }
+            }
+            if (!DISC && f_idx != 0xffffffffu) {
                 const float4 b = f_b;
                 const float r = f_r;
                 if (!(r < 0.5f)) { // :127-129 "too small"
@@ -191,7 +220,12 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             }
             if (tid < CBATCH) {
                 s_par[tid][0] = geo;
-                s_par[tid][1] = make_float4(col.x, col.y, 0.0f, 0.0f);
+                if constexpr (DISC) {
+                    s_par[tid][1] = geo2;
+                    s_par[tid][2] = make_float4(col.x, col.y, col_b, 0.0f);
+                } else {
+                    s_par[tid][1] = make_float4(col.x, col.y, 0.0f, 0.0f);
+                }
                 s_mask[0][tid] = quadrant_mask(xm & 0xffu, ym & 0xffu);
                 s_mask[1][tid] = quadrant_mask(xm >> 8, ym & 0xffu);
                 s_mask[2][tid] = quadrant_mask(xm & 0xffu, ym >> 8);
@@ -203,7 +237,12 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 if (n_idx_valid) { // index of batch k+1 arrived a batch ago: its gathers go out now
                     f_idx = n_idx;
                     if (f_idx != 0xffffffffu) {
-                        fetch_record(p, f_idx, f_b, f_r);
+                        if constexpr (DISC) {
+                            f_b = p.projected[(size_t)f_idx * 2];
+                            f_b2 = p.projected[(size_t)f_idx * 2 + 1];
+                        } else {
+                            fetch_record(p, f_idx, f_b, f_r);
+                        }
                         f_c = p.color[(size_t)f_idx * p.color_stride];
                         if (!p.prelit) f_n = p.normals[(size_t)f_idx * p.normal_stride];
                     }
@@ -244,25 +283,44 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                                             (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j1);
                 if (!two) cover1 = 0;
                 const float4 G0 = s_par[c0 + j0][0], G1 = s_par[c0 + j1][0]; // wave-uniform addresses: LDS broadcasts
-                const float2 C0 = *reinterpret_cast<const float2 *>(&s_par[c0 + j0][1]),
-                             C1 = *reinterpret_cast<const float2 *>(&s_par[c0 + j1][1]);
-                const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
-                float g0 = __builtin_amdgcn_exp2f((dx0 * dx0 + dy0 * dy0) * G0.z);
-                float g1 = __builtin_amdgcn_exp2f((dx1 * dx1 + dy1 * dy1) * G1.z);
+                float2 C0, C1;
+                float B0, B1, g0, g1; // blue, Gaussian
+                if constexpr (DISC) {
+                    const float4 Q0 = s_par[c0 + j0][1], Q1 = s_par[c0 + j1][1];
+                    const float4 L0 = s_par[c0 + j0][2], L1 = s_par[c0 + j1][2];
+                    C0 = make_float2(L0.x, L0.y); B0 = L0.z;
+                    C1 = make_float2(L1.x, L1.y); B1 = L1.z;
+                    const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
+                    const float rd0 = __builtin_amdgcn_rcpf(1.0f - (Q0.z * dx0 + Q0.w * dy0));
+                    const float rd1 = __builtin_amdgcn_rcpf(1.0f - (Q1.z * dx1 + Q1.w * dy1));
+                    const float u0 = (G0.z * dx0 + G0.w * dy0) * rd0, v0 = (Q0.x * dx0 + Q0.y * dy0) * rd0;
+                    const float u1 = (G1.z * dx1 + G1.w * dy1) * rd1, v1 = (Q1.x * dx1 + Q1.y * dy1) * rd1;
+                    const float d0 = u0 * u0 + v0 * v0, d1 = u1 * u1 + v1 * v1; // :126
+                    g0 = (d0 <= 1.0f) ? __builtin_amdgcn_exp2f(d0 * DISC_EXP2_SCALE) : 0.0f; // :128-133 (NaN: outside)
+                    g1 = (d1 <= 1.0f) ? __builtin_amdgcn_exp2f(d1 * DISC_EXP2_SCALE) : 0.0f;
+                } else {
+                    C0 = *reinterpret_cast<const float2 *>(&s_par[c0 + j0][1]);
+                    C1 = *reinterpret_cast<const float2 *>(&s_par[c0 + j1][1]);
+                    B0 = G0.w;
+                    B1 = G1.w;
+                    const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
+                    g0 = __builtin_amdgcn_exp2f((dx0 * dx0 + dy0 * dy0) * G0.z);
+                    g1 = __builtin_amdgcn_exp2f((dx1 * dx1 + dy1 * dy1) * G1.z);
+                }
                 unsigned long long lv = uniform64(live); // pinned at the use: see uniform64()
                 g0 = __builtin_amdgcn_inverse_ballot_w64(cover0 & lv) ? g0 : 0.0f;
                 if (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) { // :183-185 as written
                     const float om = 1.0f - g0;
                     cr = cr * om + C0.x * g0;
                     cg = cg * om + C0.y * g0;
-                    cb = cb * om + G0.w * g0;
+                    cb = cb * om + B0 * g0;
                     acc = acc * om + g0;
                     if (EARLY_OUT) lv &= ~__ballot(acc >= 0.99f); // :187-190
                 } else { // SURVEY §8a contract 3: nearest on top
                     const float wgt = acc * g0;
                     cr += C0.x * wgt;
                     cg += C0.y * wgt;
-                    cb += G0.w * wgt;
+                    cb += B0 * wgt;
                     acc = acc * (1.0f - g0);
                     if (EARLY_OUT) lv &= ~__ballot((1.0f - acc) >= 0.99f);
                 }
@@ -272,14 +330,14 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     const float om = 1.0f - g1;
                     cr = cr * om + C1.x * g1;
                     cg = cg * om + C1.y * g1;
-                    cb = cb * om + G1.w * g1;
+                    cb = cb * om + B1 * g1;
                     acc = acc * om + g1;
                     if (EARLY_OUT) lv &= ~__ballot(acc >= 0.99f);
                 } else {
                     const float wgt = acc * g1;
                     cr += C1.x * wgt;
                     cg += C1.y * wgt;
-                    cb += G1.w * wgt;
+                    cb += B1 * wgt;
                     acc = acc * (1.0f - g1);
                     if (EARLY_OUT) lv &= ~__ballot((1.0f - acc) >= 0.99f);
                 }
@@ -331,7 +389,11 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
     ARG_CHECK(ctx, out_rgba8 || out_rgba32f);
     ARG_CHECK(ctx, (((uintptr_t)color_opacity | (uintptr_t)normals | (uintptr_t)projected | (uintptr_t)out_rgba32f) & 15) == 0);
-    ARG_CHECK(ctx, cfg->prelit <= 1);
+    ARG_CHECK(ctx, cfg->prelit <= 1 && cfg->footprint <= SPLAT_FOOTPRINT_DISC);
+    // the oriented disc is SequentialRenderer's footprint: nearest-on-top "over" is its only blend, and its
+    // records are the projector's 32-byte disc records
+    ARG_CHECK(ctx, cfg->footprint != SPLAT_FOOTPRINT_DISC ||
+                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format == SPLAT_RECORDS_PROJECTED));
     const uint32_t ntx = div_up(width, CT), nty = div_up(height, CT);
     uint32_t r0 = cfg->tile_row0, r1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (r0 >= r1) return SPLAT_OK;
@@ -343,6 +405,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.projected = (const float4 *)projected;
     p.compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
     p.prelit = cfg->prelit != 0;
+    p.disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
     p.indices = (const uint32_t *)tile_indices;
     p.counts = (const uint32_t *)tile_counts;
     p.offsets = (const uint32_t *)tile_offsets;
@@ -358,17 +421,20 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool timed = stage_event_pair(ctx, SPLAT_STAGE_COMPOSITE, &ev0, &ev1);
-#define SPLAT_COMPOSITE_LAUNCH(MODE, EO)                                                                       \
-    do {                                                                                                       \
-        if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
-        else hipLaunchKernelGGL((k_composite<MODE, EO>), grid, block, 0, ctx->stream, p);                     \
+#define SPLAT_COMPOSITE_LAUNCH(MODE, EO, DISC)                                                                       \
+    do {                                                                                                             \
+        if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO, DISC>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
+        else hipLaunchKernelGGL((k_composite<MODE, EO, DISC>), grid, block, 0, ctx->stream, p);                     \
     } while (0)
-    if (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
-        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true);
-        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false);
+    if (p.disc) {
+        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, true);
+        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, true);
+    } else if (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
+        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, false);
+        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, false);
     } else {
-        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, true);
-        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, false);
+        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, true, false);
+        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, false, false);
     }
 #undef SPLAT_COMPOSITE_LAUNCH
     LAUNCH_CHECK(ctx, "k_composite");

@@ -231,6 +231,8 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, sorter && binner && cfg && props && (normals || cfg->prelit) && (n_records == 0 || records));
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner) && width >= 1 && height >= 1);
+    // (the band exchange carries the isotropic footprint's records; the oriented disc is single-GPU for now)
+    ARG_CHECK(ctx, cfg->footprint == SPLAT_FOOTPRINT_ISOTROPIC);
     // colours: the second vec4 of the reference's interleaved records, or (cfg->prelit) `props` IS the plane of lit colours
     const void *band_color = cfg->prelit ? props : (const void *)((const char *)props + 16);
     const uint32_t band_color_stride = cfg->prelit ? 1u : 2u;
@@ -404,6 +406,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && color && (normals || cfg->prelit) && projected);
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner));
+    ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC);
+    // the oriented disc (SequentialRenderer's footprint): its projector needs the normals, its records live with the binner
+    const bool disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
+    ARG_CHECK(ctx, !disc || (normals && (((uintptr_t)normals) & 15) == 0));
     if (n > splat_sort_capacity(sorter)) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_render_frame: n exceeds the sorter's capacity");
     ARG_CHECK(ctx, width >= 1 && height >= 1);
     // SplatProjector.project + DepthKeyExtractor.extract fused; props is the interleaved buffer.
@@ -430,9 +436,17 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         if (rc != SPLAT_OK) return rc;
         ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, 1024)};
     }
+    if (disc && n > binner->discs_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (binner->discs) (void)hipFree(binner->discs);
+        binner->discs = nullptr;
+        binner->discs_cap = 0;
+        if (hipMalloc(&binner->discs, (size_t)n * 32 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "disc records hipMalloc");
+        binner->discs_cap = n;
+    }
     // (the payload array is not written: payload = splat index)
     rc = project_launch(ctx, uniforms, props, pos_stride, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
-                        tile_first ? &ho : nullptr);
+                        tile_first ? &ho : nullptr, normals, 1, disc ? binner->discs : nullptr);
     if (rc != SPLAT_OK) return rc;
     binner->tf_hist_ready = tile_first;
     if (tile_first) {
@@ -457,8 +471,8 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         rc = ctx_ensure_consumed(ctx, ntx * nty);
         if (rc != SPLAT_OK) return rc;
     }
-    return splat_composite(ctx, cfg, color, color_stride, normals, 1, projected, indices, counts, offsets, width, height, out_rgba8,
-                           out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
+    return splat_composite(ctx, cfg, color, color_stride, normals, 1, disc && n ? binner->discs : projected, indices, counts, offsets,
+                           width, height, out_rgba8, out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
 }
 
 extern "C" {

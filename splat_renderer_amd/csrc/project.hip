@@ -11,6 +11,7 @@
 // the order written, identical to oracle/oracle.c, so records and keys are bit-exact.
 #include "common.h"
 #include "tile_range.h"
+#include "disc.h"
 
 struct FrameUniforms {
     float m[16];   // VP, column-major
@@ -59,17 +60,40 @@ __device__ __forceinline__ float4 project_centre(const FrameUniforms &u, float4 
     return make_float4(scx, scy, max_r, depth);
 }
 
+// The oriented-disc projector's second input and output (disc.h): normals in, 32-byte disc records out.
+struct DiscIO {
+    const float4 *normals;
+    uint32_t normal_stride;
+    float4 *discs;
+};
+
 // One splat: record, key, payload, packed tile range.  Returns the packed range (1 = empty).
-template <bool WITH_KEYS, bool WITH_RANGE>
+// DISC: the footprint is SequentialRenderer's oriented disc — the ProjectedSplat's bounds are the disc's exact
+// screen extent, screenRadius half the larger one, and the disc record goes to dio.discs.
+template <bool WITH_KEYS, bool WITH_RANGE, bool DISC>
 __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                 uint32_t i, uint32_t index_base, float4 *__restrict__ projected,
                                                 uint32_t *__restrict__ keys, uint32_t *__restrict__ payload,
-                                                uint32_t *__restrict__ range32, const BinParams &bp) {
-    const float4 c = project_centre(u, pos_radius[(size_t)i * stride_vec4]);
-    const float scx = c.x, scy = c.y, max_r = c.z, depth = c.w;
-    float padded = max_r * 1.5f; // :119
-    float4 a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
-    float4 b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
+                                                uint32_t *__restrict__ range32, const BinParams &bp, const DiscIO &dio) {
+    float4 a, b;
+    float depth;
+    if (DISC) {
+        const float4 pr = pos_radius[(size_t)i * stride_vec4];
+        const DiscRecord d = disc_record(u.m, u.w, u.h, pr, dio.normals[(size_t)i * dio.normal_stride]);
+        dio.discs[(size_t)i * 2] = d.a;
+        dio.discs[(size_t)i * 2 + 1] = d.b;
+        disc_bounds(d, a);
+        const float dx = pr.x - u.eye[0], dy = pr.y - u.eye[1], dz = pr.z - u.eye[2];
+        depth = sqrtf((dx * dx + dy * dy) + dz * dz); // SplatProjector.ts:77: the sort key does not depend on the footprint
+        b = make_float4(depth, 0.5f * fmaxf(a.z - a.x, a.w - a.y), __uint_as_float(index_base + i), 0.0f);
+    } else {
+        const float4 c = project_centre(u, pos_radius[(size_t)i * stride_vec4]);
+        const float scx = c.x, scy = c.y, max_r = c.z;
+        depth = c.w;
+        float padded = max_r * 1.5f; // :119
+        a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
+        b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
+    }
     projected[(size_t)i * 2] = a;
     projected[(size_t)i * 2 + 1] = b;
     if (WITH_KEYS) {
@@ -106,11 +130,12 @@ __global__ __launch_bounds__(256) void k_expand_compact(const float4 *__restrict
     projected[(size_t)i * 2 + 1] = make_float4(c.w, c.z, __uint_as_float(index_base + i), 0.0f);
 }
 
-template <bool WITH_KEYS, bool WITH_RANGE>
+template <bool WITH_KEYS, bool WITH_RANGE, bool DISC>
 __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
                                                  uint32_t stride_vec4, uint32_t n, uint32_t n_padded, uint32_t index_base,
                                                  float4 *__restrict__ projected, uint32_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, BinParams bp) {
+                                                 uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, BinParams bp,
+                                                 DiscIO dio) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) {
         if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
@@ -119,17 +144,18 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
         }
         return;
     }
-    project_one<WITH_KEYS, WITH_RANGE>(u, pos_radius, stride_vec4, i, index_base, projected, keys, payload, range32, bp);
+    project_one<WITH_KEYS, WITH_RANGE, DISC>(u, pos_radius, stride_vec4, i, index_base, projected, keys, payload, range32, bp, dio);
 }
 
 // Tile-first frame path: 1024 splats per workgroup (the binner's block), and while each splat's tile
 // rectangle is in registers the block's pairs are counted per low tile-id digit — the histogram the
 // first pass of the tile-id sort needs (tile_first.hip; k_band_prepare_tf in frame.hip does the same for
 // the gathered records of a multi-GPU band).  The kernel is HBM-bound; the LDS counting hides under the stores.
+template <bool DISC>
 __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                       uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
-                                                      TfHistOut ho) {
+                                                      TfHistOut ho, DiscIO dio) {
     __shared__ uint32_t lh[4][256];
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
@@ -144,7 +170,7 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
             if (i < n_padded) keys[i] = 0xffffffffu;
             continue;
         }
-        const uint32_t r = project_one<true, true>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp);
+        const uint32_t r = project_one<true, true, DISC>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
         local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
@@ -209,27 +235,39 @@ static void load_uniforms(FrameUniforms &u, const float *uniforms) {
 
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
-                   const BinParams *bp, const TfHistOut *hist_out) {
+                   const BinParams *bp, const TfHistOut *hist_out, const void *normals, uint32_t normal_stride_vec4, void *discs) {
     FrameUniforms u;
     load_uniforms(u, uniforms);
     const uint32_t work = keys ? n_padded : n;
     if (work == 0) return SPLAT_OK;
     BinParams none = {0, 0, 1, 0, 0, 0, 0};
     const float4 *src = (const float4 *)pos_radius + (size_t)index_base * pr_stride_vec4;
+    const bool disc = discs != nullptr; // the oriented-disc footprint (disc.h): normals in, disc records out
+    const DiscIO dio = {disc ? (const float4 *)normals + (size_t)index_base * normal_stride_vec4 : nullptr, normal_stride_vec4,
+                        (float4 *)discs};
     stage_begin(ctx, SPLAT_STAGE_PROJECT);
     dim3 grid(div_up(work, 256)), block(256);
-    if (hist_out && keys && range32 && !payload && index_base == 0)
-        hipLaunchKernelGGL(k_project_hist, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
-                           (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out);
-    else if (keys && range32)
-        hipLaunchKernelGGL((k_project<true, true>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, index_base,
-                           (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, range32, *bp);
-    else if (keys)
-        hipLaunchKernelGGL((k_project<true, false>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, index_base,
-                           (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, nullptr, none);
-    else
-        hipLaunchKernelGGL((k_project<false, false>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n, index_base,
-                           (float4 *)projected, nullptr, nullptr, nullptr, none);
+#define SPLAT_PROJECT_LAUNCH(K, R, D, RANGE, BP)                                                                                \
+    hipLaunchKernelGGL((k_project<K, R, D>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, keys ? n_padded : n, index_base, \
+                       (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, RANGE, BP, dio)
+    if (hist_out && keys && range32 && !payload && index_base == 0) {
+        if (disc)
+            hipLaunchKernelGGL(k_project_hist<true>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
+        else
+            hipLaunchKernelGGL(k_project_hist<false>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
+    } else if (keys && range32) {
+        if (disc) SPLAT_PROJECT_LAUNCH(true, true, true, range32, *bp);
+        else SPLAT_PROJECT_LAUNCH(true, true, false, range32, *bp);
+    } else if (keys) {
+        if (disc) SPLAT_PROJECT_LAUNCH(true, false, true, nullptr, none);
+        else SPLAT_PROJECT_LAUNCH(true, false, false, nullptr, none);
+    } else {
+        if (disc) SPLAT_PROJECT_LAUNCH(false, false, true, nullptr, none);
+        else SPLAT_PROJECT_LAUNCH(false, false, false, nullptr, none);
+    }
+#undef SPLAT_PROJECT_LAUNCH
     LAUNCH_CHECK(ctx, "k_project");
     stage_end(ctx, SPLAT_STAGE_PROJECT);
     return SPLAT_OK;
@@ -246,6 +284,20 @@ int splat_project(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
     ARG_CHECK(ctx, keys == nullptr || n_padded >= n);
     ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)projected) & 15) == 0);
     return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, n, 0, projected, keys, payload, n_padded, nullptr, nullptr, nullptr);
+}
+
+int splat_project_disc(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, const void *normals,
+                       uint32_t normal_stride_vec4, uint32_t n, void *projected, void *discs, void *keys, void *payload,
+                       uint32_t n_padded) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, uniforms && (n == 0 || (pos_radius && normals && projected && discs)));
+    ARG_CHECK(ctx, pr_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
+    ARG_CHECK(ctx, (keys == nullptr) == (payload == nullptr));
+    ARG_CHECK(ctx, keys == nullptr || n_padded >= n);
+    ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)normals | (uintptr_t)projected | (uintptr_t)discs) & 15) == 0);
+    // (n == 0 with keys only pads them, which either footprint's kernel does)
+    return project_launch(ctx, uniforms, pos_radius, pr_stride_vec4, n, 0, projected, keys, payload, n_padded, nullptr, nullptr, nullptr,
+                          normals, normal_stride_vec4, n ? discs : nullptr);
 }
 
 int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t first,

@@ -281,29 +281,57 @@ class SplatPropertyManager:
             self._planes = None
 
 
-class SplatProjector:
-    """src/SplatProjector.ts:5-203."""
+def _footprint(value):
+    if value in (None, "isotropic", _lib.FOOTPRINT_ISOTROPIC):
+        return _lib.FOOTPRINT_ISOTROPIC
+    if value in ("disc", _lib.FOOTPRINT_DISC):
+        return _lib.FOOTPRINT_DISC
+    raise SplatError(-1, f"footprint must be 'isotropic' or 'disc', not {value!r}")
 
-    def __init__(self, device, numSplats):
+
+class SplatProjector:
+    """src/SplatProjector.ts:5-203.
+
+    footprint="disc" (extension): project SequentialRenderer's oriented disc instead of the
+    isotropic screen-space Gaussian — project() then needs the normals, the ProjectedSplat bounds are the disc's
+    exact screen extent and getDiscBuffer() holds the 32-byte disc records the composite evaluates."""
+
+    def __init__(self, device, numSplats, footprint="isotropic"):
         self.device, self.numSplats = device, numSplats
+        self.footprint = _footprint(footprint)
         self.projectedBuffer = device.createBuffer(numSplats * 32)  # :19-23
+        self.discBuffer = device.createBuffer(numSplats * 32) if self.footprint == _lib.FOOTPRINT_DISC else None
 
     def project(self, commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer=None, payloadBuffer=None,
-                paddedSize=0):  # :174-194
+                paddedSize=0, normalsBuffer=None):  # :174-194
         """keysBuffer/payloadBuffer (extension): fuse DepthKeyExtractor.extract into the same kernel."""
         d = self.device
         u = _uniform_floats(uniformBuffer)
         if u.shape[0] < 22:
             raise SplatError(-1, "uniform block needs 22 floats (VP, eye, time, screenW, screenH)")
-        check(d.lib.splat_project(d.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), splatPropertyBuffer.ptr, 2, self.numSplats,
-                                  self.projectedBuffer.ptr, keysBuffer.ptr if keysBuffer else None,
-                                  payloadBuffer.ptr if payloadBuffer else None, paddedSize), d.ctx)
+        uptr = u.ctypes.data_as(C.POINTER(C.c_float))
+        keys, payload = keysBuffer.ptr if keysBuffer else None, payloadBuffer.ptr if payloadBuffer else None
+        if self.footprint == _lib.FOOTPRINT_DISC:
+            if normalsBuffer is None:
+                raise SplatError(-1, "SplatProjector(footprint='disc').project needs normalsBuffer")
+            check(d.lib.splat_project_disc(d.ctx, uptr, splatPropertyBuffer.ptr, 2, normalsBuffer.ptr, 1, self.numSplats,
+                                           self.projectedBuffer.ptr, self.discBuffer.ptr, keys, payload, paddedSize), d.ctx)
+            return
+        check(d.lib.splat_project(d.ctx, uptr, splatPropertyBuffer.ptr, 2, self.numSplats, self.projectedBuffer.ptr, keys, payload,
+                                  paddedSize), d.ctx)
 
     def getProjectedBuffer(self):  # :196-198
         return self.projectedBuffer
 
+    def getDiscBuffer(self):
+        if self.discBuffer is None:
+            raise SplatError(-5, "getDiscBuffer: this projector was not created with footprint='disc'")
+        return self.discBuffer
+
     def destroy(self):  # :200-202
         self.projectedBuffer.destroy()
+        if self.discBuffer is not None:
+            self.discBuffer.destroy()
 
 
 class DepthKeyExtractor:
@@ -481,9 +509,11 @@ class ComputeShaderRenderer:
     :425-456) is out of scope (no canvas); the rgba8unorm output texture is exposed instead."""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", mode=_lib.MODE_FRONT_TO_BACK,
-                 earlyOut=True):
+                 earlyOut=True, footprint="isotropic"):
         self.device = device
         self.mode, self.earlyOut = mode, earlyOut
+        # footprint="disc": projectedBuffer in render() is SplatProjector(footprint="disc").getDiscBuffer()
+        self.footprint = _footprint(footprint)
         self.outputTexture = None
         self.outputFloat = None
         self._wh = (0, 0)
@@ -508,7 +538,7 @@ class ComputeShaderRenderer:
         if numTilesX != -(-width // tileSize):
             raise SplatError(-1, "numTilesX does not match ceil(width / tileSize)")
         self.ensureOutputTexture(width, height, wantFloat)
-        cfg = CompositeCfg(self.mode, int(self.earlyOut), tileSize, self.tileRows[0], self.tileRows[1])
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), tileSize, self.tileRows[0], self.tileRows[1], 0, 0, self.footprint)
         check(d.lib.splat_composite(d.ctx, C.byref(cfg), splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
                                     projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr,
                                     width, height, self.outputTexture.ptr,
@@ -538,7 +568,9 @@ class TileRenderer(ComputeShaderRenderer):
     loop over a fixed-stride index layout (:291); north_star names this class for the per-pixel
     composite, so here it fronts the same HIP composite as ComputeShaderRenderer.  render() keeps
     the reference's argument list; the projected records and prefix-sum offsets the composite
-    needs (absent from that list) are bound beforehand with bindTileData()."""
+    needs (absent from that list) are bound beforehand with bindTileData().  footprint="disc" gives
+    the reference TileRenderer's own footprint (the oriented quad of its vertex shader, the same as
+    SequentialRenderer's): bind the disc projector's getDiscBuffer() as the records then."""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", **kw):
         super().__init__(device, context, presentationFormat, **kw)
@@ -560,30 +592,36 @@ class TileRenderer(ComputeShaderRenderer):
 
 class SequentialRenderer:
     """src/SequentialRenderer.ts:5-321 — the ordering-exact path: one draw per splat in the order of a
-    caller-supplied sorted index buffer (:268-307).  The reference does this with the hardware
-    rasteriser and an oriented-quad footprint ("model B"), which only the CPU oracle
-    restates.  This class keeps the name, constructor and render() arguments and honours the
-    caller's order exactly — it bins the given order and composites it with the HIP kernel — but
-    with the ComputeShaderRenderer footprint (model A), nearest-first: pass near-to-far indices
-    (RadixSorter's order), not the reversed order the reference's blend state needs."""
+    caller-supplied sorted index buffer (:268-307), each an oriented quad in the tangent plane of the
+    splat's normal with a Gaussian cut at the unit disc (:91-142).  The reference does this with the
+    hardware rasteriser, one draw call per splat; here the given order is binned and composited per
+    pixel by the HIP kernel with the same footprint (footprint="disc", the default: the rasteriser's
+    perspective-correct uv is the inverse plane-to-screen homography, evaluated per pixel), nearest
+    first: pass near-to-far indices (RadixSorter's order) — the image is the one the reference's
+    blend state (:189-200) gives for the reversed, back-to-front order.  Compared with the oracle's
+    software rasteriser in tests/ (<= 1e-4 per channel, except pixels within 1e-3 of a disc's rim,
+    where the discard is a step of 0.044).  footprint="isotropic" composites the same order with
+    ComputeShaderRenderer's screen-space Gaussian instead."""
 
-    def __init__(self, device, context=None, presentationFormat="rgba8unorm", numSplats=0, tileSize=16):
+    def __init__(self, device, context=None, presentationFormat="rgba8unorm", numSplats=0, tileSize=16, footprint="disc",
+                 earlyOut=True):
         self.device, self.numSplats, self.tileSize = device, numSplats, tileSize
-        self.projector = SplatProjector(device, numSplats)
+        self.projector = SplatProjector(device, numSplats, footprint)
         self.binner = GPUTileBinner(device, tileSize)
-        self.compositor = ComputeShaderRenderer(device, context, presentationFormat)
+        self.compositor = ComputeShaderRenderer(device, context, presentationFormat, earlyOut=earlyOut, footprint=footprint)
 
     def render(self, uniformData, splatPropertyBuffer, sortedIndexBuffer, curvatureBuffer, width, height,
                wantFloat=False):  # :233-314
         u = _uniform_floats(uniformData).copy()
         if u.shape[0] < 22:
             u = np.concatenate([u[:20], np.array([width, height], np.float32)])
-        self.projector.project(None, u, splatPropertyBuffer)
+        disc = self.projector.footprint == _lib.FOOTPRINT_DISC
+        self.projector.project(None, u, splatPropertyBuffer, normalsBuffer=curvatureBuffer if disc else None)
         self.binner.binSplats(None, self.projector.getProjectedBuffer(), sortedIndexBuffer, self.numSplats, width, height)
-        self.compositor.render(u, splatPropertyBuffer, self.binner.getTileIndicesBuffer(), curvatureBuffer,
-                               self.projector.getProjectedBuffer(), self.binner.getTileCountsBuffer(),
-                               self.binner.getTileOffsetsBuffer(), self.tileSize, -(-width // self.tileSize), width, height,
-                               wantFloat)
+        records = self.projector.getDiscBuffer() if disc else self.projector.getProjectedBuffer()
+        self.compositor.render(u, splatPropertyBuffer, self.binner.getTileIndicesBuffer(), curvatureBuffer, records,
+                               self.binner.getTileCountsBuffer(), self.binner.getTileOffsetsBuffer(), self.tileSize,
+                               -(-width // self.tileSize), width, height, wantFloat)
 
     def readPixels(self):
         return self.compositor.readPixels()
@@ -603,7 +641,10 @@ class Renderer:
     on the device.  (The reference's body — opaque depth-tested quads — is out of scope.)"""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", numPoints=0, tileSize=16,
-                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None):
+                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None, footprint="isotropic"):
+        # footprint="disc": the frame is drawn with SequentialRenderer's oriented discs (normalsBuffer is then
+        # required in render() even with pre-lit planes: the projector reads it)
+        self.footprint = _footprint(footprint)
         self.device, self.numPoints, self.tileSize = device, numPoints, tileSize
         self.projector = SplatProjector(device, numPoints)
         self.sorter = RadixSorter(device, numPoints)
@@ -634,7 +675,7 @@ class Renderer:
         if wantFloat and self.outputFloat is None:
             self.outputFloat = d.createBuffer(width * height * 16)
         prelit = isinstance(propertyBuffer, PropertyPlanes) and propertyBuffer.prelit
-        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], 0, int(prelit))
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], 0, int(prelit), self.footprint)
         tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
                 self.outputFloat.ptr if wantFloat else None)
         head = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)))

@@ -15,14 +15,16 @@ export class Camera {
 }
 export interface PropertyPlanes { posRadius: Buffer; colorOpacity: Buffer; isPlanes: true; prelit?: boolean; }
 export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; updatePlanesFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): PropertyPlanes; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; getPropertyPlanes(): PropertyPlanes; getLitPlanes(normalsBuffer: Buffer): PropertyPlanes; destroy(): void; }
-export class SplatProjector { constructor(device: Device, numSplats: number); project(enc: CommandEncoder | null, uniformBuffer: Buffer | Float32Array, splatPropertyBuffer: Buffer, keysBuffer?: Buffer | null, payloadBuffer?: Buffer | null, paddedSize?: number): void; getProjectedBuffer(): Buffer; destroy(): void; }
+export type Footprint = "isotropic" | "disc" | 0 | 1;
+export class SplatProjector { constructor(device: Device, numSplats: number, footprint?: Footprint); project(enc: CommandEncoder | null, uniformBuffer: Buffer | Float32Array, splatPropertyBuffer: Buffer, keysBuffer?: Buffer | null, payloadBuffer?: Buffer | null, paddedSize?: number, normalsBuffer?: Buffer | null): void; getProjectedBuffer(): Buffer; getDiscBuffer(): Buffer; destroy(): void; }
 export class DepthKeyExtractor { constructor(device: Device); extract(enc: CommandEncoder | null, projectedBuffer: Buffer, keysBuffer: Buffer, payloadBuffer: Buffer, numSplats: number, paddedSize: number): void; cleanupTempBuffers(): void; }
 export class RadixSorter { constructor(device: Device, numSplats: number); readonly paddedSize: number; sort(numKeys?: number, bitBegin?: number, bitEnd?: number): void; getSortedIndicesBuffer(): Buffer; getKeysBuffer(): Buffer; getPayloadBuffer(): Buffer; cleanupTempBuffers(): void; destroy(): void; }
 export class PrefixSumScanner { constructor(device: Device); scan(enc: CommandEncoder | null, inputBuffer: Buffer, outputBuffer: Buffer, numElements: number): Promise<void>; cleanupTempBuffers(): void; }
 export class GPUTileBinner { constructor(device: Device, tileSize: number); setFrameOrder(order: "default" | "sortFirst" | "tileFirst"): void; binSplats(enc: CommandEncoder | null, projectedBuffer: Buffer, sortedIndicesBuffer: Buffer, numSplats: number, screenWidth: number, screenHeight: number): Promise<void>; getTileOffsetsBuffer(): Buffer; getTileIndicesBuffer(): Buffer; getTileCountsBuffer(): Buffer; getTotalIndices(): number; getTileSize(): number; cleanupTempBuffers(): void; destroy(): void; }
 export class PerTileSorter { constructor(device: Device, validate?: boolean); violations: number; sort(enc: CommandEncoder | null, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, splatIndicesBuffer: Buffer, numTiles: number, maxSplatsPerTile: number, totalPairs?: number): number | undefined; cleanupTempBuffers(): void; destroy(): void; }
-export class SequentialRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numSplats?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, splatPropertyBuffer: Buffer, sortedIndexBuffer: Buffer, curvatureBuffer: Buffer, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
-export class ComputeShaderRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean }); render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
+export class SequentialRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numSplats?: number, tileSize?: number, footprint?: Footprint); render(uniformData: Float32Array | Buffer, splatPropertyBuffer: Buffer, sortedIndexBuffer: Buffer, curvatureBuffer: Buffer, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
+export class ComputeShaderRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean; footprint?: Footprint }); render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
 export class TileRenderer extends ComputeShaderRenderer { bindTileData(projectedBuffer: Buffer, tileCountsBuffer: Buffer, tileOffsetsBuffer: Buffer): void; }
-export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number); render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer | PropertyPlanes, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
+export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number, options?: { footprint?: Footprint }); render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer | PropertyPlanes, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
 export const MODE_FRONT_TO_BACK: 0; export const MODE_REFERENCE_LITERAL: 1;
+export const FOOTPRINT_ISOTROPIC: 0; export const FOOTPRINT_DISC: 1;

@@ -13,6 +13,7 @@ const native = require('./splat_napi.node');
 
 const U32_MAX = 0xffffffff;
 const MODE_FRONT_TO_BACK = 0;
+const FOOTPRINT_ISOTROPIC = 0, FOOTPRINT_DISC = 1;
 const MODE_REFERENCE_LITERAL = 1;
 
 class Buffer_ {
@@ -100,16 +101,34 @@ class SplatPropertyManager {
 }
 
 /** src/SplatProjector.ts:5-203 */
+function footprintCode(f) {
+  if (f === undefined || f === null || f === 'isotropic' || f === FOOTPRINT_ISOTROPIC) return FOOTPRINT_ISOTROPIC;
+  if (f === 'disc' || f === FOOTPRINT_DISC) return FOOTPRINT_DISC;
+  throw new Error(`footprint must be 'isotropic' or 'disc', not ${f}`);
+}
+/** footprint 'disc' (extension): SequentialRenderer's oriented disc — project() then needs normalsBuffer, the bounds are
+ * the disc's exact screen extent and getDiscBuffer() holds the 32-byte records the composite evaluates. */
 class SplatProjector {
-  constructor(device, numSplats) { this.device = device; this.numSplats = numSplats; this.projectedBuffer = device.createBuffer(numSplats * 32); }
-  project(commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer = null, payloadBuffer = null, paddedSize = 0) { // :174-194
+  constructor(device, numSplats, footprint = 'isotropic') {
+    this.device = device; this.numSplats = numSplats; this.footprint = footprintCode(footprint);
+    this.projectedBuffer = device.createBuffer(numSplats * 32);
+    this.discBuffer = this.footprint === FOOTPRINT_DISC ? device.createBuffer(numSplats * 32) : null;
+  }
+  project(commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer = null, payloadBuffer = null, paddedSize = 0, normalsBuffer = null) { // :174-194
     const u = uniformFloats(uniformBuffer);
     if (u.length < 22) throw new Error('uniform block needs 22 floats (VP, eye, time, screenW, screenH)');
-    native.project(this.device.ctx, u, splatPropertyBuffer.ptr, 2, this.numSplats, this.projectedBuffer.ptr,
-      keysBuffer ? keysBuffer.ptr : null, payloadBuffer ? payloadBuffer.ptr : null, paddedSize);
+    const keys = keysBuffer ? keysBuffer.ptr : null, payload = payloadBuffer ? payloadBuffer.ptr : null;
+    if (this.footprint === FOOTPRINT_DISC) {
+      if (!normalsBuffer) throw new Error("SplatProjector(footprint 'disc').project needs normalsBuffer");
+      native.project_disc(this.device.ctx, u, splatPropertyBuffer.ptr, 2, normalsBuffer.ptr, 1, this.numSplats, this.projectedBuffer.ptr,
+        this.discBuffer.ptr, keys, payload, paddedSize);
+      return;
+    }
+    native.project(this.device.ctx, u, splatPropertyBuffer.ptr, 2, this.numSplats, this.projectedBuffer.ptr, keys, payload, paddedSize);
   }
   getProjectedBuffer() { return this.projectedBuffer; } // :196-198
-  destroy() { this.projectedBuffer.destroy(); }          // :200-202
+  getDiscBuffer() { if (!this.discBuffer) throw new Error("getDiscBuffer: this projector was not created with footprint 'disc'"); return this.discBuffer; }
+  destroy() { this.projectedBuffer.destroy(); if (this.discBuffer) this.discBuffer.destroy(); }          // :200-202
 }
 
 /** src/DepthKeyExtractor.ts:5-115 */
@@ -188,6 +207,7 @@ class PerTileSorter {
 class ComputeShaderRenderer {
   constructor(device, context = null, presentationFormat = 'rgba8unorm', options = {}) {
     this.device = device; this.mode = options.mode || MODE_FRONT_TO_BACK; this.earlyOut = options.earlyOut !== false;
+    this.footprint = footprintCode(options.footprint); // 'disc': projectedBuffer in render() is the disc projector's getDiscBuffer()
     this.outputTexture = null; this.width = 0; this.height = 0;
   }
   ensureOutputTexture(width, height) { // :340-360
@@ -199,7 +219,7 @@ class ComputeShaderRenderer {
   render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, tileSize, numTilesX, width, height) { // :362-462
     if (numTilesX !== Math.ceil(width / tileSize)) throw new Error('numTilesX does not match ceil(width / tileSize)');
     this.ensureOutputTexture(width, height);
-    native.composite(this.device.ctx, [this.mode, this.earlyOut ? 1 : 0, tileSize, 0, U32_MAX], splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
+    native.composite(this.device.ctx, [this.mode, this.earlyOut ? 1 : 0, tileSize, 0, U32_MAX, 0, 0, this.footprint], splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
       projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr, width, height, this.outputTexture.ptr, null);
   }
   readPixels() { return this.outputTexture.read(new Uint8Array(this.width * this.height * 4)); }
@@ -215,22 +235,24 @@ class TileRenderer extends ComputeShaderRenderer {
   }
 }
 
-/** src/SequentialRenderer.ts:5-321 — ordering-exact path: composites exactly the order of the caller's
- * sorted index buffer (near-to-far), with the ComputeShaderRenderer footprint; the reference's
- * oriented-quad hardware raster (model B) exists only in the CPU oracle. */
+/** src/SequentialRenderer.ts:5-321 — ordering-exact path: composites exactly the order of the caller's sorted index
+ * buffer (near-to-far) with the reference's own footprint, the oriented disc of its vertex/fragment pair (:91-142),
+ * evaluated per pixel through the inverse plane-to-screen homography (footprint 'disc', the default); 'isotropic'
+ * composites the same order with ComputeShaderRenderer's screen-space Gaussian. */
 class SequentialRenderer {
-  constructor(device, context = null, presentationFormat = 'rgba8unorm', numSplats = 0, tileSize = 16) {
+  constructor(device, context = null, presentationFormat = 'rgba8unorm', numSplats = 0, tileSize = 16, footprint = 'disc') {
     this.device = device; this.numSplats = numSplats; this.tileSize = tileSize;
-    this.projector = new SplatProjector(device, numSplats); this.binner = new GPUTileBinner(device, tileSize);
-    this.compositor = new ComputeShaderRenderer(device, context, presentationFormat);
+    this.projector = new SplatProjector(device, numSplats, footprint); this.binner = new GPUTileBinner(device, tileSize);
+    this.compositor = new ComputeShaderRenderer(device, context, presentationFormat, { footprint });
   }
   render(uniformData, splatPropertyBuffer, sortedIndexBuffer, curvatureBuffer, width, height) { // :233-314
     let u = uniformFloats(uniformData);
     if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
-    this.projector.project(null, u, splatPropertyBuffer);
+    const disc = this.projector.footprint === FOOTPRINT_DISC;
+    this.projector.project(null, u, splatPropertyBuffer, null, null, 0, disc ? curvatureBuffer : null);
     native.bin_run(this.device.ctx, this.binner.handle, this.projector.getProjectedBuffer().ptr, this.numSplats, sortedIndexBuffer.ptr, this.numSplats, width, height, 0, U32_MAX);
     this.binner.numTiles = Math.ceil(width / this.tileSize) * Math.ceil(height / this.tileSize);
-    this.compositor.render(u, splatPropertyBuffer, this.binner.getTileIndicesBuffer(), curvatureBuffer, this.projector.getProjectedBuffer(),
+    this.compositor.render(u, splatPropertyBuffer, this.binner.getTileIndicesBuffer(), curvatureBuffer, disc ? this.projector.getDiscBuffer() : this.projector.getProjectedBuffer(),
       this.binner.getTileCountsBuffer(), this.binner.getTileOffsetsBuffer(), this.tileSize, Math.ceil(width / this.tileSize), width, height);
   }
   readPixels() { return this.compositor.readPixels(); }
@@ -239,8 +261,9 @@ class SequentialRenderer {
 
 /** src/Renderer.ts:13,250,311 — name kept as the whole-frame facade (project -> keys -> sort -> bin -> composite) */
 class Renderer {
-  constructor(device, context = null, presentationFormat = 'rgba8unorm', numPoints = 0, tileSize = 16) {
+  constructor(device, context = null, presentationFormat = 'rgba8unorm', numPoints = 0, tileSize = 16, options = {}) {
     this.device = device; this.numPoints = numPoints; this.tileSize = tileSize;
+    this.footprint = footprintCode(options.footprint); // 'disc': SequentialRenderer's oriented discs (normalsBuffer then always required)
     this.projector = new SplatProjector(device, numPoints); this.sorter = new RadixSorter(device, numPoints); this.binner = new GPUTileBinner(device, tileSize);
     this.output = null; this.width = 0; this.height = 0;
   }
@@ -248,7 +271,7 @@ class Renderer {
     let u = uniformFloats(uniformData);
     if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
     if (this.width !== width || this.height !== height) { if (this.output) this.output.destroy(); this.output = this.device.createBuffer(width * height * 4); this.width = width; this.height = height; }
-    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, 0, propertyBuffer.prelit ? 1 : 0];
+    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, 0, propertyBuffer.prelit ? 1 : 0, this.footprint];
     if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
       native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,
         normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
@@ -302,4 +325,5 @@ class Camera {
 }
 
 module.exports = { native, Device, Buffer: Buffer_, Camera, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
-  GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, SequentialRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL };
+  GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, SequentialRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL,
+  FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC };

@@ -189,6 +189,14 @@ FN(project) { /* (ctx, Float32Array(22), posRadius, strideVec4, n, projected, ke
     if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
     return check(env, x, splat_project(x, u, pr, st, n, proj, keys, pay, np), mk_undefined(env));
 }
+FN(project_disc) { /* (ctx, Float32Array(22), posRadius, strideVec4, normals, normalStrideVec4, n, projected, discs, keys|null, payload|null, nPadded) */
+    ARGS(12); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
+    void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3); void *nrm = arg_dptr(&c, 4);
+    uint32_t ns = (uint32_t)arg_number(&c, 5), n = (uint32_t)arg_number(&c, 6);
+    void *proj = arg_dptr(&c, 7), *discs = arg_dptr(&c, 8), *keys = arg_dptr(&c, 9), *pay = arg_dptr(&c, 10); uint32_t np = (uint32_t)arg_number(&c, 11); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_project_disc(x, u, pr, st, nrm, ns, n, proj, discs, keys, pay, np), mk_undefined(env));
+}
 FN(extract_keys) {
     ARGS(6); splat_ctx *x = arg_external(&c, 0); void *proj = arg_dptr(&c, 1); uint32_t n = (uint32_t)arg_number(&c, 2), np = (uint32_t)arg_number(&c, 3);
     void *k = arg_dptr(&c, 4), *p = arg_dptr(&c, 5); BAIL;
@@ -249,19 +257,19 @@ FN(validate_tile_order) { /* (ctx, projected, offsets, numTiles, indices, totalP
     uint64_t v = 0; int rc = splat_validate_tile_order(x, proj, off, nt, idx, total, &v);
     return check(env, x, rc, mk_number(env, (double)v));
 }
-static void fill_cfg(call_t *c, size_t i, splat_composite_cfg *cfg) { /* [mode, earlyOut, tile, row0, row1, recordFormat?, prelit?] */
+static void fill_cfg(call_t *c, size_t i, splat_composite_cfg *cfg) { /* [mode, earlyOut, tile, row0, row1, recordFormat?, prelit?, footprint?] */
     memset(cfg, 0, sizeof *cfg);
-    uint32_t v[7] = {0, 1, 16, 0, 0xffffffffu, 0, 0};
+    uint32_t v[8] = {0, 1, 16, 0, 0xffffffffu, 0, 0, 0};
     bool is = false;
     napi_is_array(c->env, c->argv[i], &is);
     if (is)
-        for (uint32_t k = 0; k < 7; ++k) {
+        for (uint32_t k = 0; k < 8; ++k) {
             napi_value e;
             double d;
             if (napi_get_element(c->env, c->argv[i], k, &e) == napi_ok && napi_get_value_double(c->env, e, &d) == napi_ok) v[k] = (uint32_t)d;
         }
     cfg->mode = v[0]; cfg->early_out = v[1]; cfg->tile_size = v[2]; cfg->tile_row0 = v[3]; cfg->tile_row1 = v[4];
-    cfg->record_format = v[5]; cfg->prelit = v[6];
+    cfg->record_format = v[5]; cfg->prelit = v[6]; cfg->footprint = v[7];
 }
 FN(composite) { /* (ctx, cfg[5], color, cStride, normals, nStride, projected, indices, counts, offsets, W, H, out8|null, outF|null) */
     ARGS(14); splat_ctx *x = arg_external(&c, 0); splat_composite_cfg cfg; fill_cfg(&c, 1, &cfg);
@@ -294,7 +302,7 @@ static napi_value init(napi_env env, napi_value exports) {
     napi_property_descriptor d[] = {
         EXPORT(abi_version), EXPORT(ctx_create), EXPORT(ctx_destroy), EXPORT(sync), EXPORT(set_timing), EXPORT(stage_time_ms),
         EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props), EXPORT(update_props_planes), EXPORT(props_to_planes), EXPORT(lit_colors),
-        EXPORT(project), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
+        EXPORT(project), EXPORT(project_disc), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),

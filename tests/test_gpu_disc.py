@@ -1,0 +1,235 @@
+"""GPU parity tests for the oriented-disc footprint (SequentialRenderer's / TileRenderer's splat).
+
+Bit-exact: disc records, ProjectedSplat records (the disc's screen extent), keys, sort order, tile lists.
+Tolerance (stated below): composited pixels, against the oracle's per-pixel restatement AND against the oracle's
+software rasteriser of SequentialRenderer.ts (one oriented quad per splat, back to front).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import splat_renderer_amd as sr
+from oracle import oracle as O
+from splat_renderer_amd import _lib
+from tests.helpers import make_case
+
+pytestmark = pytest.mark.gpu
+
+# float RGBA in [0,1], early-out off.  The GPU evaluates (u,v) with v_rcp_f32 and contracted FMAs and the
+# Gaussian with exp2: a few ulp per layer.
+TOL = 3e-5
+# vs the software rasteriser (f64 edge functions / barycentrics, back-to-front blend): measured 5e-5 at C0
+TOL_RASTER = 1e-4
+# The fragment shader discards at u^2+v^2 > 1 where the Gaussian is still exp(-3.125) = 0.0439: a pixel within
+# rounding distance of a rim may be kept by one evaluation and discarded by another.  The oracle flags every pixel
+# within 1e-3 (in u^2+v^2) of some disc's rim; on those, and only those, a difference up to the step is accepted.
+TOL_RIM = 0.045
+MAX_RIM_FLIPS = 16       # pixels per image that actually flip (they are rare events even among flagged pixels)
+TOL_EARLY_OUT_BOUND = 0.0101  # early-out on: (1 - 0.99) * max colour, as for the isotropic footprint
+
+CASES = [
+    (10000, 256, 256, 1234, 1.0),  # C0
+    (3000, 160, 120, 8, 2.5),
+    (20000, 333, 200, 9, 1.0),     # ragged right/bottom tiles
+    (500, 64, 64, 6, 12.0),        # discs larger than the screen
+    (60000, 640, 360, 10, 0.7),
+]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def disc_case(n, w, h, seed, rs):
+    props, normals, u = make_case(n, w, h, seed, rs)
+    normals[::7, :3] = np.float32([0.05, 0.99, 0.1])  # |n.y| > 0.9 picks the other "up" (SequentialRenderer.ts:69)
+    if n > 20:
+        normals[5] = 0                                 # zero normal -> NaN tangent -> culled
+        props[9, :3] = [0.0, 0.0, 50.0]                # behind the camera -> culled
+        normals[11, :3] = 0.5 * normals[11, :3]        # non-unit normal: the bitangent scales with it (:96)
+    return props, normals, u
+
+
+def oracle_disc(props, normals, u, w, h, early_out=False, n_padded=None):
+    proj, discs = O.project_disc(u, props, normals)
+    keys, pay = O.extract_keys(proj, n_padded)
+    _, order = O.sort_pairs(keys, pay)
+    counts, offsets, idx = O.bin_sorted(proj, order, w, h)
+    img, img8, consumed, rim = O.composite_disc(early_out, props[:, 4:], normals, discs, idx, counts, offsets, w, h)
+    return dict(proj=proj, discs=discs, keys=keys, payload=pay, order=order, counts=counts, offsets=offsets, indices=idx,
+                img=img, img8=img8, rim=rim)
+
+
+def check_image(got, ref, tol=TOL):
+    d = np.abs(got - ref["img"]).max(axis=2)
+    assert d[ref["rim"] == 0].max() <= tol
+    assert d.max() <= TOL_RIM
+    assert (d > tol).sum() <= MAX_RIM_FLIPS
+
+
+@pytest.mark.parametrize("n,w,h,seed,rs", CASES + [(1, 64, 64, 1, 1.0), (7, 64, 48, 2, 1.0)])
+def test_disc_projector_bit_exact(device, n, w, h, seed, rs):
+    props, normals, u = disc_case(n, w, h, seed, rs)
+    ref = oracle_disc(props, normals, u, w, h, n_padded=sr.scene.padded_size(n))
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    proj = sr.SplatProjector(device, n, footprint="disc")
+    sorter = sr.RadixSorter(device, n)
+    with pytest.raises(sr.SplatError):
+        proj.project(None, u, pm.getPropertyBuffer())  # the disc projector reads the normals
+    proj.project(None, u, pm.getPropertyBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), sorter.paddedSize, normalsBuffer=nbuf)
+    assert np.array_equal(bits(proj.getDiscBuffer().read(np.float32)).reshape(n, 8), bits(ref["discs"]))
+    assert np.array_equal(bits(proj.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]))
+    assert np.array_equal(sorter.getKeysBuffer().read(np.uint32), ref["keys"])
+    assert np.array_equal(sorter.getPayloadBuffer().read(np.uint32), ref["payload"])
+    # from a position plane (stride 1) through the C ABI directly: same bits
+    planes = pm.getPropertyPlanes()
+    out_p, out_d = device.createBuffer(n * 32), device.createBuffer(n * 32)
+    uu = np.ascontiguousarray(u, np.float32)
+    _lib.check(device.lib.splat_project_disc(device.ctx, uu.ctypes.data_as(C.POINTER(C.c_float)), planes.posRadius.ptr, 1, nbuf.ptr, 1, n,
+                                             out_p.ptr, out_d.ptr, None, None, 0), device.ctx)
+    assert np.array_equal(bits(out_d.read(np.float32)).reshape(n, 8), bits(ref["discs"]))
+    assert np.array_equal(bits(out_p.read(np.float32)).reshape(n, 8), bits(ref["proj"]))
+    with pytest.raises(sr.SplatError):
+        sr.SplatProjector(device, 4).getDiscBuffer()
+    for o in (pm, nbuf, proj, sorter, out_p, out_d):
+        o.destroy()
+
+
+@pytest.mark.parametrize("n,w,h,seed,rs", CASES)
+@pytest.mark.parametrize("early_out", [False, True])
+def test_disc_staged_pipeline_vs_oracle(device, n, w, h, seed, rs, early_out):
+    props, normals, u = disc_case(n, w, h, seed, rs)
+    ref = oracle_disc(props, normals, u, w, h, early_out)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    proj = sr.SplatProjector(device, n, footprint="disc")
+    sorter = sr.RadixSorter(device, n)
+    binner = sr.GPUTileBinner(device, 16)
+    proj.project(None, u, pm.getPropertyBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), sorter.paddedSize, normalsBuffer=nbuf)
+    sorter.sort()
+    binner.binSplats(None, proj.getProjectedBuffer(), sorter.getSortedIndicesBuffer(), n, w, h)
+    total = ref["indices"].shape[0]
+    assert np.array_equal(sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n])
+    assert binner.getTotalIndices() == total
+    assert np.array_equal(binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    # TileRenderer with its own (the reference's) footprint
+    tr = sr.TileRenderer(device, None, "rgba8unorm", earlyOut=early_out, footprint="disc")
+    tr.bindTileData(proj.getDiscBuffer(), binner.getTileCountsBuffer(), binner.getTileOffsetsBuffer())
+    tr.render(u, pm.getPropertyBuffer(), binner.getTileIndicesBuffer(), nbuf, ref["counts"], -(-w // 16), -(-h // 16), 16, 4096, w, h,
+              wantFloat=True)
+    got, got8 = tr.readPixelsFloat(), tr.readPixels()
+    if early_out:
+        assert np.abs(got - ref["img"]).max() <= TOL_RIM
+        d = np.abs(got - ref["img"]).max(axis=2)
+        assert d[ref["rim"] == 0].max() <= TOL_EARLY_OUT_BOUND
+    else:
+        check_image(got, ref)
+        assert np.abs(got8.astype(int) - ref["img8"].astype(int)).max(axis=2)[ref["rim"] == 0].max() <= 1
+    assert (got8[..., 3] == 255).all()
+    for o in (pm, nbuf, proj, sorter, binner, tr):
+        o.destroy()
+
+
+@pytest.mark.parametrize("n,w,h,seed,rs", [(10000, 256, 256, 1234, 1.0), (3000, 160, 120, 8, 2.5)])
+def test_sequential_renderer_is_the_reference_rasteriser_image(device, n, w, h, seed, rs):
+    """SequentialRenderer (HIP, tile lists + inverse homography per pixel) against the oracle's software rasteriser of
+    SequentialRenderer.ts fed the reversed (back-to-front) order — north_star's parity statement."""
+    props, normals, u = make_case(n, w, h, seed, rs)
+    ref = oracle_disc(props, normals, u, w, h)
+    raster, raster8 = O.sequential(u, props, normals, ref["order"][::-1].copy(), w, h)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf, obuf = device.createBufferFrom(normals), device.createBufferFrom(ref["order"][:n])
+    r = sr.SequentialRenderer(device, None, "rgba8unorm", n, earlyOut=False)
+    r.render(u[:20], pm.getPropertyBuffer(), obuf, nbuf, w, h, wantFloat=True)
+    got, got8 = r.readPixelsFloat(), r.readPixels()
+    d = np.abs(got - raster).max(axis=2)
+    off_rim = ref["rim"] == 0
+    assert d[off_rim].max() <= TOL_RASTER
+    assert d.max() <= TOL_RIM and (d > TOL_RASTER).sum() <= MAX_RIM_FLIPS
+    assert np.abs(got8.astype(int) - raster8.astype(int)).max(axis=2)[off_rim].max() <= 1
+    mse = float(np.mean((got[..., :3] - raster[..., :3]) ** 2))
+    assert -10.0 * np.log10(max(mse, 1e-30)) > 70.0  # (the isotropic footprint is 18 dB from this image)
+    for o in (r, pm, nbuf, obuf):
+        o.destroy()
+
+
+@pytest.mark.parametrize("order", ["tileFirst", "sortFirst"])
+@pytest.mark.parametrize("layout", ["interleaved", "planes", "lit"])
+def test_disc_whole_frame(device, order, layout):
+    n, w, h = 40000, 400, 240
+    props, normals, u = disc_case(n, w, h, 23, 1.5)
+    ref = oracle_disc(props, normals, u, w, h, early_out=False)
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n, earlyOut=False, frameOrder=order, footprint="disc")
+    src = {"interleaved": pm.getPropertyBuffer, "planes": pm.getPropertyPlanes, "lit": lambda: pm.getLitPlanes(nbuf)}[layout]()
+    for _ in range(3):  # the later ones are sync-free frames
+        r.render(u, src, nbuf, None, w, h, wantFloat=True)
+    total = r.finish()
+    assert total == ref["indices"].shape[0]
+    assert np.array_equal(bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]))
+    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    check_image(r.readPixelsFloat(), ref)
+    if layout == "lit":
+        with pytest.raises(sr.SplatError):  # the disc projector needs the normals even when the colours are pre-lit
+            r.render(u, src, None, None, w, h)
+    for o in (r, pm, nbuf):
+        o.destroy()
+
+
+def test_disc_and_isotropic_frames_alternate_on_one_renderer_pair(device):
+    """Two renderers sharing nothing but the device: a disc frame must not disturb an isotropic one and vice versa."""
+    n, w, h = 8000, 200, 120
+    props, normals, u = make_case(n, w, h, 31, 2.0)
+    ref = oracle_disc(props, normals, u, w, h, early_out=True)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    a = sr.Renderer(device, None, "rgba8unorm", n, footprint="disc")
+    b = sr.Renderer(device, None, "rgba8unorm", n)
+    imgs = []
+    for _ in range(2):
+        a.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+        b.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+        imgs.append((a.readPixelsFloat().copy(), b.readPixelsFloat().copy()))
+    assert np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][1], imgs[1][1])
+    d = np.abs(imgs[0][0] - ref["img"]).max(axis=2)
+    assert d[ref["rim"] == 0].max() <= TOL_EARLY_OUT_BOUND and d.max() <= TOL_RIM
+    assert np.abs(imgs[0][0] - imgs[0][1]).max() > 0.05  # they ARE different footprints
+    for o in (a, b, pbuf, nbuf):
+        o.destroy()
+
+
+def test_disc_rejects_what_it_does_not_support(device):
+    n, w, h = 256, 64, 64
+    props, normals, u = make_case(n, w, h, 3, 2.0)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    lib, ctx = device.lib, device.ctx
+    out = device.createBuffer(w * h * 4)
+    dummy = device.createBuffer(4096 * 4)
+    cfg = _lib.CompositeCfg(_lib.MODE_REFERENCE_LITERAL, 1, 16, 0, 0xFFFFFFFF, 0, 0, _lib.FOOTPRINT_DISC)
+    args = (pbuf.ptr + 16, 2, nbuf.ptr, 1, dummy.ptr, dummy.ptr, dummy.ptr, dummy.ptr, w, h, out.ptr, None, None)
+    assert lib.splat_composite(ctx, C.byref(cfg), *args) == -1  # the literal back-to-front loop is ComputeShaderRenderer's
+    cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, _lib.RECORDS_COMPACT, 0, _lib.FOOTPRINT_DISC)
+    assert lib.splat_composite(ctx, C.byref(cfg), *args) == -1
+    cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, 0, 0, 7)
+    assert lib.splat_composite(ctx, C.byref(cfg), *args) == -1
+    # band frames exchange the isotropic footprint's records
+    sorter, binner = sr.RadixSorter(device, n), sr.GPUTileBinner(device, 16)
+    cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, 0, 0, _lib.FOOTPRINT_DISC)
+    assert lib.splat_band_frame(ctx, sorter._s, binner._b, C.byref(cfg), pbuf.ptr, nbuf.ptr, dummy.ptr, 16, w, h, out.ptr, None, None) == -1
+    uu = np.ascontiguousarray(u, np.float32)
+    up = uu.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.splat_project_disc(ctx, up, pbuf.ptr, 2, None, 1, n, dummy.ptr, dummy.ptr, None, None, 0) == -1
+    assert lib.splat_project_disc(ctx, up, pbuf.ptr, 2, nbuf.ptr + 4, 1, n, dummy.ptr, dummy.ptr, None, None, 0) == -1  # alignment
+    assert lib.splat_project_disc(ctx, up, pbuf.ptr, 2, nbuf.ptr, 1, 0, None, None, None, None, 0) == 0
+    with pytest.raises(sr.SplatError):
+        sr.Renderer(device, None, "rgba8unorm", n, footprint="hexagon")
+    for o in (pbuf, nbuf, out, dummy, sorter, binner):
+        o.destroy()

@@ -562,7 +562,8 @@ def test_per_tile_sorter_validates_order(device):
 
 def test_sequential_renderer_honours_given_order(device):
     """SequentialRenderer.render(uniforms, props, sortedIdx, curvature, W, H): the image is the
-    composite of exactly the given order (here: a deliberately NON-depth order, index order)."""
+    composite of exactly the given order (here: a deliberately NON-depth order, index order); with
+    ComputeShaderRenderer's footprint here — the class's own footprint is covered in test_gpu_disc.py."""
     n, w, h = 3000, 160, 96
     props, normals, u = make_case(n, w, h, 81, 2.0)
     order = np.arange(n, dtype=np.uint32)
@@ -572,7 +573,7 @@ def test_sequential_renderer_honours_given_order(device):
     pm = sr.SplatPropertyManager(device, n)
     pm.setFromArrays(props)
     nbuf, obuf = device.createBufferFrom(normals), device.createBufferFrom(order)
-    r = sr.SequentialRenderer(device, None, "rgba8unorm", n)
+    r = sr.SequentialRenderer(device, None, "rgba8unorm", n, footprint="isotropic")
     r.render(u[:20], pm.getPropertyBuffer(), obuf, nbuf, w, h, wantFloat=True)  # 20-float block: W,H appended
     err = np.abs(r.readPixelsFloat() - want)
     assert err.max() <= TOL_EARLY_OUT_BOUND and (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
