@@ -218,7 +218,9 @@ typedef struct splat_composite_cfg {
                              * SPLAT_FOOTPRINT_DISC: SequentialRenderer's / TileRenderer's oriented disc —
                              * `projected` then points at the 32-byte DISC records of splat_project_disc, mode must
                              * be FRONT_TO_BACK and record_format PROJECTED; in splat_render_frame* the projector
-                             * used is splat_project_disc (normals are required even when prelit) */
+                             * used is splat_project_disc (normals are required even when prelit) and `projected`
+                             * may be NULL (the ProjectedSplat records are then not written: a disc frame's composite
+                             * reads the disc records) */
 } splat_composite_cfg;
 /* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
  * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;

@@ -210,7 +210,8 @@ def project_disc(u, pos_radius, normals):
         u2 = np.zeros(n, np.float32)
         t0, t1, t2 = u1 * n2 - u2 * n1, u2 * n0 - u0 * n2, u0 * n1 - u1 * n0  # cross(up, normal)
         tl = np.sqrt((t0 * t0 + t1 * t1) + t2 * t2)
-        t0, t1, t2 = t0 / tl, t1 / tl, t2 / tl  # :70
+        itl = F(1) / tl
+        t0, t1, t2 = t0 * itl, t1 * itl, t2 * itl  # :70
         b0, b1, b2 = n1 * t2 - n2 * t1, n2 * t0 - n0 * t2, n0 * t1 - n1 * t0  # :96 cross(normal, tangent)
         e0 = (t0 * r, t1 * r, t2 * r)
         e1 = (b0 * r, b1 * r, b2 * r)
@@ -227,12 +228,14 @@ def project_disc(u, pos_radius, normals):
         hw, hh = F(0.5) * m[20], F(0.5) * m[21]
         m00, m01, m02 = hw * (ctx + ctw), hw * (cbx + cbw), hw * (cpx + cpw)
         m10, m11, m12 = hh * (ctw - cty), hh * (cbw - cby), hh * (cpw - cpy)
-        scx, scy = m02 / cpw, m12 / cpw
+        icw = F(1) / cpw
+        scx, scy = m02 * icw, m12 * icw
         a00, a01 = m00 - scx * ctw, m01 - scx * cbw
         a10, a11 = m10 - scy * ctw, m11 - scy * cbw
         det = a00 * a11 - a01 * a10
         ok = front & (np.abs(det) > F(0))
-        k, idet = cpw / det, F(1) / det
+        idet = F(1) / det
+        k = cpw * idet
         rec = np.stack([scx, scy, a11 * k, (-a01) * k, (-a10) * k, a00 * k,
                         (a11 * ctw - a10 * cbw) * idet, (a00 * cbw - a01 * ctw) * idet], axis=1).astype(np.float32)
         ok &= np.isfinite(rec).all(axis=1)

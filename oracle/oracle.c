@@ -574,7 +574,8 @@ static void disc_record(const float *u, const float *p, const float *n, float *r
     float t[3], b[3];
     cross3(up, n, t);
     float tl = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
-    t[0] /= tl; t[1] /= tl; t[2] /= tl;
+    float itl = 1.0f / tl; /* normalize(): one reciprocal, three products */
+    t[0] *= itl; t[1] *= itl; t[2] *= itl;
     cross3(n, t, b);
     /* half-axes of the quad in world space (:107-109), then their clip-space images (x, y, w rows) */
     float r = p[3];
@@ -593,12 +594,13 @@ static void disc_record(const float *u, const float *p, const float *n, float *r
     float hw = 0.5f * u[20], hh = 0.5f * u[21];
     float m00 = hw * (ctx + ctw), m01 = hw * (cbx + cbw), m02 = hw * (cpx + cpw);
     float m10 = hh * (ctw - cty), m11 = hh * (cbw - cby), m12 = hh * (cpw - cpy);
-    float scx = m02 / cpw, scy = m12 / cpw;
+    float icw = 1.0f / cpw;
+    float scx = m02 * icw, scy = m12 * icw;
     float a00 = m00 - scx * ctw, a01 = m01 - scx * cbw;
     float a10 = m10 - scy * ctw, a11 = m11 - scy * cbw;
     float det = a00 * a11 - a01 * a10;
     if (!(fabsf(det) > 0.0f)) return; /* edge-on (or NaN): covers no pixel */
-    float k = cpw / det, idet = 1.0f / det;
+    float idet = 1.0f / det, k = cpw * idet;
     rec[0] = scx; rec[1] = scy;
     rec[2] = a11 * k; rec[3] = (-a01) * k; rec[4] = (-a10) * k; rec[5] = a00 * k;
     rec[6] = (a11 * ctw - a10 * cbw) * idet;

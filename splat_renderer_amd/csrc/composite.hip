@@ -27,6 +27,8 @@
 
 #include <hip/hip_ext.h>
 
+typedef float v2f __attribute__((ext_vector_type(2))); // maps onto the packed FP32 instructions (v_pk_*_f32)
+
 constexpr int CT = 16;        // tile edge (pixels)
 constexpr int CBATCH = 256;   // list entries staged per round
 
@@ -118,6 +120,13 @@ __device__ __forceinline__ void fetch_record(const CompositeParams &p, uint32_t 
     }
 }
 
+// The stop test of the nearest-first loop is (1 - T) >= 0.99 on the transmittance T (the reference's alpha >= 0.99,
+// ComputeShaderRenderer.ts:187-190).  A correctly rounded 1 - T is monotone in T, so the test is EXACTLY T <= the
+// largest binary32 T that passes it — 0x1.47ae4p-7 (found by stepping ulps; NaN fails both forms) — and the
+// subtraction leaves the per-pixel loop.
+constexpr float T_STOP = 0x1.47ae4p-7f;
+static_assert((1.0f - T_STOP) >= 0.99f && !((1.0f - 0x1.47ae42p-7f) >= 0.99f), "T_STOP is the last transmittance that stops a pixel");
+
 // exp(-0.5 * d2 / (0.4 * 0.4)) = exp2(d2 * this)   (SequentialRenderer.ts:132-133)
 constexpr float DISC_EXP2_SCALE = -4.508422002777011f;
 
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     // per entry one 32-byte record {centre.x, centre.y, exp2 scale, lit blue | lit red, lit green, -, -}: both
     // halves are read off ONE address register (ds_read_b128 + ds_read_b64 offset:16), and forming an LDS
     // address from the scalar entry index costs a VALU move per register
-    // (DISC: {centre.x, centre.y, B00, B01 | B10, B11, q0, q1 | lit red, green, blue, -})
+    // (DISC: {centre.x, centre.y, -q0, -q1 | B00, B10, B01, B11 | lit red, green, blue, -}: B by columns, so that
+    // (u,v) numerators are two packed operations on register pairs as they arrive)
     constexpr int PAR = DISC ? 3 : 2;
     __shared__ float4 s_par[CBATCH][PAR];
     __shared__ uint2 s_mask[4][CBATCH];  // per quadrant: which of its 64 pixels the entry's box covers
@@ -200,8 +210,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     const float4 c = p.prelit ? f_c : lit_color(f_c, f_n);
                     col = make_float2(c.x, c.y);
                     col_b = c.z;
-                    geo = f_b;
-                    geo2 = f_b2;
+                    geo = make_float4(f_b.x, f_b.y, -f_b2.z, -f_b2.w);
+                    geo2 = make_float4(f_b.z, f_b2.x, f_b.w, f_b2.y);
                     xm = span_mask16(bnd.x, bnd.z, tile_cx);
                     ym = span_mask16(bnd.y, bnd.w, tile_cy);
                 }
@@ -286,16 +296,17 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 float2 C0, C1;
                 float B0, B1, g0, g1; // blue, Gaussian
                 if constexpr (DISC) {
-                    const float4 Q0 = s_par[c0 + j0][1], Q1 = s_par[c0 + j1][1];
+                    const float4 M0 = s_par[c0 + j0][1], M1 = s_par[c0 + j1][1];
                     const float4 L0 = s_par[c0 + j0][2], L1 = s_par[c0 + j1][2];
                     C0 = make_float2(L0.x, L0.y); B0 = L0.z;
                     C1 = make_float2(L1.x, L1.y); B1 = L1.z;
-                    const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
-                    const float rd0 = __builtin_amdgcn_rcpf(1.0f - (Q0.z * dx0 + Q0.w * dy0));
-                    const float rd1 = __builtin_amdgcn_rcpf(1.0f - (Q1.z * dx1 + Q1.w * dy1));
-                    const float u0 = (G0.z * dx0 + G0.w * dy0) * rd0, v0 = (Q0.x * dx0 + Q0.y * dy0) * rd0;
-                    const float u1 = (G1.z * dx1 + G1.w * dy1) * rd1, v1 = (Q1.x * dx1 + Q1.y * dy1) * rd1;
-                    const float d0 = u0 * u0 + v0 * v0, d1 = u1 * u1 + v1 * v1; // :126
+                    const v2f pc = {pxf, pyf};
+                    const v2f e0 = pc - (v2f){G0.x, G0.y}, e1 = pc - (v2f){G1.x, G1.y};
+                    const float rd0 = __builtin_amdgcn_rcpf(__builtin_fmaf(G0.z, e0.x, __builtin_fmaf(G0.w, e0.y, 1.0f))); // 1 / (1 - q.d)
+                    const float rd1 = __builtin_amdgcn_rcpf(__builtin_fmaf(G1.z, e1.x, __builtin_fmaf(G1.w, e1.y, 1.0f)));
+                    const v2f uv0 = ((v2f){M0.x, M0.y} * e0.x + (v2f){M0.z, M0.w} * e0.y) * rd0; // B*d / (1 - q.d)
+                    const v2f uv1 = ((v2f){M1.x, M1.y} * e1.x + (v2f){M1.z, M1.w} * e1.y) * rd1;
+                    const float d0 = uv0.x * uv0.x + uv0.y * uv0.y, d1 = uv1.x * uv1.x + uv1.y * uv1.y; // :126
                     g0 = (d0 <= 1.0f) ? __builtin_amdgcn_exp2f(d0 * DISC_EXP2_SCALE) : 0.0f; // :128-133 (NaN: outside)
                     g1 = (d1 <= 1.0f) ? __builtin_amdgcn_exp2f(d1 * DISC_EXP2_SCALE) : 0.0f;
                 } else {
@@ -321,8 +332,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     cr += C0.x * wgt;
                     cg += C0.y * wgt;
                     cb += B0 * wgt;
-                    acc = acc * (1.0f - g0);
-                    if (EARLY_OUT) lv &= ~__ballot((1.0f - acc) >= 0.99f);
+                    acc -= wgt; // T * (1 - g), with the product already in hand
+                    if (EARLY_OUT) lv &= ~__ballot(acc <= T_STOP);
                 }
                 lv = uniform64(lv);
                 g1 = __builtin_amdgcn_inverse_ballot_w64(cover1 & lv) ? g1 : 0.0f;
@@ -338,8 +349,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     cr += C1.x * wgt;
                     cg += C1.y * wgt;
                     cb += B1 * wgt;
-                    acc = acc * (1.0f - g1);
-                    if (EARLY_OUT) lv &= ~__ballot((1.0f - acc) >= 0.99f);
+                    acc -= wgt;
+                    if (EARLY_OUT) lv &= ~__ballot(acc <= T_STOP);
                 }
                 live = lv;
                 if (EARLY_OUT && uniform64(live) == 0) break;

@@ -61,7 +61,8 @@ __device__ __forceinline__ DiscRecord disc_record(const float *m, float w, float
     const float ux = steep ? 1.0f : 0.0f, uy = steep ? 0.0f : 1.0f, uz = 0.0f;
     float tx = uy * n.z - uz * n.y, ty = uz * n.x - ux * n.z, tz = ux * n.y - uy * n.x; // cross(up, n)
     const float tl = sqrtf((tx * tx + ty * ty) + tz * tz);
-    tx /= tl; ty /= tl; tz /= tl;
+    const float itl = 1.0f / tl; // normalize(): one reciprocal, three products
+    tx *= itl; ty *= itl; tz *= itl;
     const float bx = n.y * tz - n.z * ty, by = n.z * tx - n.x * tz, bz = n.x * ty - n.y * tx; // cross(n, t)
     // half-axes of the quad in world space (:107-109) and their clip-space images (x, y, w rows)
     const float r = pr.w;
@@ -80,12 +81,13 @@ __device__ __forceinline__ DiscRecord disc_record(const float *m, float w, float
     const float hw = 0.5f * w, hh = 0.5f * h;
     const float m00 = hw * (ctx + ctw), m01 = hw * (cbx + cbw), m02 = hw * (cpx + cpw);
     const float m10 = hh * (ctw - cty), m11 = hh * (cbw - cby), m12 = hh * (cpw - cpy);
-    const float scx = m02 / cpw, scy = m12 / cpw;
+    const float icw = 1.0f / cpw;
+    const float scx = m02 * icw, scy = m12 * icw;
     const float a00 = m00 - scx * ctw, a01 = m01 - scx * cbw;
     const float a10 = m10 - scy * ctw, a11 = m11 - scy * cbw;
     const float det = a00 * a11 - a01 * a10;
     if (!(fabsf(det) > 0.0f)) return zero; // edge-on (or NaN): covers no pixel
-    const float k = cpw / det, idet = 1.0f / det;
+    const float idet = 1.0f / det, k = cpw * idet;
     DiscRecord o;
     o.a = make_float4(scx, scy, a11 * k, (-a01) * k);
     o.b = make_float4((-a10) * k, a00 * k, (a11 * ctw - a10 * cbw) * idet, (a00 * cbw - a01 * ctw) * idet);

@@ -404,9 +404,12 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
                              uint32_t color_stride, const void *normals, uint32_t n, uint32_t width, uint32_t height,
                              void *projected, void *out_rgba8, void *out_rgba32f) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && color && (normals || cfg->prelit) && projected);
+    ARG_CHECK(ctx, sorter && binner && cfg && uniforms && props && color && (normals || cfg->prelit));
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner));
     ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC);
+    // the ProjectedSplat records are the isotropic composite's input; a disc frame reads its disc records instead and
+    // may leave them out (160 MB of stores per 5M splats that nothing reads)
+    ARG_CHECK(ctx, projected || cfg->footprint == SPLAT_FOOTPRINT_DISC);
     // the oriented disc (SequentialRenderer's footprint): its projector needs the normals, its records live with the binner
     const bool disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
     ARG_CHECK(ctx, !disc || (normals && (((uintptr_t)normals) & 15) == 0));
@@ -420,6 +423,8 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (row0 > row1) row0 = row1;
     const bool fast = ntx <= 256 && nty <= 256 && n > 0;
+    if (!projected && n > 0 && !fast)
+        return ctx_fail(ctx, SPLAT_ERR_INVALID, "splat_render_frame: screens beyond 256 x 256 tiles bin from the projected records: pass a buffer");
     int rc = SPLAT_OK;
     uint32_t *range32 = nullptr;
     const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
@@ -449,10 +454,12 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
                         tile_first ? &ho : nullptr, normals, 1, disc ? binner->discs : nullptr);
     if (rc != SPLAT_OK) return rc;
     binner->tf_hist_ready = tile_first;
+    // (with per-index tile ranges the binner never reads the records; it only wants a non-null pointer)
+    const void *bin_records = projected ? projected : (const void *)binner->discs;
     if (tile_first) {
         // bin in index order, depth-sort per tile: no global sort, no gather (tile_first.hip)
         sorter->ran = false; // the sorter holds this frame's unsorted depth keys
-        rc = binner_run(binner, projected, n, nullptr, n, width, height, row0, row1, range32, nullptr, sorter->keys);
+        rc = binner_run(binner, bin_records, n, nullptr, n, width, height, row0, row1, range32, nullptr, sorter->keys);
         if (rc != SPLAT_OK) return rc;
     } else {
         stage_begin(ctx, SPLAT_STAGE_SORT);
@@ -461,7 +468,7 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         stage_end(ctx, SPLAT_STAGE_SORT);
         if (rc != SPLAT_OK) return rc;
         sorter->ran = true;
-        rc = binner_run(binner, projected, n, splat_sort_sorted_payload(sorter), n, width, height, row0, row1, range32);
+        rc = binner_run(binner, bin_records, n, splat_sort_sorted_payload(sorter), n, width, height, row0, row1, range32);
         if (rc != SPLAT_OK) return rc;
     }
     // (fields, not the public getters: those wait for a sync-free frame's pair total to come back)

@@ -94,8 +94,10 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const fl
         a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
         b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
     }
-    projected[(size_t)i * 2] = a;
-    projected[(size_t)i * 2 + 1] = b;
+    if (!DISC || projected) { // (a disc frame's composite reads the disc records: the ProjectedSplat output is optional there)
+        projected[(size_t)i * 2] = a;
+        projected[(size_t)i * 2 + 1] = b;
+    }
     if (WITH_KEYS) {
         keys[i] = depth_key(depth);
         if (payload) payload[i] = index_base + i; // (frame path: the sort's first pass synthesises it)

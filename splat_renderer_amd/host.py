@@ -641,10 +641,14 @@ class Renderer:
     on the device.  (The reference's body — opaque depth-tested quads — is out of scope.)"""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", numPoints=0, tileSize=16,
-                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None, footprint="isotropic"):
+                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None, footprint="isotropic", writeProjected=True):
         # footprint="disc": the frame is drawn with SequentialRenderer's oriented discs (normalsBuffer is then
-        # required in render() even with pre-lit planes: the projector reads it)
+        # required in render() even with pre-lit planes: the projector reads it).  writeProjected=False (disc
+        # frames only): the ProjectedSplat records, which a disc frame's composite does not read, are not written.
         self.footprint = _footprint(footprint)
+        if not writeProjected and self.footprint != _lib.FOOTPRINT_DISC:
+            raise SplatError(-1, "writeProjected=False: the isotropic composite reads the ProjectedSplat records")
+        self.writeProjected = writeProjected
         self.device, self.numPoints, self.tileSize = device, numPoints, tileSize
         self.projector = SplatProjector(device, numPoints)
         self.sorter = RadixSorter(device, numPoints)
@@ -676,7 +680,8 @@ class Renderer:
             self.outputFloat = d.createBuffer(width * height * 16)
         prelit = isinstance(propertyBuffer, PropertyPlanes) and propertyBuffer.prelit
         cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], 0, int(prelit), self.footprint)
-        tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height, self.projector.getProjectedBuffer().ptr, self.output.ptr,
+        tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height,
+                self.projector.getProjectedBuffer().ptr if self.writeProjected else None, self.output.ptr,
                 self.outputFloat.ptr if wantFloat else None)
         head = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)))
         if isinstance(propertyBuffer, PropertyPlanes):  # the native layout: SplatPropertyManager.getPropertyPlanes()

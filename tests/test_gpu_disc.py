@@ -181,6 +181,17 @@ def test_disc_whole_frame(device, order, layout):
     if layout == "lit":
         with pytest.raises(sr.SplatError):  # the disc projector needs the normals even when the colours are pre-lit
             r.render(u, src, None, None, w, h)
+    # without the ProjectedSplat by-product (nothing in a disc frame reads it): same lists, same image bits
+    r2 = sr.Renderer(device, None, "rgba8unorm", n, earlyOut=False, frameOrder=order, footprint="disc", writeProjected=False)
+    r2.projector.getProjectedBuffer().zero()
+    r2.render(u, src, nbuf, None, w, h, wantFloat=True)
+    assert r2.finish() == total
+    assert np.array_equal(r2.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert np.array_equal(r2.readPixelsFloat().view(np.uint32), r.readPixelsFloat().view(np.uint32))
+    assert not r2.projector.getProjectedBuffer().read(np.uint32).any()
+    r2.destroy()
+    with pytest.raises(sr.SplatError):
+        sr.Renderer(device, None, "rgba8unorm", n, writeProjected=False)  # the isotropic composite reads them
     for o in (r, pm, nbuf):
         o.destroy()
 
