@@ -115,7 +115,8 @@ def main():
                     help="splat properties as two vec4 planes (native) or the reference's interleaved 32-byte records")
     ap.add_argument("--footprint", default="isotropic", choices=["isotropic", "disc"],
                     help="isotropic: ComputeShaderRenderer's screen-space Gaussian (SURVEY §8a contract 3, the headline); "
-                         "disc: SequentialRenderer's oriented disc (parity vs the CPU rasteriser of SequentialRenderer.ts), N=1 only")
+                         "disc: SequentialRenderer's oriented disc (parity vs the CPU rasteriser of SequentialRenderer.ts; "
+                         "48-byte exchange records at N>1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,8 +141,6 @@ def main():
     u = cam.uniforms(width, height)
     workload = f"{name}: {n} synthetic Gaussians @{width}x{height}, {tile}x{tile} tiles"
 
-    if args.footprint == "disc" and not (world == 1 and "RANK" not in os.environ):
-        raise SystemExit("--footprint disc: the band exchange carries the isotropic footprint's records (single GPU only for now)")
     if world == 1 and "RANK" not in os.environ:
         result = run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload)
     else:
@@ -272,7 +271,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     if not td.is_initialized():
         td.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     per = dist.shard_size(n, world)
-    stages = dist.HipStages(torch, local_rank, per * world, width, height, tile)
+    stages = dist.HipStages(torch, local_rank, per * world, width, height, tile, footprint=args.footprint)
     pt = torch.from_numpy(props).cuda()
     nt = torch.from_numpy(normals).cuda()
     br = dist.BandRenderer(stages, n, width, height, rank, world, td.all_gather_into_tensor, tile)
@@ -365,10 +364,12 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
-                   "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * 16} B "
+                   "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * stages.rec_floats * 4} B "
                                   f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
                                                           "all-gather run on a second stream under this frame's band work"),
                    "frame_loop_trial_ms": {k: round(v, 4) for k, v in loop_ms.items()},
+                   "footprint": ("oriented disc (SequentialRenderer.ts:91-142), 48-byte exchange records" if stages.disc else
+                                 "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147), 16-byte exchange records"),
                    "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
                                  "composite_ms": i[4] / 1e6} for i in infos],
                    "composite": "front-to-back, early-out at alpha>=0.99"},

@@ -201,6 +201,7 @@ int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void 
 #define SPLAT_COMPOSITE_REFERENCE_LITERAL 1 /* src/ComputeShaderRenderer.ts:175-190 as written */
 #define SPLAT_RECORDS_PROJECTED 0
 #define SPLAT_RECORDS_COMPACT 1
+#define SPLAT_RECORDS_DISC48 2 /* oriented-disc exchange records, see splat_project_slice_disc (footprint DISC only) */
 #define SPLAT_FOOTPRINT_ISOTROPIC 0
 #define SPLAT_FOOTPRINT_DISC 1
 typedef struct splat_composite_cfg {
@@ -281,6 +282,13 @@ int splat_project_slice(splat_ctx *ctx, const float *uniforms, const void *pos_r
 int splat_project_slice_compact(splat_ctx *ctx, const float *uniforms, const void *pos_radius,
                                 uint32_t pr_stride_vec4, uint32_t first, uint32_t count,
                                 void *records16_slice);
+/* The oriented-disc footprint's exchange records: 48 bytes per splat, 3 x float4 {disc record (8 floats, see
+ * splat_project_disc), depth, 0, 0, 0}.  The disc's bounds are a pure function of the record and the index is the
+ * position in the gathered array, so splat_band_frame (cfg->footprint = SPLAT_FOOTPRINT_DISC, cfg->record_format =
+ * SPLAT_RECORDS_DISC48; tile-first order, screens up to 256 x 256 tiles) needs nothing else. */
+int splat_project_slice_disc(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4,
+                             const void *normals, uint32_t normal_stride_vec4, uint32_t first, uint32_t count,
+                             void *records48_slice);
 int splat_expand_compact(splat_ctx *ctx, const void *records16, uint32_t n, uint32_t index_base,
                          void *projected);
 /* Stable compaction of the splats whose clamped tile-row range meets [tile_row0, tile_row1):

@@ -16,7 +16,7 @@ ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -
 STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2, 3, 4
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
 MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
-RECORDS_PROJECTED, RECORDS_COMPACT = 0, 1
+RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_DISC48 = 0, 1, 2
 FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC = 0, 1
 U32_MAX = 0xFFFFFFFF
 
@@ -93,6 +93,7 @@ SIGNATURES = {
                                        _u32, _u32, _vp, _vp, _vp]),
     "splat_project_slice": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
     "splat_project_slice_compact": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _u32, _u32, _vp]),
+    "splat_project_slice_disc": (_i, [_vp, C.POINTER(C.c_float), _vp, _u32, _vp, _u32, _u32, _u32, _vp]),
     "splat_expand_compact": (_i, [_vp, _vp, _u32, _u32, _vp]),
     "splat_band_frame": (_i, [_vp, _vp, _vp, C.POINTER(CompositeCfg), _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "splat_band_settle": (_i, [_vp, _vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),

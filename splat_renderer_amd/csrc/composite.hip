@@ -37,7 +37,8 @@ struct CompositeParams {
     const float4 *normals; uint32_t normal_stride; // vec4(normal, scaleFactor)
     const float4 *projected;                       // 2 x float4 per splat (ProjectedSplat), or 1 x float4 (compact exchange record)
     uint32_t compact;
-    uint32_t disc;                                 // projected holds 32-byte disc records (disc.h): the oriented-disc footprint
+    uint32_t disc;                                 // projected holds disc records (disc.h): the oriented-disc footprint
+    uint32_t disc_stride;                          // float4s between disc records: 2 (projector's) or 3 (48-byte exchange records)
     uint32_t prelit;                               // color holds lit colours (k_lit_colors): normals are not read
     const uint32_t *indices, *counts, *offsets;
     uint32_t width, height, ntx, tile_row0;
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 f_idx = (tid < CBATCH && e < count) ? p.indices[off + e] : 0xffffffffu;
                 if (f_idx != 0xffffffffu) {
                     if constexpr (DISC) {
-                        f_b = p.projected[(size_t)f_idx * 2];
-                        f_b2 = p.projected[(size_t)f_idx * 2 + 1];
+                        f_b = p.projected[(size_t)f_idx * p.disc_stride];
+                        f_b2 = p.projected[(size_t)f_idx * p.disc_stride + 1];
                     } else {
                         fetch_record(p, f_idx, f_b, f_r);
                     }
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     f_idx = n_idx;
                     if (f_idx != 0xffffffffu) {
                         if constexpr (DISC) {
-                            f_b = p.projected[(size_t)f_idx * 2];
-                            f_b2 = p.projected[(size_t)f_idx * 2 + 1];
+                            f_b = p.projected[(size_t)f_idx * p.disc_stride];
+                            f_b2 = p.projected[(size_t)f_idx * p.disc_stride + 1];
                         } else {
                             fetch_record(p, f_idx, f_b, f_r);
                         }
@@ -394,7 +395,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     ARG_CHECK(ctx, cfg != nullptr);
     ARG_CHECK(ctx, cfg->tile_size == CT); // the kernel's quadrant mapping is built for 16x16 tiles
     ARG_CHECK(ctx, cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK || cfg->mode == SPLAT_COMPOSITE_REFERENCE_LITERAL);
-    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_COMPACT);
+    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_DISC48);
     ARG_CHECK(ctx, width >= 1 && height >= 1 && width <= 65535u * CT && height <= 65535u * CT);
     ARG_CHECK(ctx, color_opacity && (normals || cfg->prelit) && projected && tile_indices && tile_counts && tile_offsets);
     ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
@@ -404,7 +405,8 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     // the oriented disc is SequentialRenderer's footprint: nearest-on-top "over" is its only blend, and its
     // records are the projector's 32-byte disc records
     ARG_CHECK(ctx, cfg->footprint != SPLAT_FOOTPRINT_DISC ||
-                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format == SPLAT_RECORDS_PROJECTED));
+                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format != SPLAT_RECORDS_COMPACT));
+    ARG_CHECK(ctx, cfg->record_format != SPLAT_RECORDS_DISC48 || cfg->footprint == SPLAT_FOOTPRINT_DISC);
     const uint32_t ntx = div_up(width, CT), nty = div_up(height, CT);
     uint32_t r0 = cfg->tile_row0, r1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (r0 >= r1) return SPLAT_OK;
@@ -417,6 +419,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
     p.prelit = cfg->prelit != 0;
     p.disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
+    p.disc_stride = cfg->record_format == SPLAT_RECORDS_DISC48 ? 3u : 2u;
     p.indices = (const uint32_t *)tile_indices;
     p.counts = (const uint32_t *)tile_counts;
     p.offsets = (const uint32_t *)tile_offsets;

@@ -7,6 +7,7 @@
 // compaction so that ties in depth still resolve by ascending global index.
 #include "common.h"
 #include "tile_range.h"
+#include "disc.h"
 
 #include <cstdlib>
 
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare(const float4 *__r
 // empty range (no compaction, no sort of the kept splats).
 constexpr uint32_t BTF_PER_THREAD = 4, BTF_BLOCK = BAND_THREADS * BTF_PER_THREAD;
 
-// COMPACT: records are the 16-byte exchange records; the bounds are rebuilt as the projector forms them.
-template <bool COMPACT>
+// FORMAT = cfg->record_format.  COMPACT: 16-byte exchange records, the bounds are rebuilt as the projector forms
+// them.  DISC48: 48-byte oriented-disc exchange records, the bounds are the disc's (disc_bounds of the record).
+template <int FORMAT>
 __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *__restrict__ records, uint32_t n, BinParams bp,
                                                                   uint32_t *__restrict__ keys_by_idx, uint32_t *__restrict__ range32,
                                                                   uint32_t *__restrict__ kept_blocks, TfHistOut ho) {
@@ -90,7 +92,11 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
         if (i < n) {
             float4 a;
             float depth;
-            if (COMPACT) {
+            if (FORMAT == SPLAT_RECORDS_DISC48) {
+                const DiscRecord d = {records[(size_t)i * 3], records[(size_t)i * 3 + 1]};
+                disc_bounds(d, a); // (NaN padding records: not finite -> all zero -> bins nowhere)
+                depth = records[(size_t)i * 3 + 2].x;
+            } else if (FORMAT == SPLAT_RECORDS_COMPACT) {
                 const float4 c = records[i];
                 const float padded = c.z * 1.5f; // SplatProjector.ts:119-121 (this file is compiled with -ffp-contract=off)
                 a = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
@@ -231,8 +237,9 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, sorter && binner && cfg && props && (normals || cfg->prelit) && (n_records == 0 || records));
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner) && width >= 1 && height >= 1);
-    // (the band exchange carries the isotropic footprint's records; the oriented disc is single-GPU for now)
-    ARG_CHECK(ctx, cfg->footprint == SPLAT_FOOTPRINT_ISOTROPIC);
+    ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC && cfg->record_format <= SPLAT_RECORDS_DISC48);
+    // the oriented disc travels as its own 48-byte records, and only those carry it
+    ARG_CHECK(ctx, (cfg->footprint == SPLAT_FOOTPRINT_DISC) == (cfg->record_format == SPLAT_RECORDS_DISC48));
     // colours: the second vec4 of the reference's interleaved records, or (cfg->prelit) `props` IS the plane of lit colours
     const void *band_color = cfg->prelit ? props : (const void *)((const char *)props + 16);
     const uint32_t band_color_stride = cfg->prelit ? 1u : 2u;
@@ -241,8 +248,11 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (row0 > row1) row0 = row1;
     const uint32_t ntx = div_up(width, tile);
     const bool fast = ntx <= 256 && nty <= 256 && n_records > 0;
-    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_COMPACT);
     const bool compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
+    const bool disc = cfg->record_format == SPLAT_RECORDS_DISC48;
+    if (disc && n_records > 0 && !(fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST))
+        return ctx_fail(ctx, SPLAT_ERR_INVALID,
+                        "splat_band_frame: oriented-disc records need the tile-first frame order and a screen of at most 256 x 256 tiles");
     ARG_CHECK(ctx, ((uintptr_t)records & 15) == 0);
     if (compact && n_records > 0 && !(fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST)) {
         // the other orders of work read ProjectedSplat records: rebuild them once (bit-exact) and go on
@@ -273,12 +283,15 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         const uint32_t blocks = div_up(n_records, BTF_BLOCK);
         const TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
-        if (compact)
-            hipLaunchKernelGGL(k_band_prepare_tf<true>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records,
-                               bp, sorter->keys, binner->range32, sorter->hist, ho);
+        if (disc)
+            hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_DISC48>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
+                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho);
+        else if (compact)
+            hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_COMPACT>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
+                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho);
         else
-            hipLaunchKernelGGL(k_band_prepare_tf<false>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream, (const float4 *)records, n_records,
-                               bp, sorter->keys, binner->range32, sorter->hist, ho);
+            hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_PROJECTED>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
+                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho);
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
         binner->tf_hist_ready = true;

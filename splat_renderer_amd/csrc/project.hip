@@ -122,6 +122,21 @@ __global__ __launch_bounds__(256) void k_project_compact(FrameUniforms u, const 
     if (i < n) records16[i] = project_centre(u, pos_radius[(size_t)i * stride_vec4]);
 }
 
+// The same for the oriented-disc footprint: 48 bytes per splat {disc record, depth, 0, 0, 0} (the disc's bounds are a
+// pure function of its record: disc_bounds).
+__global__ __launch_bounds__(256) void k_project_disc48(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                        const float4 *__restrict__ normals, uint32_t normal_stride, uint32_t n,
+                                                        float4 *__restrict__ records48) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 pr = pos_radius[(size_t)i * stride_vec4];
+    const DiscRecord d = disc_record(u.m, u.w, u.h, pr, normals[(size_t)i * normal_stride]);
+    const float dx = pr.x - u.eye[0], dy = pr.y - u.eye[1], dz = pr.z - u.eye[2];
+    records48[(size_t)i * 3] = d.a;
+    records48[(size_t)i * 3 + 1] = d.b;
+    records48[(size_t)i * 3 + 2] = make_float4(sqrtf((dx * dx + dy * dy) + dz * dz), 0.0f, 0.0f, 0.0f); // SplatProjector.ts:77
+}
+
 __global__ __launch_bounds__(256) void k_expand_compact(const float4 *__restrict__ records16, uint32_t n, uint32_t index_base,
                                                         float4 *__restrict__ projected) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -324,6 +339,23 @@ int splat_project_slice_compact(splat_ctx *ctx, const float *uniforms, const voi
     hipLaunchKernelGGL(k_project_compact, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream, u,
                        (const float4 *)pos_radius + (size_t)first * pr_stride_vec4, pr_stride_vec4, count, (float4 *)records16_slice);
     LAUNCH_CHECK(ctx, "k_project_compact");
+    stage_end(ctx, SPLAT_STAGE_PROJECT);
+    return SPLAT_OK;
+}
+
+int splat_project_slice_disc(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, const void *normals,
+                             uint32_t normal_stride_vec4, uint32_t first, uint32_t count, void *records48_slice) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, uniforms && (count == 0 || (pos_radius && normals && records48_slice)) && pr_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
+    ARG_CHECK(ctx, (((uintptr_t)pos_radius | (uintptr_t)normals | (uintptr_t)records48_slice) & 15) == 0);
+    if (count == 0) return SPLAT_OK;
+    FrameUniforms u;
+    load_uniforms(u, uniforms);
+    stage_begin(ctx, SPLAT_STAGE_PROJECT);
+    hipLaunchKernelGGL(k_project_disc48, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream, u,
+                       (const float4 *)pos_radius + (size_t)first * pr_stride_vec4, pr_stride_vec4,
+                       (const float4 *)normals + (size_t)first * normal_stride_vec4, normal_stride_vec4, count, (float4 *)records48_slice);
+    LAUNCH_CHECK(ctx, "k_project_disc48");
     stage_end(ctx, SPLAT_STAGE_PROJECT);
     return SPLAT_OK;
 }

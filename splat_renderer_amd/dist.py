@@ -9,7 +9,9 @@ reference counterpart; it composes the same C-ABI stages:
 
 The exchange record is float4 {screen centre x, y, screen radius, depth}: the 32-byte ProjectedSplat is a
 pure function of it and of the record's position in the gathered array (= global splat index), so half
-the bytes cross xGMI and every rank rebuilds bounds bit-exactly where it needs them.
+the bytes cross xGMI and every rank rebuilds bounds bit-exactly where it needs them.  With the oriented-disc
+footprint (HipStages(footprint="disc"): SequentialRenderer's splat) the record is 48 bytes — the 8-float disc
+record, whose bounds are again a pure function of it, and the depth (splat_project_slice_disc).
 
 Per-tile lists are the global stable order restricted to the tile, so the stitched image is
 bit-identical to the single-GPU frame (tests/test_gpu_stages.py::test_band_rendering... on one GPU,
@@ -30,7 +32,8 @@ from . import _lib
 from ._lib import CompositeCfg, check
 
 TILE = 16
-REC_FLOATS = 4  # exchange record: centre x, centre y, screen radius, depth
+REC_FLOATS = 4        # exchange record: centre x, centre y, screen radius, depth
+DISC_REC_FLOATS = 12  # oriented-disc exchange record: disc record (8), depth, 3 x 0
 
 
 def shard_size(n, world):
@@ -73,13 +76,28 @@ def balanced_rows(row_weights, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def _project_slice(lib, ctx, disc, uniforms, props_ptr, normals_ptr, first, count, out_records):
+    u = np.ascontiguousarray(uniforms, np.float32)
+    up = u.ctypes.data_as(C.POINTER(C.c_float))
+    if disc:  # the oriented disc lies in the tangent plane of the splat's normal
+        if normals_ptr is None:
+            raise ValueError("the oriented-disc projector needs the normals")
+        check(lib.splat_project_slice_disc(ctx, up, props_ptr, 2, normals_ptr, 1, first, count, out_records.data_ptr()), ctx)
+    else:
+        check(lib.splat_project_slice_compact(ctx, up, props_ptr, 2, first, count, out_records.data_ptr()), ctx)
+
+
 class HipStages:
     """Device work of one rank through the C ABI.  Tensors are torch CUDA tensors; the splat ctx
     is created on torch's current stream so that RCCL's stream dependencies order the exchange."""
 
     def __init__(self, torch, device_ordinal, n_total_padded, width, height, tile=TILE, mode=_lib.MODE_FRONT_TO_BACK,
-                 early_out=True):
+                 early_out=True, footprint="isotropic"):
         self.torch = torch
+        if footprint not in ("isotropic", "disc"):
+            raise ValueError(f"footprint must be 'isotropic' or 'disc', not {footprint!r}")
+        self.disc = footprint == "disc"
+        self.rec_floats = DISC_REC_FLOATS if self.disc else REC_FLOATS
         self.lib = _lib.load()
         self.ordinal = device_ordinal
         p = C.c_void_p()
@@ -125,7 +143,7 @@ class HipStages:
         return host.reshape(nty, ntx).sum(axis=1).astype(np.int64)
 
     def new_records(self, count, fill_nan=False):
-        t = self.torch.empty((count, REC_FLOATS), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
+        t = self.torch.empty((count, self.rec_floats), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
         if fill_nan:
             t.fill_(float("nan"))
         return t
@@ -133,17 +151,17 @@ class HipStages:
     def new_image(self):
         return self.torch.zeros((self.height, self.width, 4), dtype=self.torch.uint8, device=f"cuda:{self.ordinal}")
 
-    def project_slice(self, uniforms, props_ptr, first, count, out_records):
-        u = np.ascontiguousarray(uniforms, np.float32)
-        check(self.lib.splat_project_slice_compact(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
-                                                   out_records.data_ptr()), self.ctx)
+    def project_slice(self, uniforms, props_ptr, first, count, out_records, normals_ptr=None):
+        _project_slice(self.lib, self.ctx, self.disc, uniforms, props_ptr, normals_ptr, first, count, out_records)
 
     def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False):
         """settle=False (frame loops): sync-free; a frame whose pairs outgrew 1.5x the previous frame's
         is only noticed at the next call (which then has room).  settle=True: wait for this frame's pair
         total and render it again if it overflowed — results are final on return."""
         prelit = self.lit is not None
-        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1, _lib.RECORDS_COMPACT, int(prelit))
+        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1,
+                           _lib.RECORDS_DISC48 if self.disc else _lib.RECORDS_COMPACT, int(prelit),
+                           _lib.FOOTPRINT_DISC if self.disc else _lib.FOOTPRINT_ISOTROPIC)
         if prelit:
             props_ptr, normals_ptr = self.lit.data_ptr(), None
         args = (self.ctx, self.sorter, self.binner, C.byref(cfg), props_ptr, normals_ptr, records.data_ptr(), n_records,
@@ -197,7 +215,7 @@ class BandRenderer:
 
     def render(self, uniforms, props_ptr, normals_ptr, settle=False):
         st = self.stages
-        st.project_slice(uniforms, props_ptr, self.first, self.count, self.shard)
+        st.project_slice(uniforms, props_ptr, self.first, self.count, self.shard, normals_ptr)
         if self.world > 1:
             self.all_gather(self.gathered, self.shard)
         if settle:
@@ -226,16 +244,15 @@ class ProjectStage:
     """The projector alone, on its own splat ctx bound to a second stream: the exchange side of a
     pipelined multi-GPU frame loop (FramePipeline)."""
 
-    def __init__(self, torch, device_ordinal, stream):
+    def __init__(self, torch, device_ordinal, stream, disc=False):
         self.lib = _lib.load()
+        self.disc = disc
         p = C.c_void_p()
         check(self.lib.splat_ctx_create_on_stream(device_ordinal, C.c_void_p(stream.cuda_stream), C.byref(p)))
         self.ctx = p
 
-    def project_slice(self, uniforms, props_ptr, first, count, out_records):
-        u = np.ascontiguousarray(uniforms, np.float32)
-        check(self.lib.splat_project_slice_compact(self.ctx, u.ctypes.data_as(C.POINTER(C.c_float)), props_ptr, 2, first, count,
-                                                   out_records.data_ptr()), self.ctx)
+    def project_slice(self, uniforms, props_ptr, first, count, out_records, normals_ptr=None):
+        _project_slice(self.lib, self.ctx, self.disc, uniforms, props_ptr, normals_ptr, first, count, out_records)
 
     def destroy(self):
         self.lib.splat_ctx_destroy(self.ctx)
@@ -253,7 +270,7 @@ class FramePipeline:
         self.torch, self.br = torch, br
         self.main = torch.cuda.current_stream()
         self.comm = torch.cuda.Stream()
-        self.proj = ProjectStage(torch, device_ordinal, self.comm)
+        self.proj = ProjectStage(torch, device_ordinal, self.comm, getattr(br.stages, "disc", False))
         st = br.stages
         self.shards = [br.shard, st.new_records(br.per, fill_nan=True)]
         self.gathered = [br.gathered, st.new_records(br.per * br.world) if br.world > 1 else self.shards[1]]
@@ -261,13 +278,13 @@ class FramePipeline:
         self.free = [torch.cuda.Event(), torch.cuda.Event()]
         self.used = [False, False]
 
-    def exchange(self, k, uniforms, props_ptr):
+    def exchange(self, k, uniforms, props_ptr, normals_ptr=None):
         """Project and all-gather frame k's records (asynchronous, on the second stream)."""
         s, br = k & 1, self.br
         with self.torch.cuda.stream(self.comm):
             if self.used[s]:
                 self.comm.wait_event(self.free[s])  # the band frame that read this pair has finished
-            self.proj.project_slice(uniforms, props_ptr, br.first, br.count, self.shards[s])
+            self.proj.project_slice(uniforms, props_ptr, br.first, br.count, self.shards[s], normals_ptr)
             if br.world > 1:
                 br.all_gather(self.gathered[s], self.shards[s])
             self.ready[s].record(self.comm)
@@ -283,10 +300,10 @@ class FramePipeline:
 
     def run(self, frames, uniforms_of, props_ptr, normals_ptr):
         """frames frames; uniforms_of(k) gives frame k's uniform block."""
-        self.exchange(0, uniforms_of(0), props_ptr)
+        self.exchange(0, uniforms_of(0), props_ptr, normals_ptr)
         for k in range(frames):
             if k + 1 < frames:
-                self.exchange(k + 1, uniforms_of(k + 1), props_ptr)
+                self.exchange(k + 1, uniforms_of(k + 1), props_ptr, normals_ptr)
             self.band(k, props_ptr, normals_ptr)
 
     def destroy(self):

@@ -22,12 +22,13 @@ from tests.helpers import make_case, oracle_pipeline  # noqa: E402
 class OracleStages:
     """Same surface as dist.HipStages, computed by the oracle on CPU tensors."""
 
-    def __init__(self, width, height, tile=16):
+    def __init__(self, width, height, tile=16, disc=False):
         self.width, self.height, self.tile = width, height, tile
         self.kept = 0
+        self.disc = disc  # the oriented-disc footprint: 48-byte exchange records {disc record, depth, 0, 0, 0}
 
     def new_records(self, count, fill_nan=False):
-        t = torch.zeros((count, 4), dtype=torch.float32)  # the 16-byte exchange records
+        t = torch.zeros((count, 12 if self.disc else 4), dtype=torch.float32)  # the 16-byte (48-byte) exchange records
         if fill_nan:
             t.fill_(float("nan"))
         return t
@@ -35,11 +36,29 @@ class OracleStages:
     def new_image(self):
         return torch.zeros((self.height, self.width, 4), dtype=torch.uint8)
 
-    def project_slice(self, uniforms, props, first, count, out_records):
+    def project_slice(self, uniforms, props, first, count, out_records, normals=None):
+        if self.disc:
+            proj, discs = O.project_disc(uniforms, props[first:first + count], normals[first:first + count])
+            out_records[:count, :8] = torch.from_numpy(discs)
+            out_records[:count, 8] = torch.from_numpy(proj[:, 4].copy())
+            out_records[:count, 9:] = 0
+            return
         out_records[:count] = torch.from_numpy(O.project_compact(uniforms, props[first:first + count]))
 
+    def _records_of(self, records):
+        """ProjectedSplat records (originalIndex = position = global index) rebuilt from the exchange records."""
+        if not self.disc:
+            return O.expand_compact(records.numpy())
+        r48 = records.numpy()
+        rec = np.zeros((r48.shape[0], 8), np.float32)
+        for i in range(r48.shape[0]):
+            ok, b = O.disc_bounds(r48[i, :8])  # NaN padding -> not ok -> zeros -> bins nowhere
+            rec[i, :4] = b
+        rec[:, 4] = r48[:, 8]
+        return rec
+
     def band_frame(self, records, n_records, props, normals, row0, row1, out_image, settle=False):
-        rec = O.expand_compact(records.numpy())  # ProjectedSplat records, originalIndex = position = global index
+        rec = self._records_of(records)
         ntx, nty = -(-self.width // self.tile), -(-self.height // self.tile)
         # splat_band_keys: keep splats whose clamped tile rows meet [row0,row1), ascending index
         keep = []
@@ -68,17 +87,22 @@ class OracleStages:
         offsets, _ = O.scan_exclusive(counts)
         idx = np.concatenate(lists) if lists else idx[:0]
         r0, r1 = row0 * self.tile, min(row1 * self.tile, self.height)
-        _, img8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, rec[:, :8], idx, counts, offsets,
-                                 self.width, self.height, self.tile, rows=(r0, r1))
+        if self.disc:
+            discs = np.ascontiguousarray(records.numpy()[:, :8])
+            _, img8, _, _ = O.composite_disc(True, props[:, 4:], normals, discs, idx, counts, offsets, self.width, self.height,
+                                             self.tile, rows=(r0, r1))
+        else:
+            _, img8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, rec[:, :8], idx, counts, offsets,
+                                     self.width, self.height, self.tile, rows=(r0, r1))
         out_image[r0:r1] = torch.from_numpy(img8[r0:r1])
 
 
-def _worker(rank, world, port, n, w, h, out_dir):
+def _worker(rank, world, port, n, w, h, out_dir, disc=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     props, normals, u = make_case(n, w, h, 31, 1.5)
-    st = OracleStages(w, h)
+    st = OracleStages(w, h, disc=disc)
     br = dist.BandRenderer(st, n, w, h, rank, world, td.all_gather_into_tensor)
     img = br.render(u, props, normals)
     r0, r1 = br.pixel_rows()
@@ -116,6 +140,23 @@ def test_band_renderer_gloo_matches_single_process(world, tmp_path):
     assert covered == h
     assert np.array_equal(got, want8)  # bit-identical to the single-process frame
     assert kept_total >= (a["counts"].reshape(7, 10).sum(axis=1) > 0).sum()  # every non-empty row has an owner
+
+
+def test_band_renderer_gloo_oriented_disc_footprint(tmp_path):
+    """The same sharding with the oriented-disc footprint's 48-byte exchange records (world 2)."""
+    world, n, w, h = 2, 1201, 160, 112
+    props, normals, u = make_case(n, w, h, 31, 1.5)
+    proj, discs = O.project_disc(u, props, normals)
+    keys, pay = O.extract_keys(proj)
+    _, order = O.sort_pairs(keys, pay)
+    counts, offsets, idx = O.bin_sorted(proj, order, w, h)
+    _, want8, _, _ = O.composite_disc(True, props[:, 4:], normals, discs, idx, counts, offsets, w, h)
+    mp.spawn(_worker, args=(world, _free_port(), n, w, h, str(tmp_path), True), nprocs=world, join=True)
+    got = np.zeros_like(want8)
+    for r in range(world):
+        r0, r1, _ = np.load(tmp_path / f"rows{r}.npy")
+        got[r0:r1] = np.load(tmp_path / f"band{r}.npy")
+    assert np.array_equal(got, want8)
 
 
 def test_slice_and_band_partition_properties():

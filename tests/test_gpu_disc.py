@@ -244,3 +244,85 @@ def test_disc_rejects_what_it_does_not_support(device):
         sr.Renderer(device, None, "rgba8unorm", n, footprint="hexagon")
     for o in (pbuf, nbuf, out, dummy, sorter, binner):
         o.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_disc_virtual_ranks_band_frame_matches_single_gpu(device, world):
+    """SURVEY §8e for the oriented-disc footprint, without a cluster: every rank's work in turn on the one GPU, the
+    all-gather of the 48-byte exchange records is a concat; the stitched rgba8 image must be bit-identical to the
+    single-GPU disc frame, and the records those of the oracle."""
+    import torch
+    from splat_renderer_amd import dist
+    n, w, h = 30001, 400, 232  # odd n: the last shard is padded with NaN records
+    props, normals, u = disc_case(n, w, h, 41, 1.5)
+    ref = oracle_disc(props, normals, u, w, h, early_out=True)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    full = sr.Renderer(device, None, "rgba8unorm", n, footprint="disc")
+    full.render(u, pbuf, nbuf, None, w, h)
+    want = full.readPixels().copy()
+    device.sync()
+    pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+    per = dist.shard_size(n, world)
+    stages = dist.HipStages(torch, 0, per * world, w, h, footprint="disc")
+    if world == 4:
+        stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
+    renderers = [dist.BandRenderer(stages, n, w, h, r, world, None) for r in range(world)]
+    with pytest.raises(ValueError):
+        stages.project_slice(u, pt.data_ptr(), 0, 1, renderers[0].shard)  # the disc projector needs the normals
+    for br in renderers:
+        stages.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard, nt.data_ptr())
+    gathered = torch.cat([br.shard for br in renderers], dim=0).contiguous()
+    rec = gathered.cpu().numpy()[:n]
+    assert np.array_equal(bits(rec[:, :8]), bits(ref["discs"]))
+    assert np.array_equal(bits(rec[:, 8]), bits(ref["proj"][:, 4])) and not rec[:, 9:].any()
+    got = np.zeros_like(want)
+    for br in renderers:
+        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=True)
+        torch.cuda.synchronize()
+        r0, r1 = br.pixel_rows()
+        got[r0:r1] = br.image.cpu().numpy()[r0:r1]
+    assert np.array_equal(got, want)
+    # and a sort-first band frame says what it cannot do instead of rendering something else
+    lib = device.lib
+    _lib.check(lib.splat_bin_set_frame_order(stages.binner, 0), stages.ctx)  # SPLAT_FRAME_ORDER_SORT_FIRST
+    cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 4, _lib.RECORDS_DISC48, 0, _lib.FOOTPRINT_DISC)
+    br = renderers[0]
+    rc = lib.splat_band_frame(stages.ctx, stages.sorter, stages.binner, C.byref(cfg), pt.data_ptr(), nt.data_ptr(), gathered.data_ptr(),
+                              per * world, w, h, br.image.data_ptr(), None, None)
+    assert rc == -1
+    stages.destroy()
+    for o in (full, pbuf, nbuf):
+        o.destroy()
+
+
+def test_disc_frame_pipeline_two_frames_in_flight(device):
+    """FramePipeline with the disc footprint (world 1: the exchange is the projection alone): frames stay apart."""
+    import torch
+    from splat_renderer_amd import dist
+    from splat_renderer_amd.camera import Camera
+    n, w, h = 20000, 320, 200
+    props, normals, _ = make_case(n, w, h, 51, 1.5)
+    cams = []
+    for k in range(4):
+        cam = Camera()
+        cam.setAspect(w / h)
+        cam.rotate(0.2 * k, 0.05 * k)
+        cams.append(cam.uniforms(w, h))
+    pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+    stages = dist.HipStages(torch, 0, n, w, h, footprint="disc")
+    br = dist.BandRenderer(stages, n, w, h, 0, 1, None)
+    want = []
+    for k in range(4):
+        want.append(br.render(cams[k], pt.data_ptr(), nt.data_ptr(), settle=True).cpu().numpy().copy())
+    pipe = dist.FramePipeline(torch, br, 0)
+    got = []
+    pipe.exchange(0, cams[0], pt.data_ptr(), nt.data_ptr())
+    for k in range(4):
+        if k + 1 < 4:
+            pipe.exchange(k + 1, cams[k + 1], pt.data_ptr(), nt.data_ptr())
+        got.append(pipe.band(k, pt.data_ptr(), nt.data_ptr(), settle=True).cpu().numpy().copy())
+    for k in range(4):
+        assert np.array_equal(got[k], want[k])
+    assert not np.array_equal(want[0], want[1])
+    pipe.destroy()
+    stages.destroy()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-rank device time of the multi-GPU frame, measured on ONE GPU with virtual ranks (the
-all-gather is a pre-built concat and is NOT included): python tools/band_bench.py [C2] [G ...]"""
+all-gather is a pre-built concat and is NOT included): python tools/band_bench.py [C2] [G ...] [disc]"""
 import os
 import sys
 import time
@@ -12,8 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import splat_renderer_amd as sr
 from splat_renderer_amd import dist
 
-name = sys.argv[1] if len(sys.argv) > 1 else "C2"
-worlds = [int(a) for a in sys.argv[2:]] or [1, 2, 4, 8]
+footprint = "disc" if "disc" in sys.argv[1:] else "isotropic"
+argv = [a for a in sys.argv[1:] if a != "disc"]
+name = argv[0] if argv else "C2"
+worlds = [int(a) for a in argv[1:]] or [1, 2, 4, 8]
 n, w, h = sr.scene.CONFIGS[name]
 props, normals = sr.scene.make_scene(n)
 cam = sr.Camera()
@@ -22,11 +24,11 @@ u = cam.uniforms(w, h)
 pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
 for world in worlds:
     per = dist.shard_size(n, world)
-    st = dist.HipStages(torch, 0, per * world, w, h)
+    st = dist.HipStages(torch, 0, per * world, w, h, footprint=footprint)
     st.set_lit(pt.data_ptr(), nt.data_ptr(), n)  # shading once per property update (as bench.py does)
     brs = [dist.BandRenderer(st, n, w, h, r, world, None) for r in range(world)]
     for br in brs:
-        st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+        st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard, nt.data_ptr())
     gathered = torch.cat([br.shard for br in brs], dim=0).contiguous()
     # balance bands by pairs per row from one calibration pass over all rows
     full = dist.BandRenderer(st, n, w, h, 0, 1, None)
@@ -37,16 +39,16 @@ for world in worlds:
     for r, br in enumerate(brs):
         r0, r1 = bands[r]
         for _ in range(3):
-            st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+            st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard, nt.data_ptr())
             st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), r0, r1, br.image, settle=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         K = 20
         for _ in range(K):
-            st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+            st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard, nt.data_ptr())
             st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), r0, r1, br.image)
         torch.cuda.synchronize()
         out.append(((time.perf_counter() - t0) / K * 1e3, r1 - r0, st.kept))
-    print(f"{name} G={world}: per-rank ms (rows, kept): " + "  ".join(f"{t:.3f} ({rr},{k})" for t, rr, k in out)
-          + f"   max {max(t for t, _, _ in out):.3f} ms  [+ all-gather of {per * 16 / 1e6:.0f} MB shards]")
+    print(f"{name} {footprint} G={world}: per-rank ms (rows, kept): " + "  ".join(f"{t:.3f} ({rr},{k})" for t, rr, k in out)
+          + f"   max {max(t for t, _, _ in out):.3f} ms  [+ all-gather of {per * st.rec_floats * 4 / 1e6:.0f} MB shards]")
     st.destroy()
