@@ -218,7 +218,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                                  "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147)"),
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name + ("_disc" if disc else "")),
                      "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                      "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"]},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
