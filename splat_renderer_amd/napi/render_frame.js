@@ -1,10 +1,10 @@
 'use strict';
-// node render_frame.js <props.f32> <normals.f32> <n> <W> <H> <out.rgba8> [<order.u32> <counts.u32> <indices.u32> [<frame.rgba8>]]
+// node render_frame.js <props.f32> <normals.f32> <n> <W> <H> <out.rgba8> [<order.u32> <counts.u32> <indices.u32> [<frame.rgba8> [<seq.rgba8> <discframe.rgba8>]]]
 // Renders one frame through the JS host classes (stage by stage, like the reference's call order)
 // and writes the raw outputs for tests/test_napi.py to compare with the oracle.
 const fs = require('fs');
 const sr = require('./index.js');
-const [propsPath, normalsPath, nStr, wStr, hStr, outPath, orderPath, countsPath, indicesPath, framePath] = process.argv.slice(2);
+const [propsPath, normalsPath, nStr, wStr, hStr, outPath, orderPath, countsPath, indicesPath, framePath, seqPath, discFramePath] = process.argv.slice(2);
 const n = +nStr, W = +wStr, H = +hStr;
 const f32 = (p) => { const b = fs.readFileSync(p); return new Float32Array(b.buffer, b.byteOffset, b.length / 4); };
 const device = new sr.Device(0);
@@ -41,5 +41,19 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     fs.writeFileSync(framePath, Buffer.from(whole.readPixels().buffer));
     framePairs = whole.binner.getTotalIndices();
   }
-  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, uniforms: Array.from(uniforms) }));
+  let seqPairs = -1, discFramePairs = -1;
+  if (seqPath) { // SequentialRenderer with its own footprint (the oriented disc), fed RadixSorter's near-to-far order
+    const seq = new sr.SequentialRenderer(device, null, 'rgba8unorm', n);
+    seq.render(uniforms, props.getPropertyBuffer(), sorter.getSortedIndicesBuffer(), normals, W, H);
+    fs.writeFileSync(seqPath, Buffer.from(seq.readPixels().buffer));
+    seqPairs = seq.binner.getTotalIndices();
+    seq.destroy();
+  }
+  if (discFramePath) { // the whole-frame facade with that footprint, colour plane pre-lit
+    const whole = new sr.Renderer(device, null, 'rgba8unorm', n, 16, { footprint: 'disc' });
+    for (let k = 0; k < 2; k++) whole.render(uniforms, props.getLitPlanes(normals), normals, null, W, H);
+    fs.writeFileSync(discFramePath, Buffer.from(whole.readPixels().buffer));
+    discFramePairs = whole.binner.getTotalIndices();
+  }
+  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, seqPairs, discFramePairs, uniforms: Array.from(uniforms) }));
 })().catch((e) => { console.error(e); process.exit(1); });

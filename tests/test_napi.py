@@ -76,7 +76,8 @@ def test_js_frame_matches_oracle(tmp_path):
     normals.tofile(tmp_path / "normals.f32")
     r = subprocess.run([NODE, "render_frame.js", str(tmp_path / "props.f32"), str(tmp_path / "normals.f32"), str(n), str(w),
                         str(h), str(tmp_path / "out.rgba8"), str(tmp_path / "order.u32"), str(tmp_path / "counts.u32"),
-                        str(tmp_path / "indices.u32"), str(tmp_path / "frame.rgba8")], cwd=NAPI, capture_output=True, text=True,
+                        str(tmp_path / "indices.u32"), str(tmp_path / "frame.rgba8"), str(tmp_path / "seq.rgba8"),
+                        str(tmp_path / "discframe.rgba8")], cwd=NAPI, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
@@ -92,3 +93,18 @@ def test_js_frame_matches_oracle(tmp_path):
     assert info["framePairs"] == ref["indices"].shape[0]
     frame8 = np.fromfile(tmp_path / "frame.rgba8", np.uint8).reshape(h, w, 4)
     assert np.array_equal(frame8, got8)  # same lists, same composite: same bytes as the staged path
+    # SequentialRenderer from JS draws its own footprint (the oriented disc): against the oracle's per-pixel restatement
+    # (early-out on, as the class renders) and, off the rims, against the software rasteriser of SequentialRenderer.ts
+    dproj, discs = O.project_disc(u, props, normals)
+    dkeys, dpay = O.extract_keys(dproj)
+    _, dorder = O.sort_pairs(dkeys, dpay)
+    dcounts, doffsets, didx = O.bin_sorted(dproj, dorder, w, h)
+    _, dwant8, _, rim = O.composite_disc(True, props[:, 4:], normals, discs, didx, dcounts, doffsets, w, h)
+    _, raster8 = O.sequential(u, props, normals, dorder[::-1].copy(), w, h)
+    assert info["seqPairs"] == didx.shape[0] and info["discFramePairs"] == didx.shape[0]
+    seq8 = np.fromfile(tmp_path / "seq.rgba8", np.uint8).reshape(h, w, 4)
+    d = np.abs(seq8.astype(int) - dwant8.astype(int)).max(axis=2)
+    assert d[rim == 0].max() <= 3 and d.max() <= 12 and (d > 1).mean() <= 2e-3
+    assert np.abs(seq8.astype(int) - raster8.astype(int)).max(axis=2)[rim == 0].max() <= 3  # early-out: (1 - 0.99) * 255
+    dframe8 = np.fromfile(tmp_path / "discframe.rgba8", np.uint8).reshape(h, w, 4)
+    assert np.array_equal(dframe8, seq8)  # same lists, same composite
