@@ -326,3 +326,75 @@ def test_disc_frame_pipeline_two_frames_in_flight(device):
     assert not np.array_equal(want[0], want[1])
     pipe.destroy()
     stages.destroy()
+
+
+def test_disc_full_size_C2_properties(device):
+    """BASELINE's headline size (5M @1080p) with the oriented-disc footprint — too big for the oracle's composite in a
+    unit test, so size-independent properties: both frame orders give the same lists and image; the records and
+    bounds are the oracle's (bit for bit, the projector is cheap on the CPU); every list is depth-ordered with index
+    ties ascending; sampled pairs overlap their tile; sampled pixels equal an f64 evaluation of their own list."""
+    n, w, h = sr.scene.CONFIGS["C2"]
+    props, normals, u = make_case(n, w, h)
+    proj_ref, discs_ref = O.project_disc(u, props, normals)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    a = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst", footprint="disc", earlyOut=False)
+    b = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="tileFirst", footprint="disc", earlyOut=False)
+    a.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    b.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    total = a.finish()
+    assert total == b.finish()
+    assert np.array_equal(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(proj_ref))
+    counts = a.binner.getTileCountsBuffer().read(np.uint32)
+    offsets = a.binner.getTileOffsetsBuffer().read(np.uint32)
+    idx = a.binner.getTileIndicesBuffer().read(np.uint32, total)
+    assert np.array_equal(offsets, b.binner.getTileOffsetsBuffer().read(np.uint32))
+    assert np.array_equal(idx, b.binner.getTileIndicesBuffer().read(np.uint32, total))
+    img = a.readPixelsFloat()
+    assert np.array_equal(img.view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    assert int(counts.sum(dtype=np.uint64)) == total
+    # depth order inside every list, ties by ascending index
+    depth = proj_ref[idx, 4]
+    dd = np.diff(depth)
+    starts = offsets[counts > 0][1:]
+    bad = np.nonzero((dd < 0) | ((dd == 0) & (np.diff(idx.astype(np.int64)) <= 0)))[0] + 1
+    assert np.isin(bad, starts).all()
+    # every pair overlaps its tile (spot check)
+    rng = np.random.default_rng(1)
+    pick = rng.integers(0, total, 200000)
+    tile_of = np.searchsorted(offsets, pick, side="right") - 1
+    while True:
+        emp = counts[tile_of] == 0
+        if not emp.any():
+            break
+        tile_of[emp] += 1
+    tx, ty = tile_of % 120, tile_of // 120
+    bb = proj_ref[idx[pick]]
+    assert (np.maximum(bb[:, 0], 0) < (tx + 1) * 16).all() and (np.minimum(bb[:, 2], w) >= tx * 16).all()
+    assert (np.maximum(bb[:, 1], 0) < (ty + 1) * 16).all() and (np.minimum(bb[:, 3], h) >= ty * 16).all()
+    # sampled pixels: the "over" composite of the pixel's own tile list, evaluated in f64 from the f32 records
+    k = np.float64(1.0) / np.sqrt(np.float64(3.0))
+    worst, rim_hits = 0.0, 0
+    for _ in range(300):
+        px, py = int(rng.integers(0, w)), int(rng.integers(0, h))
+        t = (py // 16) * 120 + (px // 16)
+        lst = idx[offsets[t]:offsets[t] + counts[t]]
+        r = discs_ref[lst].astype(np.float64)
+        dx, dy = (px + 0.5) - r[:, 0], (py + 0.5) - r[:, 1]
+        den = 1.0 - (r[:, 6] * dx + r[:, 7] * dy)
+        uu, vv = (r[:, 2] * dx + r[:, 3] * dy) / den, (r[:, 4] * dx + r[:, 5] * dy) / den
+        d2 = uu * uu + vv * vv
+        if (np.abs(d2 - 1.0) < 1e-3).any():
+            rim_hits += 1
+            continue
+        bnd = proj_ref[lst, :4].astype(np.float64)
+        inside = (d2 <= 1.0) & (px + 0.5 >= bnd[:, 0]) & (px + 0.5 <= bnd[:, 2]) & (py + 0.5 >= bnd[:, 1]) & (py + 0.5 <= bnd[:, 3])
+        g = np.where(inside, np.exp(-0.5 * d2 / 0.16), 0.0)
+        trans = np.concatenate([[1.0], np.cumprod(1.0 - g)])
+        nr = normals[lst].astype(np.float64)
+        kd = 0.85 + 0.15 * np.maximum((nr[:, 0] + nr[:, 1] + nr[:, 2]) * k, 0.0)
+        col = props[lst, 4:7].astype(np.float64) * kd[:, None]
+        want = (col * (g * trans[:-1])[:, None]).sum(axis=0) + np.array([0.05, 0.05, 0.1]) * trans[-1]
+        worst = max(worst, float(np.abs(img[py, px, :3] - want).max()))
+    assert worst <= 1e-4 and rim_hits < 100
+    for o in (a, b, pbuf, nbuf):
+        o.destroy()
