@@ -343,10 +343,10 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     td.all_reduce(tmax, op=td.ReduceOp.MAX)
     dt = float(tmax.item())
+    comp_ms = stages.stage_avg_ms(_lib.STAGE_COMPOSITE)
+    p_used = int(stages.consumed.sum().item()) / args.steps  # (before the settling frame below adds its own entries)
     br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # outside the timed region: proves no sync-free frame overflowed
     assert stages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
-    comp_ms = stages.stage_avg_ms(_lib.STAGE_COMPOSITE)
-    p_used = int(stages.consumed.sum().item()) / args.steps
     stages.set_timing(False)
     r0, r1 = br.pixel_rows()
     info = torch.tensor([stages.kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6)], dtype=torch.int64, device="cuda")
