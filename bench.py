@@ -117,6 +117,10 @@ def main():
                     help="isotropic: ComputeShaderRenderer's screen-space Gaussian (SURVEY §8a contract 3, the headline); "
                          "disc: SequentialRenderer's oriented disc (parity vs the CPU rasteriser of SequentialRenderer.ts; "
                          "48-byte exchange records at N>1)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "none"],
+                    help="multi-GPU: allgather = every rank projects 1/N of the splats, ONE RCCL all-gather of the records, band work "
+                         "(north_star's cut); none = every rank projects all splats itself and renders its band (no collective); "
+                         "auto (default) = a timed trial of both, the faster is run and both times are reported")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -303,34 +307,66 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         if ok.item() < 1:
             pipe = None
     loop_ms = {}
+
+    # which loop is faster on THIS node and rank count is measured, not assumed (a few frames of each, slowest rank
+    # decides, all ranks take the same one)
+    def timed(fn):
+        torch.cuda.synchronize()
+        td.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        v = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+        td.all_reduce(v, op=td.ReduceOp.MAX)
+        return float(v.item())
+    trial = 8
     if pipe is not None:
-        # which loop is faster on THIS node and rank count is measured, not assumed (a few frames of each,
-        # slowest rank decides, all ranks take the same one): with a cheap exchange the second stream's
-        # events cost more than the overlap returns
-        def timed(fn):
-            torch.cuda.synchronize()
-            td.barrier()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            v = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
-            td.all_reduce(v, op=td.ReduceOp.MAX)
-            return float(v.item())
-        trial = 8
+        # with a cheap exchange the second stream's events cost more than the overlap returns
         loop_ms["serial"] = timed(lambda: [frame() for _ in range(trial)]) / trial * 1e3
         loop_ms["two_frames_in_flight"] = timed(lambda: pipe.run(trial, lambda k: u, pt.data_ptr(), nt.data_ptr())) / trial * 1e3
         if loop_ms["serial"] <= loop_ms["two_frames_in_flight"]:
             pipe.destroy()
             pipe = None
-    stages.overflows = 0
+    # The same bands with no exchange: every rank holds the splats anyway (the composite gathers their colours), so it
+    # can project all of them itself — 75 us at 5M splats against the all-gather of their records.  Its own ctx, sorter
+    # and binner; the same tile rows; bit-identical band images (tests/test_gpu_stages.py).
+    local = None
+    if args.exchange != "allgather":
+        lst = dist.HipStages(torch, local_rank, n, width, height, tile, footprint=args.footprint)
+        if stages.lit is not None:
+            lst.set_lit(pt.data_ptr(), nt.data_ptr(), n)
+        local = dist.LocalBandRenderer(lst, n, width, height, rank, world, tile)
+        local.row0, local.row1 = br.row0, br.row1
+        for _ in range(3):
+            local.render(u, pt.data_ptr(), nt.data_ptr())
+        local.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
+        if args.exchange == "auto":
+            if "serial" not in loop_ms:
+                loop_ms["serial"] = timed(lambda: [frame() for _ in range(trial)]) / trial * 1e3
+            loop_ms["no_exchange_every_rank_projects_all"] = timed(lambda: [local.render(u, pt.data_ptr(), nt.data_ptr())
+                                                                            for _ in range(trial)]) / trial * 1e3
+            if min(v for k, v in loop_ms.items() if k != "no_exchange_every_rank_projects_all") <= loop_ms["no_exchange_every_rank_projects_all"]:
+                lst.destroy()
+                local = None
+    if local is not None:  # the all-gather side is not run: release it
+        if pipe is not None:
+            pipe.destroy()
+            pipe = None
+        tstages = local.stages
+    else:
+        tstages = stages
+    tstages.overflows = 0
     stages.consumed = torch.zeros(ntx * nty, dtype=torch.int64, device="cuda")  # per tile (no atomics in the kernel)
-    stages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
+    tstages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
     torch.cuda.synchronize()
     td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if pipe is not None:
+    if local is not None:
+        for _ in range(args.steps):
+            local.render(u, pt.data_ptr(), nt.data_ptr())
+    elif pipe is not None:
         # two frames in flight: frame k+1's projection + all-gather (second stream) under frame k's band work
         pipe.run(args.steps, lambda k: u, pt.data_ptr(), nt.data_ptr())
     else:
@@ -343,13 +379,16 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     td.all_reduce(tmax, op=td.ReduceOp.MAX)
     dt = float(tmax.item())
-    comp_ms = stages.stage_avg_ms(_lib.STAGE_COMPOSITE)
-    p_used = int(stages.consumed.sum().item()) / args.steps  # (before the settling frame below adds its own entries)
-    br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)  # outside the timed region: proves no sync-free frame overflowed
-    assert stages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
-    stages.set_timing(False)
+    comp_ms = tstages.stage_avg_ms(_lib.STAGE_COMPOSITE)
+    # (before the settling frame below adds its own entries)
+    p_used = (tstages.timing_consumed() if local is not None else int(stages.consumed.sum().item())) / args.steps
+    # outside the timed region: proves no sync-free frame overflowed
+    (local if local is not None else br).render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
+    assert tstages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
+    tstages.set_timing(False)
     r0, r1 = br.pixel_rows()
-    info = torch.tensor([stages.kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6)], dtype=torch.int64, device="cuda")
+    kept = n if local is not None else stages.kept  # (no band filter without an exchange: every rank bins from all n splats)
+    info = torch.tensor([kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6)], dtype=torch.int64, device="cuda")
     infos = [torch.zeros_like(info) for _ in range(world)]
     td.all_gather(infos, info)
     infos = [[int(v) for v in t.tolist()] for t in infos]
@@ -364,12 +403,17 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
-                   "parallelism": f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * stages.rec_floats * 4} B "
-                                  f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
-                                                          "all-gather run on a second stream under this frame's band work"),
+                   "parallelism": (f"tile-row bands x{world} (balanced by pairs per row), no exchange: every rank projects all "
+                                   f"{n} splats from its own copy (" + ("--exchange none" if args.exchange == "none" else
+                                   "faster on this node than the all-gather of their records, see frame_loop_trial_ms; --exchange "
+                                   "allgather forces the other cut") + ")" if local is not None else
+                                   f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * stages.rec_floats * 4} B "
+                                   f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
+                                                           "all-gather run on a second stream under this frame's band work")),
                    "frame_loop_trial_ms": {k: round(v, 4) for k, v in loop_ms.items()},
-                   "footprint": ("oriented disc (SequentialRenderer.ts:91-142), 48-byte exchange records" if stages.disc else
-                                 "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147), 16-byte exchange records"),
+                   "footprint": ("oriented disc (SequentialRenderer.ts:91-142)" if stages.disc else
+                                 "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147)") +
+                                ("" if local is not None else f", {stages.rec_floats * 4}-byte exchange records"),
                    "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
                                  "composite_ms": i[4] / 1e6} for i in infos],
                    "composite": "front-to-back, early-out at alpha>=0.99"},
@@ -381,6 +425,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     td.barrier()
     if pipe is not None:
         pipe.destroy()
+    if local is not None:
+        local.stages.destroy()
     stages.destroy()
     td.destroy_process_group()
     return result

@@ -20,6 +20,12 @@ tests/test_dist_cpu.py for the sharding logic under gloo).
 Process set-up: import torch BEFORE the first splat ctx is created (before libsplat_hip.so is loaded).  torch
 bundles its own HIP runtime, and the one loaded first serves the whole process.
 
+A second way to cut the same frame needs no exchange at all: every rank holds the splats anyway (the composite
+gathers their colours), so it can project all of them itself and render its band (LocalBandRenderer:
+splat_render_frame with tile_row0/1).  That costs each rank the full projection (75 us at 5M splats) instead of
+1/world of it plus the all-gather; which is faster depends on the links, so bench.py times both and keeps the
+faster.  The image is the same either way.
+
 `stages` is the object that runs device work; the product always uses HipStages (below).  The
 gloo CPU tests inject a checker-backed stand-in to exercise THIS file's slicing / gathering /
 banding logic without a GPU — that stand-in lives under tests/, never here.
@@ -116,6 +122,8 @@ class HipStages:
         self.overflows = 0
         self.consumed = None  # optional torch int64[tiles]: per tile, list entries staged by the composite
         self.lit = None       # optional torch float32[n,4]: lit colour plane (set_lit); band_frame then ignores props/normals
+        self.pos_plane = None  # with it: the (pos, radius) plane, for local_frame
+        self.local_projected = None  # local_frame: the projector's ProjectedSplat records
 
     def set_lit(self, props_ptr, normals_ptr, n):
         """Shade every splat once (kd from its normal) into a colour plane: the composite then gathers two
@@ -123,6 +131,12 @@ class HipStages:
         if self.lit is None or self.lit.shape[0] != n:
             self.lit = self.torch.empty((n, 4), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
         check(self.lib.splat_lit_colors(self.ctx, props_ptr + 16, 2, normals_ptr, 1, n, self.lit.data_ptr()), self.ctx)
+        # the other plane of the native layout (what local_frame's projector reads next to the lit colours)
+        if self.pos_plane is None or self.pos_plane.shape[0] != n:
+            self.pos_plane = self.torch.empty((n, 4), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
+        scratch = self.torch.empty((n, 4), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")  # (the unlit colour plane)
+        check(self.lib.splat_props_to_planes(self.ctx, props_ptr, n, self.pos_plane.data_ptr(), scratch.data_ptr()), self.ctx)
+        check(self.lib.splat_sync(self.ctx), self.ctx)  # scratch is released on return
 
     def set_timing(self, enabled, stage_mask=0xFFFFFFFF):
         check(self.lib.splat_set_timing_stages(self.ctx, stage_mask), self.ctx)
@@ -183,6 +197,43 @@ class HipStages:
             check(rc, self.ctx)
             self.pairs = int(t.value)
 
+    def local_frame(self, uniforms, props_ptr, normals_ptr, n, row0, row1, out_image, settle=False):
+        """Tile rows [row0, row1) of the frame from THIS rank's copy of the splats (splat_render_frame with a band): no
+        exchange; every rank projects all n splats itself.  Same sync-free rules as band_frame."""
+        prelit = self.lit is not None
+        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1, _lib.RECORDS_PROJECTED, int(prelit),
+                           _lib.FOOTPRINT_DISC if self.disc else _lib.FOOTPRINT_ISOTROPIC)
+        if self.local_projected is None or self.local_projected.shape[0] < n:
+            self.local_projected = self.torch.empty((max(n, 1), 8), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
+        u = np.ascontiguousarray(uniforms, np.float32)
+        head = (self.ctx, self.sorter, self.binner, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)))
+        tail = (normals_ptr if (self.disc or not prelit) else None, n, self.width, self.height, self.local_projected.data_ptr(),
+                out_image.data_ptr(), None)
+        if prelit:
+            fn, args = self.lib.splat_render_frame_planes, head + (self.pos_plane.data_ptr(), self.lit.data_ptr()) + tail
+        else:
+            fn, args = self.lib.splat_render_frame, head + (props_ptr,) + tail
+        rc = fn(*args)
+        if rc == -4:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
+            self.overflows += 1
+            rc = fn(*args)
+        check(rc, self.ctx)
+        if settle:
+            t = C.c_uint64()
+            rc = self.lib.splat_bin_total(self.binner, C.byref(t))
+            if rc == -4:
+                self.overflows += 1
+                check(fn(*args), self.ctx)
+                rc = self.lib.splat_bin_total(self.binner, C.byref(t))
+            check(rc, self.ctx)
+            self.pairs = int(t.value)
+
+    def timing_consumed(self):
+        """List entries the composites of local_frame staged since timing was switched on."""
+        v = C.c_uint64()
+        check(self.lib.splat_timing_consumed(self.ctx, C.byref(v)), self.ctx)
+        return int(v.value)
+
     @property
     def kept(self):
         """Splats the last band_frame kept (synchronises)."""
@@ -235,6 +286,25 @@ class BandRenderer:
             rows = t.cpu().numpy()
         self.row0, self.row1 = balanced_rows(rows, self.world)[self.rank]
         return rows
+
+    def pixel_rows(self):
+        return self.row0 * self.tile, min(self.row1 * self.tile, self.height)
+
+
+class LocalBandRenderer:
+    """One rank of a multi-GPU frame with no exchange: the rank projects all n splats from its own copy and renders
+    its band of tile rows.  Same surface as BandRenderer where bench.py and the tests use it."""
+
+    def __init__(self, stages, n, width, height, rank, world, tile=TILE):
+        self.stages, self.n, self.rank, self.world = stages, n, rank, world
+        self.width, self.height, self.tile = width, height, tile
+        self.nty = -(-height // tile)
+        self.row0, self.row1 = band_rows(self.nty, rank, world)
+        self.image = stages.new_image()
+
+    def render(self, uniforms, props_ptr, normals_ptr, settle=False):
+        self.stages.local_frame(uniforms, props_ptr, normals_ptr, self.n, self.row0, self.row1, self.image, settle)
+        return self.image
 
     def pixel_rows(self):
         return self.row0 * self.tile, min(self.row1 * self.tile, self.height)

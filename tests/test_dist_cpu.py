@@ -45,6 +45,12 @@ class OracleStages:
             return
         out_records[:count] = torch.from_numpy(O.project_compact(uniforms, props[first:first + count]))
 
+    def local_frame(self, uniforms, props, normals, n, row0, row1, out_image, settle=False):
+        """dist.LocalBandRenderer's stage: the band from this rank's own copy of all n splats (no exchange)."""
+        rec = self.new_records(n)
+        self.project_slice(uniforms, props, 0, n, rec, normals)
+        self.band_frame(rec, n, props, normals, row0, row1, out_image)
+
     def _records_of(self, records):
         """ProjectedSplat records (originalIndex = position = global index) rebuilt from the exchange records."""
         if not self.disc:
@@ -97,13 +103,14 @@ class OracleStages:
         out_image[r0:r1] = torch.from_numpy(img8[r0:r1])
 
 
-def _worker(rank, world, port, n, w, h, out_dir, disc=False):
+def _worker(rank, world, port, n, w, h, out_dir, disc=False, local=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     props, normals, u = make_case(n, w, h, 31, 1.5)
     st = OracleStages(w, h, disc=disc)
-    br = dist.BandRenderer(st, n, w, h, rank, world, td.all_gather_into_tensor)
+    br = (dist.LocalBandRenderer(st, n, w, h, rank, world) if local else
+          dist.BandRenderer(st, n, w, h, rank, world, td.all_gather_into_tensor))
     img = br.render(u, props, normals)
     r0, r1 = br.pixel_rows()
     np.save(os.path.join(out_dir, f"band{rank}.npy"), img.numpy()[r0:r1])
@@ -152,6 +159,21 @@ def test_band_renderer_gloo_oriented_disc_footprint(tmp_path):
     counts, offsets, idx = O.bin_sorted(proj, order, w, h)
     _, want8, _, _ = O.composite_disc(True, props[:, 4:], normals, discs, idx, counts, offsets, w, h)
     mp.spawn(_worker, args=(world, _free_port(), n, w, h, str(tmp_path), True), nprocs=world, join=True)
+    got = np.zeros_like(want8)
+    for r in range(world):
+        r0, r1, _ = np.load(tmp_path / f"rows{r}.npy")
+        got[r0:r1] = np.load(tmp_path / f"band{r}.npy")
+    assert np.array_equal(got, want8)
+
+
+def test_local_band_renderer_gloo_no_exchange(tmp_path):
+    """dist.LocalBandRenderer under gloo world 2: every rank renders its band from its own copy; no collective."""
+    world, n, w, h = 2, 1201, 160, 112
+    props, normals, u = make_case(n, w, h, 31, 1.5)
+    a = oracle_pipeline(props, normals, u, w, h)
+    _, want8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, a["proj"], a["indices"], a["counts"],
+                              a["offsets"], w, h)
+    mp.spawn(_worker, args=(world, _free_port(), n, w, h, str(tmp_path), False, True), nprocs=world, join=True)
     got = np.zeros_like(want8)
     for r in range(world):
         r0, r1, _ = np.load(tmp_path / f"rows{r}.npy")

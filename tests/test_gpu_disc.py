@@ -398,3 +398,37 @@ def test_disc_full_size_C2_properties(device):
     assert worst <= 1e-4 and rim_hits < 100
     for o in (a, b, pbuf, nbuf):
         o.destroy()
+
+
+@pytest.mark.parametrize("footprint", ["isotropic", "disc"])
+@pytest.mark.parametrize("prelit", [False, True])
+def test_exchange_free_bands_stitch_to_the_single_gpu_frame(device, footprint, prelit):
+    """dist.LocalBandRenderer: every (virtual) rank projects all splats from its own copy and renders its band — no
+    exchange.  The stitched rgba8 image must be bit-identical to the single-GPU frame, for both footprints."""
+    import torch
+    from splat_renderer_amd import dist
+    world, n, w, h = 3, 30001, 400, 232
+    props, normals, u = make_case(n, w, h, 41, 1.5)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    full = sr.Renderer(device, None, "rgba8unorm", n, footprint=footprint)
+    full.render(u, pbuf, nbuf, None, w, h)
+    want = full.readPixels().copy()
+    device.sync()
+    pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+    stages = dist.HipStages(torch, 0, n, w, h, footprint=footprint)
+    if prelit:
+        stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
+        assert np.array_equal(stages.pos_plane.cpu().numpy(), props[:, :4])
+    got = np.zeros_like(want)
+    for rank in range(world):
+        lr = dist.LocalBandRenderer(stages, n, w, h, rank, world)
+        for _ in range(2):  # the second one is a sync-free frame
+            lr.render(u, pt.data_ptr(), nt.data_ptr())
+        lr.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
+        torch.cuda.synchronize()
+        r0, r1 = lr.pixel_rows()
+        got[r0:r1] = lr.image.cpu().numpy()[r0:r1]
+    assert np.array_equal(got, want)
+    stages.destroy()
+    for o in (full, pbuf, nbuf):
+        o.destroy()
