@@ -239,7 +239,10 @@ int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *
                     const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8,
                     void *out_rgba32f, void *consumed_dptr);
 
-/* ---- whole frame: project -> keys -> sort -> bin -> composite ---------------- */
+/* ---- whole frame: project -> keys -> sort -> bin -> composite ----------------
+ * With cfg->tile_row0/1 set to a strict band of tile rows (multi-GPU, no exchange: every rank renders its band from
+ * its own copy of the splats) only that band's pixels, lists and counts are produced, and `projected` holds records
+ * only for splats that may reach the band (the projector skips the others after a conservative test). */
 int splat_render_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                        const splat_composite_cfg *cfg, const float *uniforms, const void *props,
                        const void *normals, uint32_t n, uint32_t width, uint32_t height,

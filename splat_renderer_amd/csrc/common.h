@@ -142,6 +142,7 @@ struct splat_binner {
 // Tile-range parameters handed to the projector so that it can emit range32[] (frame path)
 struct BinParams {
     uint32_t width, height, tile, ntx, nty, row0, row1;
+    uint32_t skip_outside; // frame of a strict band of tile rows: splats that provably cannot reach it are not projected in full
 };
 
 // Where the frame path's projector leaves the first sort pass's histogram (tile_first.hip): per

@@ -440,7 +440,8 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         return ctx_fail(ctx, SPLAT_ERR_INVALID, "splat_render_frame: screens beyond 256 x 256 tiles bin from the projected records: pass a buffer");
     int rc = SPLAT_OK;
     uint32_t *range32 = nullptr;
-    const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
+    // (a strict band: the projector skips what provably cannot reach it; those splats' records are then not written)
+    const BinParams bp = {width, height, tile, ntx, nty, row0, row1, (row0 > 0 || row1 < nty) ? 1u : 0u};
     if (fast) {
         rc = binner_reserve_range32(binner, n);
         if (rc != SPLAT_OK) return rc;

@@ -67,6 +67,35 @@ struct DiscIO {
     float4 *discs;
 };
 
+// Band frames without an exchange (every rank projects all splats): most splats cannot reach the rank's
+// tile rows, and the six offset projections that give the screen radius (12 IEEE divides) are what the projector
+// costs.  This is a cheap, provably conservative test: with a_i = radius * VP[:, i] the screen displacement of the
+// offset along axis i is W/2 * (a_x - ndc_x * a_w) / (c_w + a_w) (and likewise in y), so
+//     |dx| <= W/2 * (max_i |a_x| + |ndc_x| * max_i |a_w|) / (c_w - max_i |a_w|)
+// bounds the radius, hence the padded box; 0.1 % and one pixel of slack cover the rounding of the bound itself, and
+// a tile row more on either side covers the floor/clamp of the exact path.  A splat it rejects has an empty clamped
+// tile range in the exact path too (its record is not written: no list of the band can contain it); anything
+// doubtful (w <= 0, NaN) goes through the exact path.
+__device__ __forceinline__ bool cannot_reach_band(const FrameUniforms &u, float4 pr, const BinParams &bp) {
+    const float *m = u.m;
+    const float cx = ((m[0] * pr.x + m[4] * pr.y) + m[8] * pr.z) + m[12];
+    const float cy = ((m[1] * pr.x + m[5] * pr.y) + m[9] * pr.z) + m[13];
+    const float cw = ((m[3] * pr.x + m[7] * pr.y) + m[11] * pr.z) + m[15];
+    const float r = fabsf(pr.w);
+    const float ax = r * fmaxf(fmaxf(fabsf(m[0]), fabsf(m[4])), fabsf(m[8]));
+    const float ay = r * fmaxf(fmaxf(fabsf(m[1]), fabsf(m[5])), fabsf(m[9]));
+    const float aw = r * fmaxf(fmaxf(fabsf(m[3]), fabsf(m[7])), fabsf(m[11]));
+    const float den = cw - aw;
+    if (!(cw > 0.0f) || !(den > 0.0f)) return false;
+    const float icw = 1.0f / cw, iden = 1.0f / den;
+    const float ndx = cx * icw, ndy = cy * icw;
+    const float bx = (0.5f * u.w) * (ax + fabsf(ndx) * aw) * iden, by = (0.5f * u.h) * (ay + fabsf(ndy) * aw) * iden;
+    const float reach = sqrtf(bx * bx + by * by) * (1.5f * 1.001f) + 1.0f; // >= the padded radius of SplatProjector.ts:119
+    const float scy = ((1.0f - ndy) * 0.5f) * u.h;
+    const float ts = (float)bp.tile;
+    return (scy + reach < (float)bp.row0 * ts - ts) || (scy - reach > (float)bp.row1 * ts + ts); // (NaN: false)
+}
+
 // One splat: record, key, payload, packed tile range.  Returns the packed range (1 = empty).
 // DISC: the footprint is SequentialRenderer's oriented disc — the ProjectedSplat's bounds are the disc's exact
 // screen extent, screenRadius half the larger one, and the disc record goes to dio.discs.
@@ -202,6 +231,66 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
     }
 }
 
+// The same kernel for a strict band of tile rows (bp.skip_outside): a cheap conservative test first, for all 1024
+// splats of the block; the survivors — about 1/G of them, scattered at random over the lanes — are compacted through
+// LDS so that the full projection runs on dense waves (left in place, every wave would still execute it for its few
+// surviving lanes).  Same records, keys, ranges and histogram for every splat that can reach the band; the others get
+// their key, an empty range and no record.
+__global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                           uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
+                                                           uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
+                                                           TfHistOut ho) {
+    __shared__ uint32_t lh[4][256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_list[1024];
+    __shared__ uint32_t s_count;
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
+    if (tid == 0) s_count = 0;
+    for (uint32_t j = tid; j < 4 * 256; j += 256) (&lh[0][0])[j] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = blockIdx.x * 1024u + k * 256u + tid;
+        bool keep = false;
+        if (i < n) {
+            const float4 pr = pos_radius[(size_t)i * stride_vec4];
+            keep = !cannot_reach_band(u, pr, bp);
+            if (!keep) {
+                const float dx = pr.x - u.eye[0], dy = pr.y - u.eye[1], dz = pr.z - u.eye[2];
+                keys[i] = depth_key(sqrtf((dx * dx + dy * dy) + dz * dz)); // (the keys are per splat index: kept whole)
+                range32[i] = 1u;                                           // pack_range32's empty range
+            }
+        } else if (i < n_padded) {
+            keys[i] = 0xffffffffu;
+        }
+        const unsigned long long m = __ballot(keep);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (keep) s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = i;
+    }
+    __syncthreads();
+    const uint32_t kept = s_count;
+    const DiscIO none = {nullptr, 1, nullptr};
+    uint32_t local = 0;
+    for (uint32_t j = tid; j < kept; j += 256) {
+        const uint32_t i = s_list[j];
+        const uint32_t r = project_one<true, true, false>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, none);
+        const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
+        if (tx0 > tx1 || ty0 > ty1) continue;
+        local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if (lane == 0) wsum[w] = local;
+    __syncthreads();
+    if (blockIdx.x < ho.num_parts) {
+        if (tid <= ho.mask) ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+        if (tid == 0) ho.blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_extract_keys(const float4 *__restrict__ projected, uint32_t n, uint32_t n_padded,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ payload) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -271,6 +360,9 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
         if (disc)
             hipLaunchKernelGGL(k_project_hist<true>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
                                (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
+        else if (bp->skip_outside)
+            hipLaunchKernelGGL(k_project_hist_band, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out);
         else
             hipLaunchKernelGGL(k_project_hist<false>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
                                (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
