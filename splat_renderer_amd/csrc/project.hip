@@ -87,10 +87,12 @@ __device__ __forceinline__ bool cannot_reach_band(const FrameUniforms &u, float4
     const float aw = r * fmaxf(fmaxf(fabsf(m[3]), fabsf(m[7])), fabsf(m[11]));
     const float den = cw - aw;
     if (!(cw > 0.0f) || !(den > 0.0f)) return false;
-    const float icw = 1.0f / cw, iden = 1.0f / den;
+    // (hardware reciprocal and square root, 1 ulp: the slack below is a thousand times that, and this test runs for
+    // every splat of the scene on every rank)
+    const float icw = __builtin_amdgcn_rcpf(cw), iden = __builtin_amdgcn_rcpf(den);
     const float ndx = cx * icw, ndy = cy * icw;
     const float bx = (0.5f * u.w) * (ax + fabsf(ndx) * aw) * iden, by = (0.5f * u.h) * (ay + fabsf(ndy) * aw) * iden;
-    const float reach = sqrtf(bx * bx + by * by) * (1.5f * 1.001f) + 1.0f; // >= the padded radius of SplatProjector.ts:119
+    const float reach = __builtin_amdgcn_sqrtf(bx * bx + by * by) * (1.5f * 1.001f) + 1.0f; // >= the padded radius of SplatProjector.ts:119
     const float scy = ((1.0f - ndy) * 0.5f) * u.h;
     const float ts = (float)bp.tile;
     return (scy + reach < (float)bp.row0 * ts - ts) || (scy - reach > (float)bp.row1 * ts + ts); // (NaN: false)
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
 // splats of the block; the survivors — about 1/G of them, scattered at random over the lanes — are compacted through
 // LDS so that the full projection runs on dense waves (left in place, every wave would still execute it for its few
 // surviving lanes).  Same records, keys, ranges and histogram for every splat that can reach the band; the others get
-// their key, an empty range and no record.
+// an all-ones key, an empty range and no record.
 __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                            uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
@@ -257,9 +259,8 @@ __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, cons
             const float4 pr = pos_radius[(size_t)i * stride_vec4];
             keep = !cannot_reach_band(u, pr, bp);
             if (!keep) {
-                const float dx = pr.x - u.eye[0], dy = pr.y - u.eye[1], dz = pr.z - u.eye[2];
-                keys[i] = depth_key(sqrtf((dx * dx + dy * dy) + dz * dz)); // (the keys are per splat index: kept whole)
-                range32[i] = 1u;                                           // pack_range32's empty range
+                keys[i] = 0xffffffffu; // (never read: a splat without pairs contributes no key; written so that the array is defined)
+                range32[i] = 1u;       // pack_range32's empty range
             }
         } else if (i < n_padded) {
             keys[i] = 0xffffffffu;
