@@ -76,15 +76,21 @@ struct DiscIO {
 // a tile row more on either side covers the floor/clamp of the exact path.  A splat it rejects has an empty clamped
 // tile range in the exact path too (its record is not written: no list of the band can contain it); anything
 // doubtful (w <= 0, NaN) goes through the exact path.
-__device__ __forceinline__ bool cannot_reach_band(const FrameUniforms &u, float4 pr, const BinParams &bp) {
+// BALL (the oriented disc): the offsets are not along the axes but anywhere in a ball of radius `r` (the disc p +
+// r (t u + b v), |t| = 1, |b| = |n|, lies in the ball of radius r * max(1, |n|)), so the row NORMS of VP bound the
+// clip-space displacement instead of the largest entry of each row.
+template <bool BALL>
+__device__ __forceinline__ bool cannot_reach_band(const FrameUniforms &u, float4 pr, float r, const BinParams &bp) {
     const float *m = u.m;
     const float cx = ((m[0] * pr.x + m[4] * pr.y) + m[8] * pr.z) + m[12];
     const float cy = ((m[1] * pr.x + m[5] * pr.y) + m[9] * pr.z) + m[13];
     const float cw = ((m[3] * pr.x + m[7] * pr.y) + m[11] * pr.z) + m[15];
-    const float r = fabsf(pr.w);
-    const float ax = r * fmaxf(fmaxf(fabsf(m[0]), fabsf(m[4])), fabsf(m[8]));
-    const float ay = r * fmaxf(fmaxf(fabsf(m[1]), fabsf(m[5])), fabsf(m[9]));
-    const float aw = r * fmaxf(fmaxf(fabsf(m[3]), fabsf(m[7])), fabsf(m[11]));
+    const float ax = r * (BALL ? 1.001f * __builtin_amdgcn_sqrtf((m[0] * m[0] + m[4] * m[4]) + m[8] * m[8])
+                               : fmaxf(fmaxf(fabsf(m[0]), fabsf(m[4])), fabsf(m[8])));
+    const float ay = r * (BALL ? 1.001f * __builtin_amdgcn_sqrtf((m[1] * m[1] + m[5] * m[5]) + m[9] * m[9])
+                               : fmaxf(fmaxf(fabsf(m[1]), fabsf(m[5])), fabsf(m[9])));
+    const float aw = r * (BALL ? 1.001f * __builtin_amdgcn_sqrtf((m[3] * m[3] + m[7] * m[7]) + m[11] * m[11])
+                               : fmaxf(fmaxf(fabsf(m[3]), fabsf(m[7])), fabsf(m[11])));
     const float den = cw - aw;
     if (!(cw > 0.0f) || !(den > 0.0f)) return false;
     // (hardware reciprocal and square root, 1 ulp: the slack below is a thousand times that, and this test runs for
@@ -238,10 +244,11 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
 // LDS so that the full projection runs on dense waves (left in place, every wave would still execute it for its few
 // surviving lanes).  Same records, keys, ranges and histogram for every splat that can reach the band; the others get
 // an all-ones key, an empty range and no record.
+template <bool DISC>
 __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                            uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
-                                                           TfHistOut ho) {
+                                                           TfHistOut ho, DiscIO dio) {
     __shared__ uint32_t lh[4][256];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_list[1024];
@@ -257,7 +264,12 @@ __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, cons
         bool keep = false;
         if (i < n) {
             const float4 pr = pos_radius[(size_t)i * stride_vec4];
-            keep = !cannot_reach_band(u, pr, bp);
+            float r = fabsf(pr.w);
+            if (DISC) {
+                const float4 nr = dio.normals[(size_t)i * dio.normal_stride];
+                r *= fmaxf(1.0f, 1.001f * __builtin_amdgcn_sqrtf((nr.x * nr.x + nr.y * nr.y) + nr.z * nr.z));
+            }
+            keep = !cannot_reach_band<DISC>(u, pr, r, bp); // (NaN radius or normal: kept, the exact path decides)
             if (!keep) {
                 keys[i] = 0xffffffffu; // (never read: a splat without pairs contributes no key; written so that the array is defined)
                 range32[i] = 1u;       // pack_range32's empty range
@@ -273,11 +285,10 @@ __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, cons
     }
     __syncthreads();
     const uint32_t kept = s_count;
-    const DiscIO none = {nullptr, 1, nullptr};
     uint32_t local = 0;
     for (uint32_t j = tid; j < kept; j += 256) {
         const uint32_t i = s_list[j];
-        const uint32_t r = project_one<true, true, false>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, none);
+        const uint32_t r = project_one<true, true, DISC>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
         local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
@@ -358,12 +369,15 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
     hipLaunchKernelGGL((k_project<K, R, D>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, keys ? n_padded : n, index_base, \
                        (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, RANGE, BP, dio)
     if (hist_out && keys && range32 && !payload && index_base == 0) {
-        if (disc)
+        if (disc && bp->skip_outside)
+            hipLaunchKernelGGL(k_project_hist_band<true>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n,
+                               n_padded, (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
+        else if (disc)
             hipLaunchKernelGGL(k_project_hist<true>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
                                (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
         else if (bp->skip_outside)
-            hipLaunchKernelGGL(k_project_hist_band, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
-                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out);
+            hipLaunchKernelGGL(k_project_hist_band<false>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n,
+                               n_padded, (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
         else
             hipLaunchKernelGGL(k_project_hist<false>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
                                (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
