@@ -432,3 +432,32 @@ def test_exchange_free_bands_stitch_to_the_single_gpu_frame(device, footprint, p
     stages.destroy()
     for o in (full, pbuf, nbuf):
         o.destroy()
+
+
+@pytest.mark.parametrize("footprint", ["isotropic", "disc"])
+def test_full_size_C2_eight_exchange_free_bands_stitch_bit_identically(device, footprint):
+    """5M @1080p cut into 8 bands of tile rows, each rendered from all splats with the projector's conservative
+    reach test (k_project_hist_band): a single splat wrongly rejected would change its band's pixels."""
+    from splat_renderer_amd import dist
+    n, w, h = sr.scene.CONFIGS["C2"]
+    props, normals, u = make_case(n, w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n, footprint=footprint)
+    r.render(u, pbuf, nbuf, None, w, h)
+    want = r.readPixels().copy()
+    total = r.finish()
+    counts_full = r.binner.getTileCountsBuffer().read(np.uint32).copy()
+    nty = -(-h // 16)
+    bands = dist.balanced_rows(counts_full.reshape(nty, -1).sum(axis=1), 8)
+    got = np.zeros_like(want)
+    pairs = 0
+    for (r0, r1) in bands:
+        r.render(u, pbuf, nbuf, None, w, h, tileRows=(r0, r1))
+        got[r0 * 16:min(r1 * 16, h)] = r.readPixels()[r0 * 16:min(r1 * 16, h)]
+        c = r.binner.getTileCountsBuffer().read(np.uint32).reshape(nty, -1)
+        assert np.array_equal(c[r0:r1], counts_full.reshape(nty, -1)[r0:r1])  # the band's lists are the full frame's
+        pairs += int(c[r0:r1].sum(dtype=np.uint64))
+    assert pairs == total
+    assert np.array_equal(got, want)
+    for o in (r, pbuf, nbuf):
+        o.destroy()
