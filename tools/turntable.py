@@ -35,12 +35,14 @@ def main():
     ap.add_argument("--config", default="C1", choices=sorted(sr.scene.CONFIGS))
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--out", default="gpurun_out/turntable")
+    ap.add_argument("--footprint", default="isotropic", choices=["isotropic", "disc"],
+                    help="isotropic = ComputeShaderRenderer's Gaussian, disc = SequentialRenderer's oriented disc")
     args = ap.parse_args()
     n, w, h = sr.scene.CONFIGS[args.config]
     props, normals = sr.scene.make_scene(n)
     dev = sr.Device(0)
     pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
-    r = sr.Renderer(dev, None, "rgba8unorm", n)
+    r = sr.Renderer(dev, None, "rgba8unorm", n, footprint=args.footprint)
     cam = sr.Camera()
     cam.setAspect(w / h)
     os.makedirs(args.out, exist_ok=True)
