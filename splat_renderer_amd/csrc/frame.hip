@@ -492,8 +492,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         rc = ctx_ensure_consumed(ctx, ntx * nty);
         if (rc != SPLAT_OK) return rc;
     }
-    return splat_composite(ctx, cfg, color, color_stride, normals, 1, disc && n ? binner->discs : projected, indices, counts, offsets,
-                           width, height, out_rgba8, out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
+    // (n == 0: every list is empty and no record is read; the composite only wants a non-null pointer)
+    const void *records = disc ? (n ? (const void *)binner->discs : (projected ? projected : (const void *)counts)) : projected;
+    return splat_composite(ctx, cfg, color, color_stride, normals, 1, records, indices, counts, offsets, width, height, out_rgba8,
+                           out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
 }
 
 extern "C" {

@@ -461,3 +461,20 @@ def test_full_size_C2_eight_exchange_free_bands_stitch_bit_identically(device, f
     assert np.array_equal(got, want)
     for o in (r, pbuf, nbuf):
         o.destroy()
+
+
+@pytest.mark.parametrize("footprint", ["isotropic", "disc"])
+def test_frame_of_no_splats_is_the_background(device, footprint):
+    w, h = 96, 64
+    _, _, u = make_case(4, w, h, 1)
+    pbuf, nbuf = device.createBuffer(256), device.createBuffer(256)
+    pbuf.zero()
+    nbuf.zero()
+    r = sr.Renderer(device, None, "rgba8unorm", 0, footprint=footprint)
+    for _ in range(2):
+        r.render(u, pbuf, nbuf, None, w, h)
+    img = r.readPixels()
+    assert (img == np.array([13, 13, 26, 255], np.uint8)).all()  # (0.05, 0.05, 0.1, 1) as rgba8unorm
+    assert r.finish() == 0
+    for o in (r, pbuf, nbuf):
+        o.destroy()
