@@ -478,3 +478,41 @@ def test_frame_of_no_splats_is_the_background(device, footprint):
     assert r.finish() == 0
     for o in (r, pbuf, nbuf):
         o.destroy()
+
+
+def test_disc_random_scenes(device):
+    """Seeded sweep over sizes, aspect ratios, splat scales, camera distances (inside the cube too: splats behind the
+    eye and discs crossing w = 0 are culled) and normal distributions (unit, scaled, near the |n.y| = 0.9 switch, zero):
+    records and lists against the oracle bit for bit, the image within the stated tolerance."""
+    rng = np.random.default_rng(20261004)
+    for case in range(24):
+        n = int(rng.integers(1, 6000))
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        rs = float(rng.choice([0.05, 0.3, 1.0, 2.5, 8.0]))
+        cam = dict(distance=float(rng.uniform(0.5, 6.0)), azimuth=float(rng.uniform(0, 6.28)), elevation=float(rng.uniform(-1.2, 1.2)))
+        props, normals, u = make_case(n, w, h, 2000 + case, rs, camera=cam)
+        kind = case % 4
+        if kind == 1:
+            normals[:, :3] *= rng.uniform(0.2, 3.0, (n, 1)).astype(np.float32)
+        elif kind == 2:
+            normals[:, 1] = np.float32(0.9) + rng.uniform(-1e-3, 1e-3, n).astype(np.float32)
+        elif kind == 3:
+            normals[rng.random(n) < 0.2] = 0
+        ref = oracle_disc(props, normals, u, w, h, early_out=False)
+        pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+        r = sr.Renderer(device, None, "rgba8unorm", n, earlyOut=False, footprint="disc",
+                        frameOrder="tileFirst" if case % 2 else "sortFirst")
+        r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+        tag = (case, n, w, h, rs, cam)
+        total = ref["indices"].shape[0]
+        assert r.finish() == total, tag
+        assert np.array_equal(bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"])), tag
+        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"]), tag
+        if total:
+            assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), tag
+        got = r.readPixelsFloat()
+        d = np.abs(got - ref["img"]).max(axis=2)
+        off = ref["rim"] == 0
+        assert (not off.any() or d[off].max() <= TOL) and d.max() <= TOL_RIM, (tag, float(d.max()))
+        for o in (r, pbuf, nbuf):
+            o.destroy()
