@@ -28,18 +28,24 @@ from splat_renderer_amd import _lib, dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
 
 
-def composite_alg_bytes(p_used, width, height, prelit=False):
-    """per consumed list entry 4 (idx) + 32 (ProjectedSplat) + 16 (colour vec4) +
-    16 (normal vec4) = 68 B, plus 4 B per rgba8 pixel written.  With a pre-lit colour plane the normal
-    is not read: 52 B per entry (the kernel is credited only with what it moves)."""
-    return (52 if prelit else 68) * p_used + 4 * width * height
+def composite_alg_bytes(p_used, width, height):
+    """SURVEY §8d, unchanged: per CONSUMED list entry 4 (idx) + 32 (ProjectedSplat) + 16 (colour vec4) +
+    16 (normal vec4) = 68 B in the reference's own layouts, plus 4 B per rgba8 pixel written."""
+    return 68 * p_used + 4 * width * height
 
 
-def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height, prelit=False, disc=False):
+def composite_traffic_model(p_staged, width, height, records, prelit, disc=False):
+    """What the kernel as built is expected to move: per STAGED entry (256-entry batches) the 4-byte index and its
+    gathers — one 32-byte lit composite record; or ProjectedSplat 32 + colour 16 (+ normal 16 unless pre-lit)."""
+    per = 4 + (32 if (records == "lit" and not disc) else (48 if prelit else 64))
+    return per * p_staged + 4 * width * height
+
+
+def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height, disc=False):
     """SURVEY §8d whole-frame model: project+key 56N, sort 68Np, count 20N, scan 8T, fill 20N+4P,
-    composite (68 or 52) P_used + 4WH.  The oriented-disc projector also reads the normal (16) and writes
+    composite 68 P_used + 4WH.  The oriented-disc projector also reads the normal (16) and writes
     the disc record (32) and, as benched, leaves the ProjectedSplat (32) out: 72N."""
-    return (72 if disc else 56) * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height, prelit)
+    return (72 if disc else 56) * n + 68 * n_sorted + 20 * n + 8 * tiles + 20 * n + 4 * pairs + composite_alg_bytes(p_used, width, height)
 
 
 def cpu_baseline(name, props, normals, u, width, height):
@@ -95,14 +101,46 @@ def measured_copy_ceiling(dev):
 
 
 def load_traffic(config):
+    """PMC-derived figures of k_composite for this configuration, collected under rocprofv3 in separate --pmc passes
+    and committed (profiles/traffic.json names the csv each comes from): they are NOT measured in this run."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
     try:
         with open(path) as f:
-            return json.load(f).get(config, {}).get("k_composite_hbm_bytes_per_launch")
+            return json.load(f).get(config) or {}
     except Exception:
+        return {}
+
+
+def time_composite_alone(dev, r, u, pbuf, nbuf, width, height, tile, early_out, launches=5):
+    """k_composite by itself on the frame's own records and lists (outside the timed region): HIP-event duration per
+    launch and the {staged, consumed} entry counts.  early_out=False is SURVEY §8d's composite-only figure
+    (P_used = P: every entry of every list, 68 P + 4WH algorithmic bytes)."""
+    lib, ctx = dev.lib, dev.ctx
+    ntx, nty = -(-width // tile), -(-height // tile)
+    csr = sr.ComputeShaderRenderer(dev, None, "rgba8unorm", earlyOut=early_out, footprint=r.footprint, recordFormat=r.recordFormat)
+    csr.consumedBuffer = dev.createBuffer(ntx * nty * 16)
+    b = r.binner
+    records = r.projector.getProjectedBuffer()
+    if r.footprint == _lib.FOOTPRINT_DISC:
+        raise SystemExit("time_composite_alone: isotropic frames only")
+    props = pbuf if not isinstance(pbuf, sr.host.PropertyPlanes) else None
+    if props is None and r.recordFormat != _lib.RECORDS_LIT32:
         return None
+    args = (u, props if props is not None else records, b.getTileIndicesBuffer(), nbuf if nbuf is not None else records, records,
+            b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), tile, ntx, width, height)
+    csr.render(*args)  # warm
+    csr.consumedBuffer.zero()
+    _lib.check(lib.splat_set_timing_stages(ctx, 1 << _lib.STAGE_COMPOSITE), ctx)
+    dev.setTiming(True)
+    for _ in range(launches):
+        csr.render(*args)
+    dev.sync()
+    cnt, tot = C.c_uint32(), C.c_double()
+    _lib.check(lib.splat_stage_time_stats(ctx, _lib.STAGE_COMPOSITE, C.byref(cnt), C.byref(tot)), ctx)
+    dev.setTiming(False)
+    cons = csr.consumedBuffer.read(np.uint64).reshape(-1, 2).sum(axis=0) / launches
+    csr.destroy()
+    return {"ms": tot.value / max(cnt.value, 1), "staged": float(cons[0]), "consumed": float(cons[1])}
 
 
 def main():
@@ -111,16 +149,21 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=sorted(sr.scene.CONFIGS))
-    ap.add_argument("--layout", default="planes", choices=["planes", "interleaved"],
-                    help="splat properties as two vec4 planes (native) or the reference's interleaved 32-byte records")
+    ap.add_argument("--layout", default="interleaved", choices=["planes", "interleaved"],
+                    help="splat properties as the reference's interleaved 32-byte records + vec4 normals (default: shading happens "
+                         "inside the timed frame) or as two vec4 planes with the colour plane lit once, outside the frame")
+    ap.add_argument("--records", default="lit", choices=["lit", "projected"],
+                    help="what the frame's projector writes and the composite gathers per staged list entry: the 32-byte lit "
+                         "composite record (one line) or the reference's ProjectedSplat + colour + normal (three lines)")
     ap.add_argument("--footprint", default="isotropic", choices=["isotropic", "disc"],
                     help="isotropic: ComputeShaderRenderer's screen-space Gaussian (SURVEY §8a contract 3, the headline); "
                          "disc: SequentialRenderer's oriented disc (parity vs the CPU rasteriser of SequentialRenderer.ts; "
                          "48-byte exchange records at N>1)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "none"],
+    ap.add_argument("--exchange", default="allgather", choices=["auto", "allgather", "none"],
                     help="multi-GPU: allgather = every rank projects 1/N of the splats, ONE RCCL all-gather of the records, band work "
                          "(north_star's cut); none = every rank projects all splats itself and renders its band (no collective); "
-                         "auto (default) = a timed trial of both, the faster is run and both times are reported")
+                         "auto = a timed trial of both, the faster is run.  Default allgather; the other cut's trial time is "
+                         "reported as an extra key either way")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,12 +202,14 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     pm = sr.SplatPropertyManager(dev, n)
     pm.setFromArrays(props)
     nbuf = dev.createBufferFrom(normals)
-    # the native layout unless asked for the reference's records: two vec4 planes (what updatePlanesFromCurvature
-    # writes), the colour plane carrying the reference's shading (once per property update, not per list entry)
-    pbuf = pm.getLitPlanes(nbuf) if args.layout == "planes" else pm.getPropertyBuffer()
+    # default: the reference's layouts (32-byte interleaved property records + vec4 normals), shading inside the frame.
+    # --layout planes: two vec4 planes (what updatePlanesFromCurvature writes), the colour plane lit once per property
+    # update, outside the frame
+    prelit = args.layout == "planes"
+    pbuf = pm.getLitPlanes(nbuf) if prelit else pm.getPropertyBuffer()
     disc = args.footprint == "disc"
     # (a disc frame's composite reads the disc records: the ProjectedSplat by-product is left out)
-    r = sr.Renderer(dev, None, "rgba8unorm", n, tile, footprint=args.footprint, writeProjected=not disc)
+    r = sr.Renderer(dev, None, "rgba8unorm", n, tile, footprint=args.footprint, writeProjected=not disc, records=args.records)
 
     def frame():
         r.render(u, pbuf, nbuf, None, width, height)
@@ -188,9 +233,9 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     dev.sync()
     dt = time.perf_counter() - t0
     composite_ms = stage_avg(_lib.STAGE_COMPOSITE)
-    consumed = C.c_uint64()
-    _lib.check(lib.splat_timing_consumed(ctx, C.byref(consumed)), ctx)
-    p_used = consumed.value / args.steps
+    staged, consumed = C.c_uint64(), C.c_uint64()
+    _lib.check(lib.splat_timing_consumed(ctx, C.byref(staged), C.byref(consumed)), ctx)
+    p_staged, p_used = staged.value / args.steps, consumed.value / args.steps
     # per-stage breakdown from a separate short loop with every stage's events on (not part of `value`)
     _lib.check(lib.splat_set_timing_stages(ctx, 0xFFFFFFFF), ctx)
     dev.setTiming(True)
@@ -203,34 +248,59 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     pairs = r.binner.getTotalIndices()
 
     copy_gbs = measured_copy_ceiling(dev)
-    prelit = args.layout == "planes"
-    comp_bytes = composite_alg_bytes(p_used, width, height, prelit)
+    comp_bytes = composite_alg_bytes(p_used, width, height)
     comp_s = stage_ms["composite"] / 1e3
     achieved = comp_bytes / comp_s / 1e9
-    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, prelit, disc)
+    frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, disc)
+    pmc = load_traffic(name + ("_disc" if disc else "") + ("" if (args.records == "lit" or disc) else "_projected_records"))
+    roofline = {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"],
+                "formula": "SURVEY 8d: 68 B x pairs_consumed + 4 B x W x H, / avg launch (HIP events on the ctx stream inside the timed region)",
+                "pairs_consumed": round(p_used), "pairs_staged": round(p_staged),
+                "traffic_model": composite_traffic_model(p_staged, width, height, args.records, prelit, disc),
+                "traffic_model_note": "bytes the kernel as built is expected to move: per STAGED entry (256-entry batches) 4 B index + its "
+                                      "gathered record(s), + 4 B per pixel",
+                "traffic": pmc.get("k_composite_hbm_bytes_per_launch"),
+                "traffic_source": pmc.get("source", "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not measured in this run)")
+                                  if pmc.get("k_composite_hbm_bytes_per_launch") else None,
+                "valu_frac": pmc.get("valu_busy_frac"),
+                "valu_frac_source": pmc.get("valu_source") if pmc.get("valu_busy_frac") else None,
+                "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
         "frames_per_s": args.steps / dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
-                   "pairs_P": pairs, "pairs_consumed_P_used": round(p_used), "parallelism": "1 GPU",
-                   "property_layout": ("two vec4 planes (pos,radius | lit rgb,opacity): shading kd(normal) applied once per property update"
-                                       if args.layout == "planes" else "interleaved 32-byte records (reference layout), shading in the composite"),
+                   "pairs_P": pairs, "pairs_consumed_P_used": round(p_used), "pairs_staged": round(p_staged), "parallelism": "1 GPU",
+                   "property_layout": ("two vec4 planes (pos,radius | lit rgb,opacity): shading kd(normal) applied once per property update, outside the frame"
+                                       if prelit else "interleaved 32-byte records + vec4 normals (the reference's layouts); shading inside the timed frame"),
+                   "records": ("disc records" if disc else
+                               "32-byte lit composite records written by the projector (centre, radius, depth | lit rgb): one gathered line per staged entry"
+                               if args.records == "lit" else "ProjectedSplat records; colour (+ normal) gathered per staged entry"),
                    "frame_order": os.environ.get("SPLAT_FRAME_ORDER", "tile-first (bin, then depth-sort per tile; library default)"),
                    "footprint": ("oriented disc (SequentialRenderer.ts:91-142), inverse homography per pixel" if disc else
                                  "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147)"),
                    "composite": "front-to-back, early-out at alpha>=0.99"},
-        "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(name + ("_disc" if disc else "")),
-                     "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                     "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"]},
+        "roofline": roofline,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                            "achieved_GBps": frame_bytes / (dt / args.steps) / 1e9,
                            "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "frac_of_measured_copy": frame_bytes / (dt / args.steps) / 1e9 / copy_gbs},
     }
+    if not disc:
+        # SURVEY 8d's composite-only figure: early-out OFF, every entry of every list consumed (68 P + 4WH), the same
+        # kernel on the same frame's records and lists, outside the timed region
+        off = time_composite_alone(dev, r, u, pbuf, nbuf, width, height, tile, early_out=False)
+        if off is not None:
+            ob = composite_alg_bytes(off["consumed"], width, height)
+            result["extra"] = {"composite_early_out_off": {
+                "avg_launch_ms": off["ms"], "pairs_consumed": round(off["consumed"]), "algorithmic_bytes_per_launch": ob,
+                "achieved_GBps": ob / (off["ms"] / 1e3) / 1e9, "frac": ob / (off["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                "traffic_model": composite_traffic_model(off["staged"], width, height, args.records, prelit),
+                "note": "k_composite alone with the alpha>=0.99 break disabled on the timed frame's lists: SURVEY 8d composite-only figure"}}
     if not args.no_cpu_baseline:
         cb = cpu_baseline(name, props, normals, u, width, height)
         ref8 = cb.pop("frame_u8")
@@ -245,6 +315,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
             cb.pop("all_cores")
             ref8 = seq8
         if not args.no_parity:
+            frame()  # (the early-out-off launches above wrote their own output texture, not the renderer's)
             got8 = r.readPixels()
             diff = np.abs(got8.astype(np.int16) - ref8.astype(np.int16))
             result["parity_vs_cpu_frame"] = {"max_abs_lsb": int(diff.max()),
@@ -332,7 +403,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     # can project all of them itself — 75 us at 5M splats against the all-gather of their records.  Its own ctx, sorter
     # and binner; the same tile rows; bit-identical band images (tests/test_gpu_stages.py).
     local = None
-    if args.exchange != "allgather":
+    try:  # (the trial of the other cut is an extra key: it must never cost the run its headline)
         lst = dist.HipStages(torch, local_rank, n, width, height, tile, footprint=args.footprint)
         if stages.lit is not None:
             lst.set_lit(pt.data_ptr(), nt.data_ptr(), n)
@@ -341,14 +412,24 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         for _ in range(3):
             local.render(u, pt.data_ptr(), nt.data_ptr())
         local.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
-        if args.exchange == "auto":
-            if "serial" not in loop_ms:
-                loop_ms["serial"] = timed(lambda: [frame() for _ in range(trial)]) / trial * 1e3
-            loop_ms["no_exchange_every_rank_projects_all"] = timed(lambda: [local.render(u, pt.data_ptr(), nt.data_ptr())
-                                                                            for _ in range(trial)]) / trial * 1e3
-            if min(v for k, v in loop_ms.items() if k != "no_exchange_every_rank_projects_all") <= loop_ms["no_exchange_every_rank_projects_all"]:
-                lst.destroy()
-                local = None
+        ok = torch.ones(1, device="cuda")
+    except Exception as e:
+        print(f"[rank {rank}] exchange-free band renderer unavailable ({e!r})", file=sys.stderr)
+        local, ok = None, torch.zeros(1, device="cuda")
+    td.all_reduce(ok, op=td.ReduceOp.MIN)
+    if ok.item() < 1:
+        if args.exchange == "none":
+            raise SystemExit("--exchange none: the exchange-free band renderer could not be set up on every rank")
+        local = None
+    if local is not None:
+        if "serial" not in loop_ms:
+            loop_ms["serial"] = timed(lambda: [frame() for _ in range(trial)]) / trial * 1e3
+        loop_ms["no_exchange_every_rank_projects_all"] = timed(lambda: [local.render(u, pt.data_ptr(), nt.data_ptr())
+                                                                        for _ in range(trial)]) / trial * 1e3
+        faster = loop_ms["no_exchange_every_rank_projects_all"] < min(v for k, v in loop_ms.items() if k != "no_exchange_every_rank_projects_all")
+        if args.exchange == "allgather" or (args.exchange == "auto" and not faster):
+            local.stages.destroy()
+            local = None
     if local is not None:  # the all-gather side is not run: release it
         if pipe is not None:
             pipe.destroy()
@@ -357,7 +438,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     else:
         tstages = stages
     tstages.overflows = 0
-    stages.consumed = torch.zeros(ntx * nty, dtype=torch.int64, device="cuda")  # per tile (no atomics in the kernel)
+    stages.consumed = torch.zeros((ntx * nty, 2), dtype=torch.int64, device="cuda")  # per tile {staged, consumed} (no atomics in the kernel)
     tstages.set_timing(True, 1 << _lib.STAGE_COMPOSITE)
     torch.cuda.synchronize()
     td.barrier()
@@ -381,7 +462,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     dt = float(tmax.item())
     comp_ms = tstages.stage_avg_ms(_lib.STAGE_COMPOSITE)
     # (before the settling frame below adds its own entries)
-    p_used = (tstages.timing_consumed() if local is not None else int(stages.consumed.sum().item())) / args.steps
+    p_used = (tstages.timing_consumed()[1] if local is not None else int(stages.consumed[:, 1].sum().item())) / args.steps
     # outside the timed region: proves no sync-free frame overflowed
     (local if local is not None else br).render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
     assert tstages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
@@ -395,7 +476,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     # roofline of the dominant kernel on the slowest rank's composite (per launch = per band)
     slow = max(range(world), key=lambda k: infos[k][4])
     rows_px = min(infos[slow][2] * tile, height) - infos[slow][1] * tile
-    comp_bytes = composite_alg_bytes(infos[slow][3], width, rows_px, stages.lit is not None)
+    comp_bytes = composite_alg_bytes(infos[slow][3], width, rows_px)
     achieved = comp_bytes / (infos[slow][4] / 1e9) / 1e9 if infos[slow][4] else 0.0
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
@@ -405,8 +486,8 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         "config": {"workload": workload, "n_splats": n, "width": width, "height": height, "tile": tile,
                    "parallelism": (f"tile-row bands x{world} (balanced by pairs per row), no exchange: every rank projects all "
                                    f"{n} splats from its own copy (" + ("--exchange none" if args.exchange == "none" else
-                                   "faster on this node than the all-gather of their records, see frame_loop_trial_ms; --exchange "
-                                   "allgather forces the other cut") + ")" if local is not None else
+                                   "--exchange auto: faster on this node than the all-gather of their records, see frame_loop_trial_ms"
+                                   ) + ")" if local is not None else
                                    f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * stages.rec_floats * 4} B "
                                    f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
                                                            "all-gather run on a second stream under this frame's band work")),

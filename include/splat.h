@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 1
+#define SPLAT_ABI_VERSION 2
 
 #define SPLAT_OK 0
 #define SPLAT_ERR_INVALID (-1)  /* bad argument */
@@ -81,9 +81,11 @@ int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);
 /* Every timed run of `stage` since timing was last enabled: number of samples and their summed
  * duration (synchronises).  Enabling timing again starts a new sample set. */
 int splat_stage_time_stats(splat_ctx *ctx, int stage, uint32_t *samples, double *total_ms);
-/* List entries staged by splat_render_frame's composite since timing was last enabled (P_used of
- * SURVEY §8d, at the kernel's 256-entry batch granularity); synchronises. */
-int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries); /* summed over tiles and timed frames; synchronises */
+/* List entries of splat_render_frame's composite since timing was last enabled, summed over tiles and timed
+ * frames; synchronises.  *consumed = P_used of SURVEY §8d: per tile, the entries its pixels visited before the
+ * last of them reached alpha >= 0.99 (the whole list if one never did; = the pair total with early-out off).
+ * *staged = what the kernel actually gathered: the same, rounded up to its 256-entry batches. */
+int splat_timing_consumed(splat_ctx *ctx, uint64_t *staged, uint64_t *consumed);
 
 /* ---- buffers (GPUBuffer equivalent: device.createBuffer / queue.writeBuffer / mapAsync) --- */
 int splat_buf_alloc(splat_ctx *ctx, size_t bytes, void **dptr);
@@ -202,6 +204,12 @@ int splat_validate_tile_order(splat_ctx *ctx, const void *projected, const void 
 #define SPLAT_RECORDS_PROJECTED 0
 #define SPLAT_RECORDS_COMPACT 1
 #define SPLAT_RECORDS_DISC48 2 /* oriented-disc exchange records, see splat_project_slice_disc (footprint DISC only) */
+#define SPLAT_RECORDS_LIT32 3  /* lit composite records: float4 {centre x, y, screen radius, depth}, float4 {lit r, g, b, opacity} per
+                                * splat — everything evaluateSplat (src/ComputeShaderRenderer.ts:117-147) reads of a splat in ONE
+                                * 32-byte line: the ProjectedSplat's bounds are centre -/+ radius * 1.5 in the projector's operation
+                                * order (src/SplatProjector.ts:119-121), the colour already carries the shading of :143-145.
+                                * splat_render_frame* writes them in place of the ProjectedSplat records when asked to (isotropic
+                                * footprint); the composite then gathers one line per staged list entry instead of three. */
 #define SPLAT_FOOTPRINT_ISOTROPIC 0
 #define SPLAT_FOOTPRINT_DISC 1
 typedef struct splat_composite_cfg {
@@ -211,8 +219,10 @@ typedef struct splat_composite_cfg {
     uint32_t tile_row0;  /* render tile rows [tile_row0, tile_row1) (multi-GPU band) */
     uint32_t tile_row1;  /* UINT32_MAX = to the last row */
     uint32_t record_format; /* what `projected` / `records` point at: SPLAT_RECORDS_PROJECTED (32-byte
-                             * ProjectedSplat, the reference's struct) or SPLAT_RECORDS_COMPACT (16-byte
-                             * exchange records, see splat_project_slice_compact) */
+                             * ProjectedSplat, the reference's struct), SPLAT_RECORDS_COMPACT (16-byte
+                             * exchange records, see splat_project_slice_compact) or SPLAT_RECORDS_LIT32 (color_opacity
+                             * and normals are then not read and may be NULL).  In splat_render_frame*: the format the
+                             * frame's projector leaves in `projected` — PROJECTED or LIT32 */
     uint32_t prelit;        /* 1 = color_opacity holds LIT colours (splat_lit_colors): the composite then gathers two
                              * lines per staged entry instead of three and does not read normals (may be NULL) */
     uint32_t footprint;     /* SPLAT_FOOTPRINT_ISOTROPIC: ComputeShaderRenderer's screen-space Gaussian (default).
@@ -225,9 +235,9 @@ typedef struct splat_composite_cfg {
 } splat_composite_cfg;
 /* color_opacity / normals: vec4 per splat, *_stride_vec4 float4s apart.  out_rgba8 (W*H*4 bytes,
  * rgba8unorm, may be NULL) and out_rgba32f (W*H*16 bytes, may be NULL) are full-frame images;
- * only pixels of the rendered tile rows are written.  consumed_dptr (optional): u64[ceil(W/16) *
- * ceil(H/16)], one counter per tile; a rendered tile's counter is incremented by the number of its
- * list entries staged before the tile saturated (their sum over tiles is P_used). */
+ * only pixels of the rendered tile rows are written.  consumed_dptr (optional): u64[2 * ceil(W/16) *
+ * ceil(H/16)], two counters per tile; a rendered tile's counters are incremented by {entries staged,
+ * entries consumed} (see splat_timing_consumed; the sum of the second over tiles is P_used). */
 /* The reference shades every splat with kd = 0.85 + 0.15 * max(dot(normal, (1,1,1)/sqrt 3), 0)
  * (src/ComputeShaderRenderer.ts:143-145).  lit[i] = vec4(rgb * kd, opacity): computed once per property
  * update instead of once per staged entry; the same bits either way (explicitly rounded operations). */

@@ -329,7 +329,14 @@ typedef struct {
     uint32_t tile, ntx, width, height, row0, row1;
     float *out_f32; uint8_t *out_u8;
     uint64_t consumed;
+    uint32_t *stop;  /* optional, per pixel: list entries visited (index of the break + 1, or the whole list) */
+    uint8_t *near;   /* optional, per pixel: 1 if its alpha came within ORC_STOP_MARGIN of the 0.99 threshold at some entry */
 } comp_job;
+
+/* a pixel whose alpha lands this close to the threshold may legitimately stop one entry earlier or later in
+ * another correct float evaluation (different exp, fused multiply-adds): tests hold such pixels to the loose
+ * bound (1 - 0.99) * max colour and every other pixel to the tight one */
+#define ORC_STOP_MARGIN 2e-5f
 
 static void composite_rows(comp_job *j) {
     const float inv_sqrt3 = 1.0f / sqrtf(3.0f); /* normalize(vec3(1,1,1)) :143 */
@@ -342,9 +349,12 @@ static void composite_rows(comp_job *j) {
             float cr = 0.0f, cg = 0.0f, cb = 0.0f;
             float alpha = 0.0f; /* literal mode */
             float trans = 1.0f; /* front-to-back mode: T = prod(1-g) */
+            uint32_t visited = 0;
+            uint8_t near = 0;
             for (uint32_t i = 0; i < cnt; ++i) {
                 uint32_t s = j->indices[off + i];
                 ++consumed;
+                ++visited;
                 const float *rec = j->proj + (size_t)s * ORC_PROJ_FLOATS;
                 float g = 0.0f, lr = 0.0f, lg = 0.0f, lb = 0.0f;
                 /* evaluateSplat :98-148 */
@@ -370,15 +380,19 @@ static void composite_rows(comp_job *j) {
                     cg = cg * (1.0f - g) + lg * g;
                     cb = cb * (1.0f - g) + lb * g;
                     alpha = alpha * (1.0f - g) + g;
+                    if (fabsf(alpha - 0.99f) < ORC_STOP_MARGIN) near = 1;
                     if (j->early_out && alpha >= 0.99f) break; /* :187-190 */
                 } else {
                     /* SURVEY §8a contract 3: nearest on top, C += c*g*T, T *= (1-g) */
                     float w = trans * g;
                     cr = cr + lr * w; cg = cg + lg * w; cb = cb + lb * w;
                     trans = trans * (1.0f - g);
+                    if (fabsf((1.0f - trans) - 0.99f) < ORC_STOP_MARGIN) near = 1;
                     if (j->early_out && (1.0f - trans) >= 0.99f) break;
                 }
             }
+            if (j->stop) j->stop[(size_t)py * j->width + px] = visited;
+            if (j->near) j->near[(size_t)py * j->width + px] = near;
             float rem = (j->mode == ORC_MODE_REFERENCE_LITERAL) ? (1.0f - alpha) : trans;
             float fr = cr + 0.05f * rem, fg = cg + 0.05f * rem, fb = cb + 0.1f * rem; /* :193-195 */
             size_t o = ((size_t)py * j->width + px) * 4;
@@ -394,8 +408,17 @@ uint64_t orc_composite(int mode, int early_out, const float *color_opacity, size
                        const uint32_t *indices, const uint32_t *counts, const uint32_t *offsets,
                        uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
                        uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8) {
+    return orc_composite_ex(mode, early_out, color_opacity, color_stride, normals, normal_stride, projected, indices, counts,
+                            offsets, tile, ntx, width, height, row0, row1, out_f32, out_u8, NULL, NULL);
+}
+
+uint64_t orc_composite_ex(int mode, int early_out, const float *color_opacity, size_t color_stride,
+                          const float *normals, size_t normal_stride, const float *projected,
+                          const uint32_t *indices, const uint32_t *counts, const uint32_t *offsets,
+                          uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
+                          uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8, uint32_t *stop, uint8_t *near) {
     comp_job j = {mode, early_out, color_opacity, color_stride, normals, normal_stride, projected,
-                  indices, counts, offsets, tile, ntx, width, height, row0, row1, out_f32, out_u8, 0};
+                  indices, counts, offsets, tile, ntx, width, height, row0, row1, out_f32, out_u8, 0, stop, near};
     if (row1 > height) j.row1 = height;
     composite_rows(&j);
     return j.consumed;
@@ -759,7 +782,7 @@ int orc_frame(int mode, int early_out, const float uniforms[22], const float *pr
             if (r1 > height) r1 = height;
             if (r0 > height) r0 = height;
             cj[t] = (comp_job){mode, early_out, props + 4, 8, normals, 4, proj, indices, counts, offsets,
-                               tile, ntx, width, height, r0, r1, out_f32, out_u8, 0};
+                               tile, ntx, width, height, r0, r1, out_f32, out_u8, 0, NULL, NULL};
             pthread_create(&th[t], NULL, comp_thread, &cj[t]);
         }
         for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);

@@ -91,6 +91,15 @@ uint64_t orc_composite(int mode, int early_out, const float *color_opacity, size
                        const uint32_t *indices, const uint32_t *counts, const uint32_t *offsets,
                        uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
                        uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8);
+/* The same with two optional per-pixel outputs (width*height each): stop = list entries the pixel visited (the
+ * index of its break + 1, or its tile's whole list) — the per-tile maximum is SURVEY §8d's P_used of that tile;
+ * near = 1 where the pixel's alpha came within 2e-5 of the 0.99 threshold at some entry (such a pixel may stop
+ * one entry earlier or later in another correct float evaluation). */
+uint64_t orc_composite_ex(int mode, int early_out, const float *color_opacity, size_t color_stride,
+                          const float *normals, size_t normal_stride, const float *projected,
+                          const uint32_t *indices, const uint32_t *counts, const uint32_t *offsets,
+                          uint32_t tile, uint32_t ntx, uint32_t width, uint32_t height,
+                          uint32_t row0, uint32_t row1, float *out_f32, uint8_t *out_u8, uint32_t *stop, uint8_t *near);
 
 /* SequentialRenderer (src/SequentialRenderer.ts:68-142,186-209,246-307), "model B":
  * one oriented quad per splat in `order[0..n_order)`, src-alpha blending over the clear colour.

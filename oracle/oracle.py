@@ -50,6 +50,8 @@ def lib():
                                     u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, fp, u8p]
         L.orc_composite.restype = C.c_uint64
+        L.orc_composite_ex.argtypes = L.orc_composite.argtypes + [u32p, u8p]
+        L.orc_composite_ex.restype = C.c_uint64
         L.orc_sequential.argtypes = [fp, fp, C.c_size_t, fp, C.c_size_t, fp, C.c_size_t, u32p,
                                      C.c_uint32, C.c_uint32, C.c_uint32, fp, u8p]
         L.orc_update_props.argtypes = [fp, fp, C.c_uint32, fp]
@@ -177,8 +179,10 @@ def gpu_tile_range(rec, tile, ntx, nty):
 
 
 def composite(mode, early_out, color_opacity, normals, projected, indices, counts, offsets, width,
-              height, tile=16, rows=None, want_u8=True):
-    """color_opacity: (n,4) plane or a view into (n,8) props[:,4:]; normals: (n,4)."""
+              height, tile=16, rows=None, want_u8=True, want_stops=False):
+    """color_opacity: (n,4) plane or a view into (n,8) props[:,4:]; normals: (n,4).
+    want_stops: also return (stop, near) per pixel — entries visited, and whether the pixel's alpha came within
+    2e-5 of the 0.99 threshold (see orc_composite_ex)."""
     color_opacity = np.asarray(color_opacity, dtype=np.float32)
     cs = color_opacity.strides[0] // 4
     normals = _c32(normals)
@@ -193,9 +197,14 @@ def composite(mode, early_out, color_opacity, normals, projected, indices, count
     out = np.zeros((height, width, 4), np.float32)
     out8 = np.zeros((height, width, 4), np.uint8) if want_u8 else None
     cptr = C.cast(color_opacity.ctypes.data, C.POINTER(C.c_float))
-    consumed = lib().orc_composite(mode, int(early_out), cptr, cs, _f(normals), normals.shape[1], _f(projected),
-                                   _u(indices), _u(counts), _u(offsets), tile, ntx, width, height, r0, r1,
-                                   _f(out), _b(out8) if want_u8 else None)
+    stop = np.zeros((height, width), np.uint32) if want_stops else None
+    near = np.zeros((height, width), np.uint8) if want_stops else None
+    consumed = lib().orc_composite_ex(mode, int(early_out), cptr, cs, _f(normals), normals.shape[1], _f(projected),
+                                      _u(indices), _u(counts), _u(offsets), tile, ntx, width, height, r0, r1,
+                                      _f(out), _b(out8) if want_u8 else None, _u(stop) if want_stops else None,
+                                      _b(near) if want_stops else None)
+    if want_stops:
+        return out, out8, int(consumed), stop, near
     return out, out8, int(consumed)
 
 

@@ -16,7 +16,7 @@ ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -
 STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2, 3, 4
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
 MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
-RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_DISC48 = 0, 1, 2
+RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_DISC48, RECORDS_LIT32 = 0, 1, 2, 3
 FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC = 0, 1
 U32_MAX = 0xFFFFFFFF
 
@@ -48,7 +48,7 @@ SIGNATURES = {
     "splat_set_timing_stages": (_i, [_vp, _u32]),
     "splat_stage_time_ms": (_i, [_vp, _i, C.POINTER(C.c_float)]),
     "splat_stage_time_stats": (_i, [_vp, _i, C.POINTER(_u32), C.POINTER(C.c_double)]),
-    "splat_timing_consumed": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "splat_timing_consumed": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "splat_buf_alloc": (_i, [_vp, _sz, _pvp]),
     "splat_buf_free": (_i, [_vp, _vp]),
     "splat_buf_upload": (_i, [_vp, _vp, _vp, _sz]),

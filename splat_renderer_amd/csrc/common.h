@@ -182,4 +182,5 @@ int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
                    const BinParams *bp, const TfHistOut *hist_out = nullptr, const void *normals = nullptr,
-                   uint32_t normal_stride_vec4 = 1, void *discs = nullptr); // discs != NULL: the oriented-disc footprint (disc.h)
+                   uint32_t normal_stride_vec4 = 1, void *discs = nullptr, // discs != NULL: the oriented-disc footprint (disc.h)
+                   const struct LitIO *lit = nullptr);                     // lit->records != NULL: also write lit composite records (shade.h)

@@ -24,6 +24,7 @@
 // Compiled with -ffp-contract=fast; compared with the oracle within a stated tolerance.
 #include "common.h"
 #include "disc.h"
+#include "shade.h"
 
 #include <hip/hip_ext.h>
 
@@ -37,6 +38,7 @@ struct CompositeParams {
     const float4 *normals; uint32_t normal_stride; // vec4(normal, scaleFactor)
     const float4 *projected;                       // 2 x float4 per splat (ProjectedSplat), or 1 x float4 (compact exchange record)
     uint32_t compact;
+    uint32_t lit32;                                // projected holds lit composite records (shade.h): colour and normals are not read
     uint32_t disc;                                 // projected holds disc records (disc.h): the oriented-disc footprint
     uint32_t disc_stride;                          // float4s between disc records: 2 (projector's) or 3 (48-byte exchange records)
     uint32_t prelit;                               // color holds lit colours (k_lit_colors): normals are not read
@@ -44,7 +46,7 @@ struct CompositeParams {
     uint32_t width, height, ntx, tile_row0;
     uint32_t *out_rgba8;
     float4 *out_rgba32f;
-    unsigned long long *consumed;
+    unsigned long long *consumed; // per tile {entries staged, entries consumed}, accumulated (or NULL)
 };
 
 __device__ __forceinline__ uint32_t unorm8(float v) {
@@ -82,19 +84,6 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
-// The reference's shading of one splat (ComputeShaderRenderer.ts:143-145): colour scaled by
-// kd = 0.85 + 0.15 * max(dot(normal, normalize(1,1,1)), 0).  Contraction is switched off for this function:
-// one IEEE operation per operator, so the bits are the oracle's, and the same whether it runs per staged
-// entry in the composite or once per splat in k_lit_colors (the rest of this file is compiled with
-// contraction on, and two call sites would otherwise be free to fuse differently).
-__device__ __forceinline__ float4 lit_color(float4 c, float4 nrm) {
-#pragma clang fp contract(off) // (HIP's __fmul_rn / __fadd_rn are plain operators and would be contracted like any other)
-    const float k = 0.577350269189625764f; // normalize(vec3(1,1,1)) :143
-    const float ndl = (nrm.x * k + nrm.y * k) + nrm.z * k;
-    const float kd = 0.85f + 0.15f * fmaxf(ndl, 0.0f); // :144-145
-    return make_float4(c.x * kd, c.y * kd, c.z * kd, c.w);
-}
-
 // The lit colours of all splats as a plane: when the composite is given this plane (cfg->prelit) it
 // gathers two lines per staged entry (record, lit colour) instead of three (record, colour, normal) —
 // the gathers, not the arithmetic, are what a staged entry costs (108 -> 93 us at C2 for one line less).
@@ -109,11 +98,9 @@ __global__ __launch_bounds__(256) void k_lit_colors(const float4 *__restrict__ c
 // y, radius, depth}: the bounds are rebuilt exactly as the projector forms them (SplatProjector.ts:
 // 119-121) — with contraction switched off for this function (the file is compiled with it on).
 __device__ __forceinline__ void fetch_record(const CompositeParams &p, uint32_t idx, float4 &bounds, float &radius) {
-#pragma clang fp contract(off) // the bounds must be the projector's: one rounding per operation
     if (p.compact) {
         const float4 c = p.projected[idx];
-        const float padded = c.z * 1.5f;
-        bounds = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
+        bounds = lit_bounds(c); // the bounds must be the projector's: one rounding per operation
         radius = c.z;
     } else {
         bounds = p.projected[(size_t)idx * 2];
@@ -134,7 +121,28 @@ constexpr float DISC_EXP2_SCALE = -4.508422002777011f;
 // DISC: the footprint is SequentialRenderer's oriented disc (disc.h) — per entry the 32-byte disc record and
 // the lit colour are staged, a pixel is inside when u^2 + v^2 <= 1 with (u,v) = B*d / (1 - q.d); the
 // coverage masks come from the disc's exact bounds, as the binner's tile ranges do.
-template <int MODE, bool EARLY_OUT, bool DISC>
+// LIT32: `projected` holds the frame's lit composite records (shade.h) — ONE 32-byte gather per staged entry gives
+// centre, radius and lit colour; colour and normal arrays are not touched.
+template <int MODE, bool EARLY_OUT, bool DISC, bool LIT32>
+__device__ __forceinline__ void fetch_entry(const CompositeParams &p, uint32_t idx, float4 &f_b, float4 &f_b2, float4 &f_c, float4 &f_n,
+                                            float &f_r) {
+    if constexpr (DISC) {
+        f_b = p.projected[(size_t)idx * p.disc_stride];
+        f_b2 = p.projected[(size_t)idx * p.disc_stride + 1];
+    } else if constexpr (LIT32) {
+        const float4 c = p.projected[(size_t)idx * 2];
+        f_c = p.projected[(size_t)idx * 2 + 1];
+        f_b = lit_bounds(c);
+        f_r = c.z;
+        return;
+    } else {
+        fetch_record(p, idx, f_b, f_r);
+    }
+    f_c = p.color[(size_t)idx * p.color_stride];
+    if (!p.prelit) f_n = p.normals[(size_t)idx * p.normal_stride];
+}
+
+template <int MODE, bool EARLY_OUT, bool DISC, bool LIT32>
 __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     // per entry one 32-byte record {centre.x, centre.y, exp2 scale, lit blue | lit red, lit green, -, -}: both
     // halves are read off ONE address register (ds_read_b128 + ds_read_b64 offset:16), and forming an LDS
@@ -145,6 +153,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     __shared__ float4 s_par[CBATCH][PAR];
     __shared__ uint2 s_mask[4][CBATCH];  // per quadrant: which of its 64 pixels the entry's box covers
     __shared__ uint32_t s_wave_done[4];
+    __shared__ uint32_t s_wave_consumed[4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t tx = blockIdx.x, ty = blockIdx.y + p.tile_row0;
@@ -164,6 +173,9 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     if (tid < 4) s_wave_done[tid] = 0;
 
     uint32_t staged = 0;
+    // list entries this wave needed: the position after the entry at which its last pixel saturated, or the whole
+    // list if some pixel never did (SURVEY §8d's P_used per tile = the largest of the four; = count with early-out off)
+    uint32_t needed = 0;
 
     // ---- list-entry fetch, split from its use (issue early / write LDS late).  Almost every tile
     // saturates inside its first batch, but tiles on a silhouette keep some pixel open and walk
@@ -193,16 +205,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             uint32_t xm = 0, ym = 0;
             if (!f_ready) { // the first three batches of a tile: fetch now
                 f_idx = (tid < CBATCH && e < count) ? p.indices[off + e] : 0xffffffffu;
-                if (f_idx != 0xffffffffu) {
-                    if constexpr (DISC) {
-                        f_b = p.projected[(size_t)f_idx * p.disc_stride];
-                        f_b2 = p.projected[(size_t)f_idx * p.disc_stride + 1];
-                    } else {
-                        fetch_record(p, f_idx, f_b, f_r);
-                    }
-                    f_c = p.color[(size_t)f_idx * p.color_stride];
-                    if (!p.prelit) f_n = p.normals[(size_t)f_idx * p.normal_stride];
-                }
+                if (f_idx != 0xffffffffu) fetch_entry<MODE, EARLY_OUT, DISC, LIT32>(p, f_idx, f_b, f_b2, f_c, f_n, f_r);
             }
             if (DISC && f_idx != 0xffffffffu) {
                 const DiscRecord rec = {f_b, f_b2};
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 const float4 b = f_b;
                 const float r = f_r;
                 if (!(r < 0.5f)) { // :127-129 "too small"
-                    const float4 c = p.prelit ? f_c : lit_color(f_c, f_n);
+                    const float4 c = (LIT32 || p.prelit) ? f_c : lit_color(f_c, f_n);
                     col = make_float2(c.x, c.y);
                     // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(dist^2 * scale)
                     geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), c.z); // :124
@@ -247,16 +250,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             if (base >= CBATCH) { // a tile that needed a second batch usually needs more
                 if (n_idx_valid) { // index of batch k+1 arrived a batch ago: its gathers go out now
                     f_idx = n_idx;
-                    if (f_idx != 0xffffffffu) {
-                        if constexpr (DISC) {
-                            f_b = p.projected[(size_t)f_idx * p.disc_stride];
-                            f_b2 = p.projected[(size_t)f_idx * p.disc_stride + 1];
-                        } else {
-                            fetch_record(p, f_idx, f_b, f_r);
-                        }
-                        f_c = p.color[(size_t)f_idx * p.color_stride];
-                        if (!p.prelit) f_n = p.normals[(size_t)f_idx * p.normal_stride];
-                    }
+                    if (f_idx != 0xffffffffu) fetch_entry<MODE, EARLY_OUT, DISC, LIT32>(p, f_idx, f_b, f_b2, f_c, f_n, f_r);
                     f_ready = true;
                 }
                 const uint32_t e2 = e + 2 * CBATCH; // batch k+2
@@ -272,6 +266,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
         }
         // ---- consume: 4 chunks of 64 entries; lane j looks at entry c0+j's mask for this quadrant ---
         const uint32_t batch_n = (count - base < CBATCH) ? (count - base) : CBATCH;
+        needed = base + batch_n; // unless the wave saturates inside this batch (below)
         for (uint32_t c0 = 0; c0 < batch_n && uniform64(live) != 0; c0 += 64) {
             const uint2 mm = s_mask[w][c0 + lane];
             // entries of this chunk that cover at least one pixel still accumulating
@@ -337,6 +332,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     if (EARLY_OUT) lv &= ~__ballot(acc <= T_STOP);
                 }
                 lv = uniform64(lv);
+                const bool first_saturated = lv == 0; // (scalar; only read on the way out)
                 g1 = __builtin_amdgcn_inverse_ballot_w64(cover1 & lv) ? g1 : 0.0f;
                 if (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) {
                     const float om = 1.0f - g1;
@@ -354,7 +350,10 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     if (EARLY_OUT) lv &= ~__ballot(acc <= T_STOP);
                 }
                 live = lv;
-                if (EARLY_OUT && uniform64(live) == 0) break;
+                if (EARLY_OUT && uniform64(live) == 0) {
+                    needed = base + c0 + (first_saturated ? j0 : j1) + 1;
+                    break;
+                }
             }
         }
         if (EARLY_OUT && uniform64(live) == 0 && lane == 0) s_wave_done[w] = 1;
@@ -362,7 +361,15 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
 
     // (per tile, no atomics: 8160 workgroups adding to ONE counter cost the kernel 30 us at C1 and 80 us
     // at C3 — the measurement was slowing down what it measured)
-    if (p.consumed && tid == 0 && staged) p.consumed[tile_idx] += (unsigned long long)staged;
+    if (p.consumed) { // (uniform branch; timed / diagnostic runs only)
+        if (lane == 0) s_wave_consumed[w] = needed;
+        __syncthreads();
+        if (tid == 0 && staged) {
+            const uint32_t used = max(max(s_wave_consumed[0], s_wave_consumed[1]), max(s_wave_consumed[2], s_wave_consumed[3]));
+            p.consumed[(size_t)tile_idx * 2] += (unsigned long long)staged;
+            p.consumed[(size_t)tile_idx * 2 + 1] += (unsigned long long)used;
+        }
+    }
 
     if (pixel_ok) {
         const float rem = (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) ? (1.0f - acc) : acc;
@@ -395,9 +402,11 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     ARG_CHECK(ctx, cfg != nullptr);
     ARG_CHECK(ctx, cfg->tile_size == CT); // the kernel's quadrant mapping is built for 16x16 tiles
     ARG_CHECK(ctx, cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK || cfg->mode == SPLAT_COMPOSITE_REFERENCE_LITERAL);
-    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_DISC48);
+    ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_LIT32);
     ARG_CHECK(ctx, width >= 1 && height >= 1 && width <= 65535u * CT && height <= 65535u * CT);
-    ARG_CHECK(ctx, color_opacity && (normals || cfg->prelit) && projected && tile_indices && tile_counts && tile_offsets);
+    const bool lit32 = cfg->record_format == SPLAT_RECORDS_LIT32; // the records carry the lit colour: no colour / normal arrays
+    ARG_CHECK(ctx, lit32 || (color_opacity && (normals || cfg->prelit)));
+    ARG_CHECK(ctx, projected && tile_indices && tile_counts && tile_offsets);
     ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
     ARG_CHECK(ctx, out_rgba8 || out_rgba32f);
     ARG_CHECK(ctx, (((uintptr_t)color_opacity | (uintptr_t)normals | (uintptr_t)projected | (uintptr_t)out_rgba32f) & 15) == 0);
@@ -405,7 +414,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     // the oriented disc is SequentialRenderer's footprint: nearest-on-top "over" is its only blend, and its
     // records are the projector's 32-byte disc records
     ARG_CHECK(ctx, cfg->footprint != SPLAT_FOOTPRINT_DISC ||
-                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format != SPLAT_RECORDS_COMPACT));
+                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format != SPLAT_RECORDS_COMPACT && !lit32));
     ARG_CHECK(ctx, cfg->record_format != SPLAT_RECORDS_DISC48 || cfg->footprint == SPLAT_FOOTPRINT_DISC);
     const uint32_t ntx = div_up(width, CT), nty = div_up(height, CT);
     uint32_t r0 = cfg->tile_row0, r1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
@@ -417,6 +426,7 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.normal_stride = normal_stride_vec4;
     p.projected = (const float4 *)projected;
     p.compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
+    p.lit32 = cfg->record_format == SPLAT_RECORDS_LIT32;
     p.prelit = cfg->prelit != 0;
     p.disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
     p.disc_stride = cfg->record_format == SPLAT_RECORDS_DISC48 ? 3u : 2u;
@@ -435,20 +445,30 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool timed = stage_event_pair(ctx, SPLAT_STAGE_COMPOSITE, &ev0, &ev1);
-#define SPLAT_COMPOSITE_LAUNCH(MODE, EO, DISC)                                                                       \
-    do {                                                                                                             \
-        if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO, DISC>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
-        else hipLaunchKernelGGL((k_composite<MODE, EO, DISC>), grid, block, 0, ctx->stream, p);                     \
+#define SPLAT_COMPOSITE_LAUNCH(MODE, EO, DISC, LIT)                                                                       \
+    do {                                                                                                                  \
+        if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO, DISC, LIT>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
+        else hipLaunchKernelGGL((k_composite<MODE, EO, DISC, LIT>), grid, block, 0, ctx->stream, p);                     \
     } while (0)
     if (p.disc) {
-        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, true);
-        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, true);
+        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, true, false);
+        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, true, false);
     } else if (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
-        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, false);
-        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, false);
+        if (lit32) {
+            if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, false, true);
+            else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, false, true);
+        } else {
+            if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, false, false);
+            else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, false, false);
+        }
     } else {
-        if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, true, false);
-        else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, false, false);
+        if (lit32) {
+            if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, true, false, true);
+            else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, false, false, true);
+        } else {
+            if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, true, false, false);
+            else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_REFERENCE_LITERAL, false, false, false);
+        }
     }
 #undef SPLAT_COMPOSITE_LAUNCH
     LAUNCH_CHECK(ctx, "k_composite");

@@ -159,7 +159,7 @@ int splat_set_timing(splat_ctx *ctx, int enabled) {
     if (ctx->timing) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (auto &t : ctx->timers) t.used = 0; // start a new sample set
-        if (ctx->d_consumed) HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, (size_t)ctx->consumed_tiles * 8, ctx->stream));
+        if (ctx->d_consumed) HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, (size_t)ctx->consumed_tiles * 16, ctx->stream));
     }
     return SPLAT_OK;
 }
@@ -177,10 +177,11 @@ int ctx_ensure_consumed(splat_ctx *ctx, uint32_t tiles) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // (grown mid-run: counts gathered so far at the old size are kept)
     unsigned long long *bigger = nullptr;
-    if (hipMalloc((void **)&bigger, (size_t)tiles * 8) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counters hipMalloc");
-    HIP_TRY(ctx, hipMemset(bigger, 0, (size_t)tiles * 8));
+    // (two counters per tile: entries staged, entries consumed)
+    if (hipMalloc((void **)&bigger, (size_t)tiles * 16) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counters hipMalloc");
+    HIP_TRY(ctx, hipMemset(bigger, 0, (size_t)tiles * 16));
     if (ctx->d_consumed) {
-        HIP_TRY(ctx, hipMemcpy(bigger, ctx->d_consumed, (size_t)ctx->consumed_tiles * 8, hipMemcpyDeviceToDevice));
+        HIP_TRY(ctx, hipMemcpy(bigger, ctx->d_consumed, (size_t)ctx->consumed_tiles * 16, hipMemcpyDeviceToDevice));
         (void)hipFree(ctx->d_consumed);
     }
     ctx->d_consumed = bigger;
@@ -190,17 +191,21 @@ int ctx_ensure_consumed(splat_ctx *ctx, uint32_t tiles) {
 
 extern "C" {
 
-int splat_timing_consumed(splat_ctx *ctx, uint64_t *entries) {
+int splat_timing_consumed(splat_ctx *ctx, uint64_t *staged, uint64_t *consumed) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ARG_CHECK(ctx, entries != nullptr);
-    *entries = 0;
+    ARG_CHECK(ctx, staged != nullptr && consumed != nullptr);
+    *staged = *consumed = 0;
     if (!ctx->d_consumed) return SPLAT_OK; // no timed frame has run
-    std::vector<unsigned long long> host(ctx->consumed_tiles);
-    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->d_consumed, (size_t)ctx->consumed_tiles * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> host((size_t)ctx->consumed_tiles * 2);
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->d_consumed, host.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long v = 0;
-    for (unsigned long long c : host) v += c;
-    *entries = v;
+    unsigned long long s = 0, c = 0;
+    for (size_t t = 0; t < host.size(); t += 2) {
+        s += host[t];
+        c += host[t + 1];
+    }
+    *staged = s;
+    *consumed = c;
     return SPLAT_OK;
 }
 

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "tile_range.h"
 #include "disc.h"
+#include "shade.h"
 
 #include <cstdlib>
 
@@ -425,6 +426,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     ARG_CHECK(ctx, projected || cfg->footprint == SPLAT_FOOTPRINT_DISC);
     // the oriented disc (SequentialRenderer's footprint): its projector needs the normals, its records live with the binner
     const bool disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
+    // cfg->record_format says what the frame leaves in `projected` and composites from: the reference's ProjectedSplat
+    // records, or the lit composite records (shade.h) — one gathered line per staged list entry instead of three
+    ARG_CHECK(ctx, cfg->record_format == SPLAT_RECORDS_PROJECTED || (cfg->record_format == SPLAT_RECORDS_LIT32 && !disc));
+    const bool lit = cfg->record_format == SPLAT_RECORDS_LIT32;
     ARG_CHECK(ctx, !disc || (normals && (((uintptr_t)normals) & 15) == 0));
     if (n > splat_sort_capacity(sorter)) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_render_frame: n exceeds the sorter's capacity");
     ARG_CHECK(ctx, width >= 1 && height >= 1);
@@ -436,8 +441,9 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (row0 > row1) row0 = row1;
     const bool fast = ntx <= 256 && nty <= 256 && n > 0;
-    if (!projected && n > 0 && !fast)
-        return ctx_fail(ctx, SPLAT_ERR_INVALID, "splat_render_frame: screens beyond 256 x 256 tiles bin from the projected records: pass a buffer");
+    if ((!projected || lit) && n > 0 && !fast)
+        return ctx_fail(ctx, SPLAT_ERR_INVALID, "splat_render_frame: screens beyond 256 x 256 tiles bin from ProjectedSplat records: pass a "
+                                                "buffer and cfg->record_format = SPLAT_RECORDS_PROJECTED");
     int rc = SPLAT_OK;
     uint32_t *range32 = nullptr;
     // (a strict band: the projector skips what provably cannot reach it; those splats' records are then not written)
@@ -464,8 +470,9 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         binner->discs_cap = n;
     }
     // (the payload array is not written: payload = splat index)
-    rc = project_launch(ctx, uniforms, props, pos_stride, n, 0, projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
-                        tile_first ? &ho : nullptr, normals, 1, disc ? binner->discs : nullptr);
+    const LitIO lio = {(const float4 *)color, (const float4 *)normals, color_stride, 1u, cfg->prelit, lit ? (float4 *)projected : nullptr};
+    rc = project_launch(ctx, uniforms, props, pos_stride, n, 0, lit ? nullptr : projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
+                        tile_first ? &ho : nullptr, normals, 1, disc ? binner->discs : nullptr, &lio);
     if (rc != SPLAT_OK) return rc;
     binner->tf_hist_ready = tile_first;
     // (with per-index tile ranges the binner never reads the records; it only wants a non-null pointer)

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "tile_range.h"
 #include "disc.h"
+#include "shade.h"
 
 struct FrameUniforms {
     float m[16];   // VP, column-major
@@ -107,11 +108,14 @@ __device__ __forceinline__ bool cannot_reach_band(const FrameUniforms &u, float4
 // One splat: record, key, payload, packed tile range.  Returns the packed range (1 = empty).
 // DISC: the footprint is SequentialRenderer's oriented disc — the ProjectedSplat's bounds are the disc's exact
 // screen extent, screenRadius half the larger one, and the disc record goes to dio.discs.
-template <bool WITH_KEYS, bool WITH_RANGE, bool DISC>
+// LIT (isotropic frames): the 32-byte composite record {centre, radius, depth | lit colour} goes to lio.records
+// (shade.h) — everything the composite reads of a splat, in one line; the ProjectedSplat is then optional.
+template <bool WITH_KEYS, bool WITH_RANGE, bool DISC, bool LIT = false>
 __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                 uint32_t i, uint32_t index_base, float4 *__restrict__ projected,
                                                 uint32_t *__restrict__ keys, uint32_t *__restrict__ payload,
-                                                uint32_t *__restrict__ range32, const BinParams &bp, const DiscIO &dio) {
+                                                uint32_t *__restrict__ range32, const BinParams &bp, const DiscIO &dio,
+                                                const LitIO &lio = LitIO{}) {
     float4 a, b;
     float depth;
     if (DISC) {
@@ -130,8 +134,13 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const fl
         float padded = max_r * 1.5f; // :119
         a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
         b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
+        if (LIT) {
+            const float4 col = lio.color[(size_t)i * lio.color_stride];
+            lio.records[(size_t)i * 2] = c;
+            lio.records[(size_t)i * 2 + 1] = lio.prelit ? col : lit_color(col, lio.normals[(size_t)i * lio.normal_stride]);
+        }
     }
-    if (!DISC || projected) { // (a disc frame's composite reads the disc records: the ProjectedSplat output is optional there)
+    if ((!DISC && !LIT) || projected) { // (a disc or lit frame's composite reads its own records: the ProjectedSplat is optional there)
         projected[(size_t)i * 2] = a;
         projected[(size_t)i * 2 + 1] = b;
     }
@@ -184,12 +193,12 @@ __global__ __launch_bounds__(256) void k_expand_compact(const float4 *__restrict
     projected[(size_t)i * 2 + 1] = make_float4(c.w, c.z, __uint_as_float(index_base + i), 0.0f);
 }
 
-template <bool WITH_KEYS, bool WITH_RANGE, bool DISC>
+template <bool WITH_KEYS, bool WITH_RANGE, bool DISC, bool LIT = false>
 __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *__restrict__ pos_radius,
                                                  uint32_t stride_vec4, uint32_t n, uint32_t n_padded, uint32_t index_base,
                                                  float4 *__restrict__ projected, uint32_t *__restrict__ keys,
                                                  uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, BinParams bp,
-                                                 DiscIO dio) {
+                                                 DiscIO dio, LitIO lio) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) {
         if (WITH_KEYS && i < n_padded) { // extract-depth-keys.wgsl:46-50
@@ -198,18 +207,19 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
         }
         return;
     }
-    project_one<WITH_KEYS, WITH_RANGE, DISC>(u, pos_radius, stride_vec4, i, index_base, projected, keys, payload, range32, bp, dio);
+    project_one<WITH_KEYS, WITH_RANGE, DISC, LIT>(u, pos_radius, stride_vec4, i, index_base, projected, keys, payload, range32, bp, dio,
+                                                  lio);
 }
 
 // Tile-first frame path: 1024 splats per workgroup (the binner's block), and while each splat's tile
 // rectangle is in registers the block's pairs are counted per low tile-id digit — the histogram the
 // first pass of the tile-id sort needs (tile_first.hip; k_band_prepare_tf in frame.hip does the same for
 // the gathered records of a multi-GPU band).  The kernel is HBM-bound; the LDS counting hides under the stores.
-template <bool DISC>
+template <bool DISC, bool LIT>
 __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                       uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
-                                                      TfHistOut ho, DiscIO dio) {
+                                                      TfHistOut ho, DiscIO dio, LitIO lio) {
     __shared__ uint32_t lh[4][256];
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
@@ -224,7 +234,8 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
             if (i < n_padded) keys[i] = 0xffffffffu;
             continue;
         }
-        const uint32_t r = project_one<true, true, DISC>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio);
+        const uint32_t r = project_one<true, true, DISC, LIT>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio,
+                                                              lio);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
         local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
@@ -244,11 +255,11 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
 // LDS so that the full projection runs on dense waves (left in place, every wave would still execute it for its few
 // surviving lanes).  Same records, keys, ranges and histogram for every splat that can reach the band; the others get
 // an all-ones key, an empty range and no record.
-template <bool DISC>
+template <bool DISC, bool LIT>
 __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                            uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
-                                                           TfHistOut ho, DiscIO dio) {
+                                                           TfHistOut ho, DiscIO dio, LitIO lio) {
     __shared__ uint32_t lh[4][256];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_list[1024];
@@ -288,7 +299,8 @@ __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, cons
     uint32_t local = 0;
     for (uint32_t j = tid; j < kept; j += 256) {
         const uint32_t i = s_list[j];
-        const uint32_t r = project_one<true, true, DISC>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio);
+        const uint32_t r = project_one<true, true, DISC, LIT>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio,
+                                                              lio);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
         local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
@@ -353,7 +365,8 @@ static void load_uniforms(FrameUniforms &u, const float *uniforms) {
 
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,
-                   const BinParams *bp, const TfHistOut *hist_out, const void *normals, uint32_t normal_stride_vec4, void *discs) {
+                   const BinParams *bp, const TfHistOut *hist_out, const void *normals, uint32_t normal_stride_vec4, void *discs,
+                   const LitIO *lit) {
     FrameUniforms u;
     load_uniforms(u, uniforms);
     const uint32_t work = keys ? n_padded : n;
@@ -363,35 +376,39 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
     const bool disc = discs != nullptr; // the oriented-disc footprint (disc.h): normals in, disc records out
     const DiscIO dio = {disc ? (const float4 *)normals + (size_t)index_base * normal_stride_vec4 : nullptr, normal_stride_vec4,
                         (float4 *)discs};
+    // lit composite records (shade.h): isotropic frames only, written next to the keys and tile ranges
+    const bool with_lit = lit && lit->records && !disc;
+    if (with_lit && !(keys && range32 && !payload && index_base == 0))
+        return ctx_fail(ctx, SPLAT_ERR_INVALID, "project_launch: lit records are written by the frame's projector only");
+    const LitIO lio = with_lit ? *lit : LitIO{};
     stage_begin(ctx, SPLAT_STAGE_PROJECT);
     dim3 grid(div_up(work, 256)), block(256);
-#define SPLAT_PROJECT_LAUNCH(K, R, D, RANGE, BP)                                                                                \
-    hipLaunchKernelGGL((k_project<K, R, D>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, keys ? n_padded : n, index_base, \
-                       (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, RANGE, BP, dio)
+#define SPLAT_PROJECT_LAUNCH(K, R, D, L, RANGE, BP)                                                                                \
+    hipLaunchKernelGGL((k_project<K, R, D, L>), grid, block, 0, ctx->stream, u, src, pr_stride_vec4, n, keys ? n_padded : n, index_base, \
+                       (float4 *)projected, (uint32_t *)keys, (uint32_t *)payload, RANGE, BP, dio, lio)
+#define SPLAT_PROJECT_HIST_LAUNCH(KERNEL, D, L)                                                                               \
+    hipLaunchKernelGGL((KERNEL<D, L>), dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, \
+                       (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio)
     if (hist_out && keys && range32 && !payload && index_base == 0) {
-        if (disc && bp->skip_outside)
-            hipLaunchKernelGGL(k_project_hist_band<true>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n,
-                               n_padded, (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
-        else if (disc)
-            hipLaunchKernelGGL(k_project_hist<true>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
-                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
-        else if (bp->skip_outside)
-            hipLaunchKernelGGL(k_project_hist_band<false>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n,
-                               n_padded, (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
-        else
-            hipLaunchKernelGGL(k_project_hist<false>, dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,
-                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio);
+        if (disc && bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, true, false);
+        else if (disc) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist, true, false);
+        else if (bp->skip_outside && with_lit) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, false, true);
+        else if (bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, false, false);
+        else if (with_lit) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist, false, true);
+        else SPLAT_PROJECT_HIST_LAUNCH(k_project_hist, false, false);
     } else if (keys && range32) {
-        if (disc) SPLAT_PROJECT_LAUNCH(true, true, true, range32, *bp);
-        else SPLAT_PROJECT_LAUNCH(true, true, false, range32, *bp);
+        if (disc) SPLAT_PROJECT_LAUNCH(true, true, true, false, range32, *bp);
+        else if (with_lit) SPLAT_PROJECT_LAUNCH(true, true, false, true, range32, *bp);
+        else SPLAT_PROJECT_LAUNCH(true, true, false, false, range32, *bp);
     } else if (keys) {
-        if (disc) SPLAT_PROJECT_LAUNCH(true, false, true, nullptr, none);
-        else SPLAT_PROJECT_LAUNCH(true, false, false, nullptr, none);
+        if (disc) SPLAT_PROJECT_LAUNCH(true, false, true, false, nullptr, none);
+        else SPLAT_PROJECT_LAUNCH(true, false, false, false, nullptr, none);
     } else {
-        if (disc) SPLAT_PROJECT_LAUNCH(false, false, true, nullptr, none);
-        else SPLAT_PROJECT_LAUNCH(false, false, false, nullptr, none);
+        if (disc) SPLAT_PROJECT_LAUNCH(false, false, true, false, nullptr, none);
+        else SPLAT_PROJECT_LAUNCH(false, false, false, false, nullptr, none);
     }
 #undef SPLAT_PROJECT_LAUNCH
+#undef SPLAT_PROJECT_HIST_LAUNCH
     LAUNCH_CHECK(ctx, "k_project");
     stage_end(ctx, SPLAT_STAGE_PROJECT);
     return SPLAT_OK;

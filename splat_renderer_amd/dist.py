@@ -120,7 +120,7 @@ class HipStages:
         self.mode, self.early_out = mode, early_out
         self.pairs = 0
         self.overflows = 0
-        self.consumed = None  # optional torch int64[tiles]: per tile, list entries staged by the composite
+        self.consumed = None  # optional torch int64[tiles, 2]: per tile, list entries {staged, consumed} by the composite
         self.lit = None       # optional torch float32[n,4]: lit colour plane (set_lit); band_frame then ignores props/normals
         self.pos_plane = None  # with it: the (pos, radius) plane, for local_frame
         self.local_projected = None  # local_frame: the projector's ProjectedSplat records
@@ -201,7 +201,10 @@ class HipStages:
         """Tile rows [row0, row1) of the frame from THIS rank's copy of the splats (splat_render_frame with a band): no
         exchange; every rank projects all n splats itself.  Same sync-free rules as band_frame."""
         prelit = self.lit is not None
-        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1, _lib.RECORDS_PROJECTED, int(prelit),
+        # (isotropic: the projector leaves lit composite records, one gathered line per staged entry)
+        small = -(-self.width // self.tile) <= 256 and -(-self.height // self.tile) <= 256
+        cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1,
+                           _lib.RECORDS_LIT32 if (small and not self.disc) else _lib.RECORDS_PROJECTED, int(prelit),
                            _lib.FOOTPRINT_DISC if self.disc else _lib.FOOTPRINT_ISOTROPIC)
         if self.local_projected is None or self.local_projected.shape[0] < n:
             self.local_projected = self.torch.empty((max(n, 1), 8), dtype=self.torch.float32, device=f"cuda:{self.ordinal}")
@@ -229,10 +232,10 @@ class HipStages:
             self.pairs = int(t.value)
 
     def timing_consumed(self):
-        """List entries the composites of local_frame staged since timing was switched on."""
-        v = C.c_uint64()
-        check(self.lib.splat_timing_consumed(self.ctx, C.byref(v)), self.ctx)
-        return int(v.value)
+        """List entries (staged, consumed) by the composites of local_frame since timing was switched on."""
+        s, c = C.c_uint64(), C.c_uint64()
+        check(self.lib.splat_timing_consumed(self.ctx, C.byref(s), C.byref(c)), self.ctx)
+        return int(s.value), int(c.value)
 
     @property
     def kept(self):

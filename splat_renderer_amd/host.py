@@ -509,9 +509,12 @@ class ComputeShaderRenderer:
     :425-456) is out of scope (no canvas); the rgba8unorm output texture is exposed instead."""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", mode=_lib.MODE_FRONT_TO_BACK,
-                 earlyOut=True, footprint="isotropic"):
+                 earlyOut=True, footprint="isotropic", recordFormat=_lib.RECORDS_PROJECTED):
         self.device = device
         self.mode, self.earlyOut = mode, earlyOut
+        # recordFormat=RECORDS_LIT32: projectedBuffer in render() holds lit composite records (what a Renderer with
+        # records="lit" leaves in its projector's buffer); colours and normals are then not read
+        self.recordFormat = recordFormat
         # footprint="disc": projectedBuffer in render() is SplatProjector(footprint="disc").getDiscBuffer()
         self.footprint = _footprint(footprint)
         self.outputTexture = None
@@ -538,7 +541,8 @@ class ComputeShaderRenderer:
         if numTilesX != -(-width // tileSize):
             raise SplatError(-1, "numTilesX does not match ceil(width / tileSize)")
         self.ensureOutputTexture(width, height, wantFloat)
-        cfg = CompositeCfg(self.mode, int(self.earlyOut), tileSize, self.tileRows[0], self.tileRows[1], 0, 0, self.footprint)
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), tileSize, self.tileRows[0], self.tileRows[1], self.recordFormat, 0,
+                           self.footprint)
         check(d.lib.splat_composite(d.ctx, C.byref(cfg), splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
                                     projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr,
                                     width, height, self.outputTexture.ptr,
@@ -641,13 +645,22 @@ class Renderer:
     on the device.  (The reference's body — opaque depth-tested quads — is out of scope.)"""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", numPoints=0, tileSize=16,
-                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None, footprint="isotropic", writeProjected=True):
+                 mode=_lib.MODE_FRONT_TO_BACK, earlyOut=True, frameOrder=None, footprint="isotropic", writeProjected=True,
+                 records="lit"):
         # footprint="disc": the frame is drawn with SequentialRenderer's oriented discs (normalsBuffer is then
         # required in render() even with pre-lit planes: the projector reads it).  writeProjected=False (disc
         # frames only): the ProjectedSplat records, which a disc frame's composite does not read, are not written.
+        # records (isotropic frames): what the frame's projector leaves in projector.getProjectedBuffer() and the
+        # composite gathers per staged list entry — "lit" (default): the 32-byte lit composite records (centre,
+        # radius, depth | lit colour; SPLAT_RECORDS_LIT32), ONE line per entry; "projected": the reference's
+        # ProjectedSplat records, with colour (and normal) gathered from the property buffers as the reference does.
+        # Same image bit for bit.  Screens beyond 256 x 256 tiles always use "projected".
         self.footprint = _footprint(footprint)
         if not writeProjected and self.footprint != _lib.FOOTPRINT_DISC:
-            raise SplatError(-1, "writeProjected=False: the isotropic composite reads the ProjectedSplat records")
+            raise SplatError(-1, "writeProjected=False: the isotropic composite reads the records the projector writes")
+        if records not in ("lit", "projected"):
+            raise SplatError(-1, f"records must be 'lit' or 'projected', not {records!r}")
+        self.records = records if self.footprint == _lib.FOOTPRINT_ISOTROPIC else "projected"
         self.writeProjected = writeProjected
         self.device, self.numPoints, self.tileSize = device, numPoints, tileSize
         self.projector = SplatProjector(device, numPoints)
@@ -679,7 +692,11 @@ class Renderer:
         if wantFloat and self.outputFloat is None:
             self.outputFloat = d.createBuffer(width * height * 16)
         prelit = isinstance(propertyBuffer, PropertyPlanes) and propertyBuffer.prelit
-        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], 0, int(prelit), self.footprint)
+        ts = self.tileSize
+        lit = self.records == "lit" and -(-width // ts) <= 256 and -(-height // ts) <= 256
+        self.recordFormat = _lib.RECORDS_LIT32 if lit else _lib.RECORDS_PROJECTED  # of getProjectedBuffer() after this frame
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], self.recordFormat, int(prelit),
+                           self.footprint)
         tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height,
                 self.projector.getProjectedBuffer().ptr if self.writeProjected else None, self.output.ptr,
                 self.outputFloat.ptr if wantFloat else None)

@@ -35,7 +35,7 @@ def test_python_binding_covers_the_header():
     from splat_renderer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     lib = _lib.load()
-    assert lib.splat_abi_version() == 1
+    assert lib.splat_abi_version() == 2
 
 
 def test_no_cpu_fallback():

@@ -29,6 +29,46 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def lit_records(u, props, normals):
+    """The frame's 32-byte lit composite records (SPLAT_RECORDS_LIT32) from the oracle's stages: {centre x, y,
+    screen radius, depth} = the oracle's compact record, {lit r, g, b, opacity} = the reference's shading
+    (ComputeShaderRenderer.ts:143-145) in one IEEE operation per operator."""
+    k = np.float32(0.577350269189625764)
+    ndl = (normals[:, 0] * k + normals[:, 1] * k) + normals[:, 2] * k
+    kd = np.float32(0.85) + np.float32(0.15) * np.maximum(ndl, np.float32(0))
+    rec = np.empty((props.shape[0], 8), np.float32)
+    rec[:, :4] = O.project_compact(u, props)
+    rec[:, 4:7] = props[:, 4:7] * kd[:, None]
+    rec[:, 7] = props[:, 7]
+    return rec
+
+
+def tile_max(a, tile):
+    """Per-tile maximum of a per-pixel array (ragged edges included)."""
+    h, w = a.shape
+    nty, ntx = -(-h // tile), -(-w // tile)
+    p = np.zeros((nty * tile, ntx * tile), a.dtype)
+    p[:h, :w] = a
+    return p.reshape(nty, tile, ntx, tile).max(axis=(1, 3))
+
+
+def check_image_against_oracle(got, got8, want, want8, near=None):
+    """The composite's stated tolerance.  Every pixel within TOL_NO_EARLY_OUT / 1 LSB of the oracle — except, with
+    early-out on, the pixels the oracle flags as `near`: their alpha came within 2e-5 of the 0.99 threshold at some
+    entry, so a correct float evaluation may stop one entry earlier or later, which is worth at most
+    (1 - 0.99) * max colour (TOL_EARLY_OUT_BOUND, 3 LSB)."""
+    err = np.abs(got - want).max(axis=2)
+    err8 = np.abs(got8.astype(int) - want8.astype(int)).max(axis=2)
+    if near is None:
+        assert err.max() <= TOL_NO_EARLY_OUT
+        assert err8.max() <= 1
+        return
+    strict = near == 0
+    assert err[strict].max(initial=0) <= TOL_NO_EARLY_OUT, f"{(err[strict] > TOL_NO_EARLY_OUT).sum()} pixels off the threshold differ"
+    assert err8[strict].max(initial=0) <= 1
+    assert err.max() <= TOL_EARLY_OUT_BOUND and err8.max() <= 3
+
+
 @pytest.mark.parametrize("n,w,h,seed", [(1, 64, 64, 1), (7, 64, 48, 2), (1000, 256, 256, 3), (10000, 256, 256, 1234),
                                         (50000, 640, 360, 5)])
 def test_project_and_keys_bit_exact(device, n, w, h, seed):
@@ -235,25 +275,37 @@ def test_bin_empty(device):
 def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
     props, normals, u = make_case(n, w, h, seed, rs)
     ref = oracle_pipeline(props, normals, u, w, h)
-    want, want8, _ = O.composite(mode, early_out, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
-                                 ref["offsets"], w, h)
+    want, want8, _, stop, near = O.composite(mode, early_out, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
+                                             ref["offsets"], w, h, want_stops=True)
     g = run_gpu_pipeline(device, props, normals, u, n, w, h)
-    r = sr.ComputeShaderRenderer(device, None, "rgba8unorm", mode=mode, earlyOut=early_out)
     b = g["binner"]
-    r.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], g["proj"].getProjectedBuffer(),
-             b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, -(-w // 16), w, h, wantFloat=True)
-    got = r.readPixelsFloat()
-    got8 = r.readPixels()
-    err = np.abs(got - want)
-    if early_out:
-        assert err.max() <= TOL_EARLY_OUT_BOUND
-        assert (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
-        assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 3
-    else:
-        assert err.max() <= TOL_NO_EARLY_OUT
-        assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 1
-    assert (got8[..., 3] == 255).all()
-    r.destroy()
+    ntx, nty = -(-w // 16), -(-h // 16)
+    for fmt in (_lib.RECORDS_PROJECTED, _lib.RECORDS_LIT32):
+        r = sr.ComputeShaderRenderer(device, None, "rgba8unorm", mode=mode, earlyOut=early_out, recordFormat=fmt)
+        r.consumedBuffer = device.createBuffer(ntx * nty * 16)
+        r.consumedBuffer.zero()
+        records = g["proj"].getProjectedBuffer()
+        if fmt == _lib.RECORDS_LIT32:  # the frame's lit composite records, built here from the oracle's stages
+            records = device.createBufferFrom(lit_records(u, props, normals))
+        r.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], records,
+                 b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h, wantFloat=True)
+        got = r.readPixelsFloat()
+        got8 = r.readPixels()
+        check_image_against_oracle(got, got8, want, want8, near if early_out else None)
+        assert (got8[..., 3] == 255).all()
+        # per tile {entries staged, entries consumed}: consumed = the largest number of entries any pixel of the tile
+        # visits (SURVEY §8d P_used), exact wherever no pixel of the tile sits on the threshold
+        cons = r.consumedBuffer.read(np.uint64).reshape(nty * ntx, 2)
+        tile_stop, tile_near = tile_max(stop, 16), tile_max(near, 16) > 0
+        ok = ~tile_near.reshape(-1)
+        assert np.array_equal(cons[ok, 1], tile_stop.reshape(-1)[ok].astype(np.uint64))
+        batches = np.minimum(ref["counts"].astype(np.uint64), (cons[:, 1] + np.uint64(255)) // np.uint64(256) * np.uint64(256))
+        assert np.array_equal(cons[:, 0], batches)
+        if not early_out:
+            assert np.array_equal(cons[:, 1], ref["counts"].astype(np.uint64))
+        if fmt == _lib.RECORDS_LIT32:
+            records.destroy()
+        r.destroy()
     destroy_all(g)
 
 
@@ -320,27 +372,69 @@ def test_update_props(device):
         o.destroy()
 
 
+@pytest.mark.parametrize("records", ["lit", "projected"])
 @pytest.mark.parametrize("order", ["sortFirst", "tileFirst", "default"])
-def test_full_frame_C0(device, order):
+def test_full_frame_C0(device, order, records):
     """BASELINE configs[0]: 10k Gaussians @256x256, whole frame through splat_render_frame."""
     n, w, h = sr.scene.CONFIGS["C0"]
     props, normals, u = make_case(n, w, h)
     ref = oracle_pipeline(props, normals, u, w, h)
     assert ref["indices"].shape[0] == 137051  # SURVEY §8 dry-run statistic for this scene
-    want, want8, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"],
-                                 ref["counts"], ref["offsets"], w, h)
+    want, want8, _, _, near = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"],
+                                          ref["counts"], ref["offsets"], w, h, want_stops=True)
     pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
-    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order, records=records)
     r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
     if order == "sortFirst":  # (the tile-first order never sorts the splats globally)
         assert np.array_equal(r.sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"])
     assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32), ref["indices"])
-    err = np.abs(r.readPixelsFloat() - want)
-    assert err.max() <= TOL_EARLY_OUT_BOUND
-    assert (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
+    check_image_against_oracle(r.readPixelsFloat(), r.readPixels(), want, want8, near)
+    # what the frame's projector left behind: the reference's ProjectedSplat records, or the lit composite records
+    rec = bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8)
+    assert np.array_equal(rec, bits(lit_records(u, props, normals) if records == "lit" else ref["proj"]))
     r.destroy()
     pbuf.destroy()
     nbuf.destroy()
+
+
+@pytest.mark.parametrize("order", ["tileFirst", "sortFirst"])
+def test_lit_composite_records_give_the_same_frame_bit_for_bit(device, order):
+    """A frame whose projector writes the 32-byte lit composite records (SPLAT_RECORDS_LIT32: one gathered line per
+    staged list entry) against the same frame from the reference's ProjectedSplat records + colour + normal gathers:
+    identical lists and float image, bit for bit, from every property layout (interleaved records, two planes, planes
+    with a pre-lit colour plane), in both composite modes; the records themselves against the oracle."""
+    n, w, h = 60000, 500, 300
+    props, normals, u = make_case(n, w, h, 41, 1.5)
+    want_rec = bits(lit_records(u, props, normals))
+    pm = sr.SplatPropertyManager(device, n)
+    pm.setFromArrays(props)
+    nbuf = device.createBufferFrom(normals)
+    for mode in (sr.MODE_FRONT_TO_BACK, sr.MODE_REFERENCE_LITERAL):
+        a = sr.Renderer(device, None, "rgba8unorm", n, mode=mode, frameOrder=order, records="projected")
+        a.render(u, pm.getPropertyBuffer(), nbuf, None, w, h, wantFloat=True)
+        total = a.finish()
+        img = a.readPixelsFloat().view(np.uint32)
+        lists = a.binner.getTileIndicesBuffer().read(np.uint32, total)
+        for layout in ("interleaved", "planes", "prelit"):
+            b = sr.Renderer(device, None, "rgba8unorm", n, mode=mode, frameOrder=order)  # records="lit" is the default
+            pbuf = {"interleaved": pm.getPropertyBuffer, "planes": pm.getPropertyPlanes, "prelit": lambda: pm.getLitPlanes(nbuf)}[layout]()
+            for _ in range(2):  # the second frame is sync-free
+                b.render(u, pbuf, None if layout == "prelit" else nbuf, None, w, h, wantFloat=True)
+            assert b.finish() == total, layout
+            assert b.recordFormat == _lib.RECORDS_LIT32
+            assert np.array_equal(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), want_rec), layout
+            assert np.array_equal(b.binner.getTileIndicesBuffer().read(np.uint32, total), lists), layout
+            assert np.array_equal(b.readPixelsFloat().view(np.uint32), img), layout
+            b.destroy()
+        a.destroy()
+    # a band of tile rows (the exchange-free multi-GPU cut): records of splats that can reach the band, same pixels
+    full = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
+    full.render(u, pm.getPropertyBuffer(), nbuf, None, w, h)
+    band = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
+    band.render(u, pm.getPropertyBuffer(), nbuf, None, w, h, tileRows=(5, 11))
+    assert np.array_equal(band.readPixels()[80:176], full.readPixels()[80:176])
+    for o in (full, band, pm, nbuf):
+        o.destroy()
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -430,7 +524,7 @@ def test_full_size_C2_properties(device):
     n, w, h = sr.scene.CONFIGS["C2"]
     props, normals, u = make_case(n, w, h)
     pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
-    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
+    r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst", records="projected")
     r.render(u, pbuf, nbuf, None, w, h)
     order = r.sorter.getSortedIndicesBuffer().read(np.uint32, n)
     keys = r.sorter.getSortedKeysBuffer().read(np.uint32, n)
@@ -829,8 +923,8 @@ def test_property_planes_give_the_same_frame_as_interleaved_records(device):
     pm = sr.SplatPropertyManager(device, n)
     pm.setFromArrays(props)
     nbuf = device.createBufferFrom(normals)
-    a = sr.Renderer(device, None, "rgba8unorm", n)
-    b = sr.Renderer(device, None, "rgba8unorm", n)
+    a = sr.Renderer(device, None, "rgba8unorm", n, records="projected")
+    b = sr.Renderer(device, None, "rgba8unorm", n, records="projected")
     a.render(u, pm.getPropertyBuffer(), nbuf, None, w, h, wantFloat=True)
     planes = pm.getPropertyPlanes()
     assert np.array_equal(planes.posRadius.read(np.float32).reshape(n, 4), props[:, :4])

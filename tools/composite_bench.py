@@ -18,13 +18,13 @@ cam.setAspect(w / h)
 u = cam.uniforms(w, h)
 dev = sr.Device(0)
 pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
-r = sr.Renderer(dev, None, "rgba8unorm", n)
+r = sr.Renderer(dev, None, "rgba8unorm", n, records="projected")
 r.render(u, pbuf, nbuf, None, w, h)
 r.finish()
 b = r.binner
 counts = b.getTileCountsBuffer().read(np.uint32)
 print(f"{name}: P={b.getTotalIndices()} tiles={counts.size} list len mean {counts.mean():.0f} max {counts.max()} p99 {np.percentile(counts, 99):.0f}")
-cons = dev.createBuffer(counts.size * 8)  # one u64 per tile
+cons = dev.createBuffer(counts.size * 16)  # two u64 per tile: {staged, consumed}
 for mode in (0, 1):
     for eo in (True, False):
         csr = sr.ComputeShaderRenderer(dev, None, "rgba8unorm", mode=mode, earlyOut=eo)
@@ -42,7 +42,7 @@ for mode in (0, 1):
         cnt, tot = C.c_uint32(), C.c_double()
         _lib.check(dev.lib.splat_stage_time_stats(dev.ctx, _lib.STAGE_COMPOSITE, C.byref(cnt), C.byref(tot)), dev.ctx)
         dev.setTiming(False)
-        used = int(cons.read(np.uint64).sum()) // K
-        print(f"  mode {mode} early_out {eo}: {tot.value / cnt.value * 1e3:8.1f} us   entries staged {used}")
+        staged, used = (int(v) // K for v in cons.read(np.uint64).reshape(-1, 2).sum(axis=0))
+        print(f"  mode {mode} early_out {eo}: {tot.value / cnt.value * 1e3:8.1f} us   entries staged {staged} consumed {used}")
         csr.consumedBuffer = None
         csr.destroy()
