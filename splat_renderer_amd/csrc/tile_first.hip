@@ -379,19 +379,23 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
                 }
             }
             __syncthreads();
-            const uint32_t dcount = ts_wave_prefixes(sh.wave_hist, tid);
-            const uint32_t excl = ts_scan256(sh.wave_sums, dcount, tid);
-            sh.digit_base[tid] = excl;
+            // digit d's run starts at the exclusive scan of the digit totals and wave w's elements of digit d follow
+            // those of the waves before it: both folded into the wave's own table — ONE lookup per element (the kernel
+            // is bound by LDS operations: measured per phase, the passes are 60 % of a long tile's time once its loads
+            // are hidden)
+            const uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
+            const uint32_t excl = ts_scan256(sh.wave_sums, (c0 + c1) + (c2 + c3), tid);
+            sh.wave_hist[0][tid] = excl;
+            sh.wave_hist[1][tid] = excl + c0;
+            sh.wave_hist[2][tid] = excl + c0 + c1;
+            sh.wave_hist[3][tid] = excl + c0 + c1 + c2;
             __syncthreads();
 #pragma unroll
             for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
                 if (g < items) {
                     uint32_t pos[4];
 #pragma unroll
-                    for (uint32_t i = g; i < g + 4; ++i) {
-                        const uint32_t d = ((el[i].x - kmin) >> shift) & 255u;
-                        pos[i - g] = sh.digit_base[d] + sh.wave_hist[w][d] + rank[i];
-                    }
+                    for (uint32_t i = g; i < g + 4; ++i) pos[i - g] = sh.wave_hist[w][((el[i].x - kmin) >> shift) & 255u] + rank[i];
 #pragma unroll
                     for (uint32_t i = g; i < g + 4; ++i)
                         if (wbase + i * 64 < n) s_el[pos[i - g]] = el[i];

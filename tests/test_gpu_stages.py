@@ -501,6 +501,56 @@ def test_golden_fixtures(device, name):
     destroy_all(gpu)
 
 
+@pytest.mark.parametrize("name", ["tiny7", "small300", "ragged1000", "edges"])
+def test_tile_lists_equal_the_reference_own_code(device, name):
+    """ref_binsorted_*.npz: outputs of the reference's own binSorted loops (src/TileBinner.ts:426-495) run under Node by
+    tests/golden/make_ref_fixtures.py.  The HIP binner on the same records and sorted order — and, for the scene
+    fixtures, the whole frame in both orders of work from the scene's properties — must give exactly those lists."""
+    import os
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, f"ref_binsorted_{name}.npz"))
+    w, h, tile = (int(x) for x in g["dims"])
+    n = g["projected"].shape[0]
+    pbuf, sbuf = device.createBufferFrom(g["projected"]), device.createBufferFrom(g["sorted"])
+    b = sr.GPUTileBinner(device, tile)
+    b.binSplats(None, pbuf, sbuf, n, w, h, numSorted=g["sorted"].shape[0])
+    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), g["counts"])
+    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), g["offsets"])
+    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"])
+    for o in (b, pbuf, sbuf):
+        o.destroy()
+    if name == "edges":
+        return
+    f = np.load(os.path.join(here, name + ".npz"))
+    props, nbuf = device.createBufferFrom(f["props"]), device.createBufferFrom(f["normals"])
+    for order in ("tileFirst", "sortFirst"):
+        r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
+        r.render(f["uniforms"], props, nbuf, None, w, h)
+        assert r.finish() == g["indices"].shape[0]
+        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), g["counts"]), order
+        assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"]), order
+        r.destroy()
+    props.destroy()
+    nbuf.destroy()
+
+
+def test_scan_equals_the_reference_own_code(device):
+    """ref_scan.npz: the loop of PrefixSumScanner.scanCPU (src/PrefixSumScanner.ts:150-155) run under Node."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_scan.npz"))
+    sc = sr.PrefixSumScanner(device)
+    k = 0
+    while f"in{k}" in g.files:
+        a = g[f"in{k}"]
+        ib, ob = device.createBufferFrom(a), device.createBuffer(max(a.nbytes, 16))
+        sc.scan(None, ib, ob, a.shape[0])
+        assert np.array_equal(ob.read(np.uint32, a.shape[0]), g[f"out{k}"]), k
+        ib.destroy()
+        ob.destroy()
+        k += 1
+    assert k >= 5
+
+
 @pytest.mark.parametrize("tile", [8, 10, 24, 32])
 def test_bin_other_tile_sizes(device, tile):
     """Binning is tile-size generic (GPUTileBinner's ctor takes any tileSize); power-of-two sizes
@@ -749,6 +799,78 @@ def test_tile_first_sync_free_repeat_and_overflow(device):
     assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref_b["indices"].shape[0]), ref_b["indices"])
     for o in (r, sbuf, bbuf, nbuf):
         o.destroy()
+
+
+# SURVEY §8 dry-run statistics of the bench scenes (seed 1234): tile-splat pairs P
+FULL_SIZE_PAIRS = {"C1": 4632329, "C2": 11280103, "C3": 29483686}
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+def test_full_size_frame_lists_and_pixels(device, name):
+    """BASELINE.json's GPU configurations at FULL size (C1 1M @1080p, C2 5M @1080p, C3 10M @4K) through the frame the
+    bench times (tile-first order, lit composite records, sync-free after the first frame).  The oracle's composite
+    of a whole frame takes too long for a unit test, so:
+      * lists: counts sum to P, offsets are their exclusive scan, and on sampled tiles the list is EXACTLY
+        TileBinner.binSorted's — the splats whose clamped tile range covers the tile (ranges recomputed here from the
+        oracle's projector), in (depth key, index) order;
+      * pixels: two 32-row bands (screen centre, top edge) against the oracle's composite of those rows run on the
+        oracle's own records and colours with the GPU's lists (just shown equal to binSorted on the sampled tiles, and
+        equal to the sort-first order's lists over the whole frame), at the composite's stated tolerance."""
+    n, w, h = sr.scene.CONFIGS[name]
+    tile = 16
+    ntx, nty = -(-w // tile), -(-h // tile)
+    props, normals, u = make_case(n, w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    for _ in range(3):  # the third frame is sync-free
+        r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+    total = r.finish()
+    assert total == FULL_SIZE_PAIRS[name]
+    assert r.recordFormat == _lib.RECORDS_LIT32
+    counts = r.binner.getTileCountsBuffer().read(np.uint32)
+    offsets = r.binner.getTileOffsetsBuffer().read(np.uint32)
+    idx = r.binner.getTileIndicesBuffer().read(np.uint32, total)
+    assert int(counts.sum(dtype=np.uint64)) == total
+    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32))
+    # the frame's records against the oracle's projector (every splat)
+    proj = O.project(u, props)
+    rec = r.projector.getProjectedBuffer().read(np.float32).reshape(n, 8)
+    assert np.array_equal(bits(rec[:, :3]), bits(O.project_compact(u, props)[:, :3])) and np.array_equal(bits(rec[:, 3]), bits(proj[:, 4]))
+    # clamped tile ranges as TileBinner.binSorted forms them (src/TileBinner.ts:432-442), vectorised
+    mnx, mny = np.maximum(proj[:, 0], 0), np.maximum(proj[:, 1], 0)
+    mxx, mxy = np.minimum(proj[:, 2], np.float32(w)), np.minimum(proj[:, 3], np.float32(h))
+    on = (mnx < mxx) & (mny < mxy)
+    tx0, ty0 = np.floor(mnx / tile).astype(np.int64), np.floor(mny / tile).astype(np.int64)
+    tx1 = np.minimum(np.floor(mxx / tile), ntx - 1).astype(np.int64)
+    ty1 = np.minimum(np.floor(mxy / tile), nty - 1).astype(np.int64)
+    keys = proj[:, 4].view(np.uint32) ^ np.uint32(0x80000000)  # all depths are positive in this scene
+    rng = np.random.default_rng(7)
+    busiest = int(np.argmax(counts))
+    sample = set(int(t) for t in rng.integers(0, ntx * nty, 24)) | {busiest, 0, ntx * nty - 1, (nty // 2) * ntx + ntx // 2}
+    for t in sorted(sample):
+        tx, ty = t % ntx, t // ntx
+        members = np.nonzero(on & (tx0 <= tx) & (tx <= tx1) & (ty0 <= ty) & (ty <= ty1))[0]
+        members = members[np.lexsort((members, keys[members]))]
+        got = idx[offsets[t]:offsets[t] + counts[t]]
+        assert np.array_equal(got, members.astype(np.uint32)), f"tile {t} ({tx},{ty}): list differs from binSorted"
+    # the sort-first order (global depth sort, then bin) gives the same lists over the whole frame
+    a = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
+    a.render(u, pbuf, nbuf, None, w, h)
+    assert a.finish() == total
+    assert np.array_equal(a.binner.getTileIndicesBuffer().read(np.uint32, total), idx)
+    assert np.array_equal(a.readPixels(), r.readPixels())
+    a.destroy()
+    # pixel parity on two bands of 32 rows
+    img, img8 = r.readPixelsFloat(), r.readPixels()
+    assert (img8[..., 3] == 255).all()
+    mid = (nty // 2) * tile
+    for r0 in (mid - 16, 0):
+        want, want8, _, _, near = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, proj, idx, counts, offsets, w, h,
+                                              rows=(r0, r0 + 32), want_stops=True)
+        check_image_against_oracle(img[r0:r0 + 32], img8[r0:r0 + 32], want[r0:r0 + 32], want8[r0:r0 + 32], near[r0:r0 + 32])
+    r.destroy()
+    pbuf.destroy()
+    nbuf.destroy()
 
 
 def test_tile_first_full_size_C2(device):

@@ -174,7 +174,37 @@ def test_update_props_matches_twin():
     assert np.array_equal(bits(O.update_props(pos, cur)), bits(NP.update_props(pos, cur)))
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+REF_BINS = ("tiny7", "small300", "ragged1000", "edges")
+
+
+@pytest.mark.parametrize("name", REF_BINS)
+def test_oracle_tile_lists_equal_the_reference_own_code(name):
+    """ref_binsorted_*.npz hold what the REFERENCE's binSorted loops (src/TileBinner.ts:426-495, executed under Node
+    by tests/golden/make_ref_fixtures.py) produce for these records and sorted orders — including off-screen,
+    straddling, degenerate, NaN and infinite bounds and padding indices: both restatements must give exactly that."""
+    g = np.load(os.path.join(GOLDEN, f"ref_binsorted_{name}.npz"))
+    w, h, tile = (int(x) for x in g["dims"])
+    for impl in (O, NP):
+        counts, offsets, idx = impl.bin_sorted(g["projected"], g["sorted"], w, h, tile)
+        assert np.array_equal(counts, g["counts"]) and np.array_equal(offsets, g["offsets"]), impl.__name__
+        assert np.array_equal(idx, g["indices"]), impl.__name__
+    if name != "edges":  # the same inputs as the oracle-made fixture of that name: one more link between the two sets
+        f = np.load(os.path.join(GOLDEN, name + ".npz"))
+        assert np.array_equal(f["indices"], g["indices"]) and np.array_equal(bits(f["projected"]), bits(g["projected"]))
+
+
+def test_oracle_scan_equals_the_reference_own_code():
+    """ref_scan.npz: the loop of PrefixSumScanner.scanCPU (src/PrefixSumScanner.ts:150-155) executed under Node."""
+    g = np.load(os.path.join(GOLDEN, "ref_scan.npz"))
+    k = 0
+    while f"in{k}" in g.files:
+        assert np.array_equal(O.scan_exclusive(g[f"in{k}"])[0], g[f"out{k}"]), k
+        assert np.array_equal(NP.scan_exclusive(g[f"in{k}"])[0], g[f"out{k}"]), k
+        k += 1
+    assert k >= 5 and g["out0"].tolist() == [0, 1, 3, 6, 10]  # the reference's stated known answer
+
+
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("ref_")))
 def test_oracle_reproduces_golden(path):
     g = np.load(path)
     n, w, h, seed = (int(x) for x in g["dims"])
