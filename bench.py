@@ -164,6 +164,9 @@ def main():
                          "(north_star's cut); none = every rank projects all splats itself and renders its band (no collective); "
                          "auto = a timed trial of both, the faster is run.  Default allgather; the other cut's trial time is "
                          "reported as an extra key either way")
+    ap.add_argument("--collective", default="abi", choices=["abi", "torch"],
+                    help="multi-GPU: who issues the frame's all-gather — the C ABI's own RCCL communicator (splat_comm_init / "
+                         "splat_allgather_records, default; falls back to torch if RCCL cannot be bound) or torch.distributed")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -349,7 +352,18 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
     stages = dist.HipStages(torch, local_rank, per * world, width, height, tile, footprint=args.footprint)
     pt = torch.from_numpy(props).cuda()
     nt = torch.from_numpy(normals).cuda()
-    br = dist.BandRenderer(stages, n, width, height, rank, world, td.all_gather_into_tensor, tile)
+    gather, collective = td.all_gather_into_tensor, "torch.distributed.all_gather_into_tensor (RCCL)"
+    if args.collective == "abi":
+        def bcast(a):  # rank 0's unique id to every rank
+            t = torch.from_numpy(a).cuda()
+            td.broadcast(t, 0)
+            return t.cpu().numpy()
+        try:
+            gather = dist.AbiAllGather(torch, stages, rank, world, bcast)
+            collective = "splat_allgather_records (the C ABI's own RCCL communicator)"
+        except Exception as e:  # (RCCL could not be bound in this process: every rank fails alike, before any collective)
+            print(f"[rank {rank}] C-ABI communicator unavailable ({e!r}); torch.distributed issues the all-gather", file=sys.stderr)
+    br = dist.BandRenderer(stages, n, width, height, rank, world, gather, tile)
     if args.layout == "planes":  # as at N=1: shading applied once per property update, not per staged list entry
         stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
 
@@ -491,6 +505,7 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
                                    f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * stages.rec_floats * 4} B "
                                    f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
                                                            "all-gather run on a second stream under this frame's band work")),
+                   "collective": None if local is not None else collective,
                    "frame_loop_trial_ms": {k: round(v, 4) for k, v in loop_ms.items()},
                    "footprint": ("oriented disc (SequentialRenderer.ts:91-142)" if stages.disc else
                                  "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147)") +
@@ -508,6 +523,9 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
         pipe.destroy()
     if local is not None:
         local.stages.destroy()
+    if hasattr(gather, "destroy"):
+        torch.cuda.synchronize()
+        gather.destroy()
     stages.destroy()
     td.destroy_process_group()
     return result

@@ -141,7 +141,12 @@ int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches);
 /* Sort algorithm of this sorter: 0 = per-pass histogram + row scan + scatter (default, fastest on
  * MI355X; ranks keys with returning LDS atomics when the lane-order probe above passes, else with
  * ballots), 1 = onesweep with decoupled look-back (the reference's structure), 2 = as 0 but always
- * ballot ranking, -1 = library default. */
+ * ballot ranking, -1 = library default.
+ * NOTE on mode 0 and on the frame path's binning kernels: ranking with returning LDS atomics is stable only if the
+ * lanes of one instruction that collide on an address complete in ascending lane order.  That is what gfx950 does
+ * (splat_probe_lds_atomic_order: 0 mismatches in 8.4 M colliding instructions) but it is not an ISA guarantee: the
+ * library probes once per context and uses the ballot ranking if the probe ever fails, and the environment variable
+ * SPLAT_RANK=ballot forces the ballot ranking for every kernel of the process without asking the hardware. */
 int splat_sort_set_mode(splat_sorter *s, int mode);
 /* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
  * (the result is then invalid).  Synchronises. */
@@ -333,6 +338,23 @@ int splat_band_settle(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner
                       uint64_t *pairs_host);
 /* Number of splats the last splat_band_frame / splat_band_keys kept (synchronises). */
 int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host);
+
+/* ---- the multi-GPU frame's one exchange (no reference equivalent): RCCL over xGMI ------------------
+ * One process per GPU.  Rank 0 makes a unique id (splat_comm_unique_id) and hands its SPLAT_COMM_ID_BYTES to the
+ * other ranks by any channel the host has (a file, a socket, MPI, torch.distributed.broadcast); every rank then
+ * calls splat_comm_init (collective: returns when all `world` ranks have joined).  A frame is then
+ *     splat_project_slice_compact(my slice) -> splat_allgather_records(shard, gathered) -> splat_band_frame(gathered)
+ * all enqueued on the ctx stream: no host synchronisation in between.  librccl is bound at run time, on first use:
+ * when it cannot be loaded these return SPLAT_ERR_COMM (nothing falls back). */
+#define SPLAT_COMM_ID_BYTES 128
+int splat_comm_unique_id(void *id_out /* SPLAT_COMM_ID_BYTES host bytes */);
+int splat_comm_init(splat_ctx *ctx, int rank, int world, const void *unique_id, splat_comm **out);
+void splat_comm_destroy(splat_comm *comm);
+int splat_comm_rank(const splat_comm *comm, int *rank, int *world);
+/* All-gather of equal shards: rank r's bytes_per_rank bytes at `shard` land at gathered + r * bytes_per_rank on every
+ * rank (in place when shard == gathered + rank * bytes_per_rank).  Asynchronous on the ctx stream (any ctx of the
+ * communicator's device); timed as SPLAT_STAGE_EXCHANGE. */
+int splat_allgather_records(splat_ctx *ctx, splat_comm *comm, const void *shard, void *gathered, size_t bytes_per_rank);
 
 #ifdef __cplusplus
 }

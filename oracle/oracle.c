@@ -9,7 +9,7 @@
  * the order written (compile with -ffp-contract=off, no -ffast-math).  The HIP projector is
  * compiled the same way, which is what makes ProjectedSplat records / keys / sort order / tile
  * lists bit-exact between this file and the GPU.  The composite uses libm expf/sqrtf; the GPU
- * composite is compared to it within a stated tolerance (tests/test_composite_gpu.py).
+ * composite is compared to it within a stated tolerance (tests/test_gpu_stages.py).
  *
  * Citations are file:line under /root/reference.
  */

@@ -34,7 +34,7 @@ class CompositeCfg(C.Structure):
 
 
 # name -> (restype, argtypes); the single source of truth checked against include/splat.h by
-# tests/test_abi.py
+# tests/test_abi_cpu.py
 _vp, _u32, _sz, _i = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
 _pvp = C.POINTER(C.c_void_p)
 SIGNATURES = {
@@ -99,7 +99,13 @@ SIGNATURES = {
     "splat_band_settle": (_i, [_vp, _vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "splat_band_kept": (_i, [_vp, _vp, C.POINTER(_u32)]),
     "splat_band_keys": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "splat_comm_unique_id": (_i, [_vp]),
+    "splat_comm_init": (_i, [_vp, _i, _i, _vp, _pvp]),
+    "splat_comm_destroy": (None, [_vp]),
+    "splat_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "splat_allgather_records": (_i, [_vp, _vp, _vp, _vp, _sz]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -78,6 +78,7 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
                      bool iota_payload = false, uint32_t first_bits = 8);
 
 int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host);
+int ctx_resolve_rank_mode(splat_ctx *ctx); // sets ctx->lds_atomic_ordered (probe, or SPLAT_RANK=ballot)
 int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);
 
 struct splat_sorter {

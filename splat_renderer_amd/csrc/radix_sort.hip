@@ -527,11 +527,9 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
                               const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary,
                               bool iota_payload, bool force_ballot_rank, uint32_t cap_stride, uint32_t first_bits) {
     // ranking by returning LDS atomics needs the lane-order property: probed once per context
-    if (ctx->lds_atomic_ordered < 0) {
-        uint64_t bad = 1;
-        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+    {
+        int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
-        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
     }
     const bool rank_atomic = ctx->lds_atomic_ordered == 1 && !force_ballot_rank;
     const uint32_t parts = div_up(n, RS_PART_KEYS);
@@ -604,11 +602,9 @@ int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2
     if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
     if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
     if (first_bits < 1 || first_bits > 8) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: first_bits must be 1..8");
-    if (ctx->lds_atomic_ordered < 0) {
-        uint64_t bad = 1;
-        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+    {
+        int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
-        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
     }
     const uint32_t RSW_PART_KEYS = RSW_ITEMS_DEFAULT * RS_THREADS;
     const uint32_t parts = div_up(n, RSW_PART_KEYS);
@@ -729,6 +725,25 @@ int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host) {
     HIP_TRY(ctx, hipMemcpyAsync(&v, d, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *mismatches_host = v;
+    return SPLAT_OK;
+}
+
+// Which ranking the sort kernels of this context use.  Returning LDS atomics give a stable rank only if the lanes of
+// one instruction that collide on an address complete in ascending lane order — observed on gfx950, not an ISA
+// promise — so it is probed once per context (radix_probe_lds_atomic_order) and the ballot ranking, which assumes
+// nothing, is used if the probe ever fails.  SPLAT_RANK=ballot in the environment forces the ballot ranking without
+// asking the hardware.
+int ctx_resolve_rank_mode(splat_ctx *ctx) {
+    if (ctx->lds_atomic_ordered >= 0) return SPLAT_OK;
+    const char *e = getenv("SPLAT_RANK");
+    if (e && (e[0] == 'b' || e[0] == 'B')) {
+        ctx->lds_atomic_ordered = 0;
+        return SPLAT_OK;
+    }
+    uint64_t bad = 1;
+    int prc = radix_probe_lds_atomic_order(ctx, &bad);
+    if (prc != SPLAT_OK) return prc;
+    ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
     return SPLAT_OK;
 }
 

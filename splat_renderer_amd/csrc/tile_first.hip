@@ -456,11 +456,9 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
 
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
                      uint32_t *counts) {
-    if (ctx->lds_atomic_ordered < 0) {
-        uint64_t bad = 1;
-        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+    {
+        int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
-        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
     }
     const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
     if (ctx->lds_atomic_ordered == 1) {
@@ -485,11 +483,9 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
                       uint2 *out_val) {
     const uint32_t parts = div_up(n, TF_BLOCK);
     const uint32_t *totals = hist + (size_t)256 * parts;
-    if (ctx->lds_atomic_ordered < 0) {
-        uint64_t bad = 1;
-        int prc = radix_probe_lds_atomic_order(ctx, &bad);
+    {
+        int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
-        ctx->lds_atomic_ordered = (bad == 0) ? 1 : 0;
     }
     if (ctx->lds_atomic_ordered == 1)
         hipLaunchKernelGGL(k_tf_scatter<true>, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, hist,

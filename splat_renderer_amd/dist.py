@@ -250,8 +250,40 @@ class HipStages:
         self.lib.splat_ctx_destroy(self.ctx)
 
 
+class AbiAllGather:
+    """The frame's exchange through the C ABI's own RCCL communicator (splat_comm_init / splat_allgather_records) — the
+    path a host without torch.distributed uses (napi/index.js: Comm) — as an `all_gather(out, shard)` callable for
+    BandRenderer / FramePipeline.  The unique id travels from rank 0 by `broadcast_bytes(numpy uint8[128]) -> same
+    array on every rank` (torch.distributed.broadcast in bench.py; any channel will do).  The collective is enqueued
+    on the splat ctx bound to the torch stream that is current at the call (register every ctx that exchanges)."""
+
+    def __init__(self, torch, stages, rank, world, broadcast_bytes):
+        self.torch, self.lib, self.rank, self.world = torch, stages.lib, rank, world
+        ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+        if rank == 0:
+            check(self.lib.splat_comm_unique_id(ident.ctypes.data))
+        ident = np.ascontiguousarray(broadcast_bytes(ident), np.uint8)
+        c = C.c_void_p()
+        check(self.lib.splat_comm_init(stages.ctx, rank, world, ident.ctypes.data, C.byref(c)), stages.ctx)
+        self.comm = c
+        self.ctx_of_stream = {}
+        self.register(torch.cuda.current_stream(), stages.ctx)
+
+    def register(self, stream, ctx):
+        self.ctx_of_stream[int(stream.cuda_stream)] = ctx
+
+    def __call__(self, out, shard):
+        ctx = self.ctx_of_stream[int(self.torch.cuda.current_stream().cuda_stream)]
+        check(self.lib.splat_allgather_records(ctx, self.comm, shard.data_ptr(), out.data_ptr(), shard.numel() * shard.element_size()), ctx)
+
+    def destroy(self):
+        if self.comm:
+            self.lib.splat_comm_destroy(self.comm)
+            self.comm = None
+
+
 class BandRenderer:
-    """One rank of a multi-GPU frame.  `all_gather(out, shard)` is
+    """One rank of a multi-GPU frame.  `all_gather(out, shard)` is AbiAllGather (the C ABI's RCCL communicator) or
     torch.distributed.all_gather_into_tensor (RCCL on GPUs; gloo in the CPU tests)."""
 
     def __init__(self, stages, n, width, height, rank, world, all_gather, tile=TILE):
@@ -344,6 +376,8 @@ class FramePipeline:
         self.main = torch.cuda.current_stream()
         self.comm = torch.cuda.Stream()
         self.proj = ProjectStage(torch, device_ordinal, self.comm, getattr(br.stages, "disc", False))
+        if hasattr(br.all_gather, "register"):  # AbiAllGather: the exchange runs on the second stream's ctx
+            br.all_gather.register(self.comm, self.proj.ctx)
         st = br.stages
         self.shards = [br.shard, st.new_records(br.per, fill_nan=True)]
         self.gathered = [br.gathered, st.new_records(br.per * br.world) if br.world > 1 else self.shards[1]]

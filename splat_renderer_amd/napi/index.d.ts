@@ -10,9 +10,12 @@ export class Device {
 export interface CommandEncoder { finish(): null; }
 export class Camera {
   target: Float32Array; distance: number; azimuth: number; elevation: number; fov: number; aspect: number; near: number; far: number;
-  setAspect(aspect: number): void; rotate(deltaAzimuth: number, deltaElevation: number): void; zoom(deltaDistance: number): void;
+  setAspect(aspect: number): void; rotate(deltaAzimuth: number, deltaElevation: number): void; zoom(deltaDistance: number): void; pan(deltaX: number, deltaY: number): void;
   getViewProjectionMatrix(): Float32Array; getPosition(): Float32Array; uniforms(width: number, height: number, time?: number): Float32Array;
 }
+export class PointManager { constructor(device: Device, scene: Float32Array | { numPoints: number; seed?: number }); reinitialize(): void; swap(): void; getCurrentPositionBuffer(): Buffer; getNextPositionBuffer(): Buffer; getNumPoints(): number; destroy(): void; }
+export class Comm { static uniqueId(): Uint8Array; constructor(device: Device, rank: number, world: number, idBytes: Uint8Array); readonly rank: number; readonly world: number; allGather(shardBuffer: Buffer, gatheredBuffer: Buffer, bytesPerRank: number): void; destroy(): void; }
+export class BandRenderer { constructor(device: Device, comm: Comm | null, numPoints: number, width: number, height: number, tileSize?: number); row0: number; row1: number; render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer, normalsBuffer: Buffer): Buffer; settle(): number; pixelRows(): [number, number]; readPixels(): Uint8Array; destroy(): void; }
 export interface PropertyPlanes { posRadius: Buffer; colorOpacity: Buffer; isPlanes: true; prelit?: boolean; }
 export class SplatPropertyManager { constructor(device: Device, numSplats: number); updateFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): void; updatePlanesFromCurvature(enc: CommandEncoder | null, positionBuffer: Buffer, curvatureBuffer: Buffer): PropertyPlanes; setFromArrays(props: Float32Array): void; getPropertyBuffer(): Buffer; getPropertyPlanes(): PropertyPlanes; getLitPlanes(normalsBuffer: Buffer): PropertyPlanes; destroy(): void; }
 export type Footprint = "isotropic" | "disc" | 0 | 1;
@@ -25,6 +28,7 @@ export class PerTileSorter { constructor(device: Device, validate?: boolean); vi
 export class SequentialRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numSplats?: number, tileSize?: number, footprint?: Footprint); render(uniformData: Float32Array | Buffer, splatPropertyBuffer: Buffer, sortedIndexBuffer: Buffer, curvatureBuffer: Buffer, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
 export class ComputeShaderRenderer { constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean; footprint?: Footprint }); render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void; readPixels(): Uint8Array; destroy(): void; }
 export class TileRenderer extends ComputeShaderRenderer { bindTileData(projectedBuffer: Buffer, tileCountsBuffer: Buffer, tileOffsetsBuffer: Buffer): void; }
-export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number, options?: { footprint?: Footprint }); render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer | PropertyPlanes, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
+export class Renderer { constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number, options?: { footprint?: Footprint; records?: "lit" | "projected" }); recordFormat: number; render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer | PropertyPlanes, normalsBuffer: Buffer, scaleFactorsBuffer: Buffer | null, width: number, height: number): Buffer; readPixels(): Uint8Array; destroy(): void; }
 export const MODE_FRONT_TO_BACK: 0; export const MODE_REFERENCE_LITERAL: 1;
 export const FOOTPRINT_ISOTROPIC: 0; export const FOOTPRINT_DISC: 1;
+export const RECORDS_PROJECTED: 0; export const RECORDS_COMPACT: 1; export const RECORDS_LIT32: 3;

@@ -15,6 +15,7 @@ const U32_MAX = 0xffffffff;
 const MODE_FRONT_TO_BACK = 0;
 const FOOTPRINT_ISOTROPIC = 0, FOOTPRINT_DISC = 1;
 const MODE_REFERENCE_LITERAL = 1;
+const RECORDS_PROJECTED = 0, RECORDS_COMPACT = 1, RECORDS_LIT32 = 3;
 
 class Buffer_ {
   constructor(device, ptr, size, owned = true) {
@@ -264,6 +265,10 @@ class Renderer {
   constructor(device, context = null, presentationFormat = 'rgba8unorm', numPoints = 0, tileSize = 16, options = {}) {
     this.device = device; this.numPoints = numPoints; this.tileSize = tileSize;
     this.footprint = footprintCode(options.footprint); // 'disc': SequentialRenderer's oriented discs (normalsBuffer then always required)
+    // records 'lit' (default, isotropic frames): the projector leaves 32-byte lit composite records (centre, radius, depth |
+    // lit colour) in projector.getProjectedBuffer() and the composite gathers ONE line per staged list entry;
+    // 'projected': the reference's ProjectedSplat records, colour and normal gathered per entry.  Same image.
+    this.records = options.records === 'projected' || this.footprint === FOOTPRINT_DISC ? 'projected' : 'lit';
     this.projector = new SplatProjector(device, numPoints); this.sorter = new RadixSorter(device, numPoints); this.binner = new GPUTileBinner(device, tileSize);
     this.output = null; this.width = 0; this.height = 0;
   }
@@ -271,7 +276,9 @@ class Renderer {
     let u = uniformFloats(uniformData);
     if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
     if (this.width !== width || this.height !== height) { if (this.output) this.output.destroy(); this.output = this.device.createBuffer(width * height * 4); this.width = width; this.height = height; }
-    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, 0, propertyBuffer.prelit ? 1 : 0, this.footprint];
+    const small = Math.ceil(width / this.tileSize) <= 256 && Math.ceil(height / this.tileSize) <= 256;
+    this.recordFormat = this.records === 'lit' && small ? RECORDS_LIT32 : RECORDS_PROJECTED; // of getProjectedBuffer() after this frame
+    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, this.recordFormat, propertyBuffer.prelit ? 1 : 0, this.footprint];
     if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
       native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,
         normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
@@ -296,6 +303,20 @@ class Camera {
   setAspect(aspect) { this.aspect = aspect; this.isDirty = true; }
   rotate(dAz, dEl) { this.azimuth += dAz; this.elevation += dEl; const m = Math.PI / 2 - 0.01; this.elevation = Math.max(-m, Math.min(m, this.elevation)); this.isDirty = true; }
   zoom(d) { this.distance += d; this.distance = Math.max(0.5, Math.min(20.0, this.distance)); this.isDirty = true; }
+  pan(deltaX, deltaY) { // :61-83 with gl-matrix's vec3 semantics (every result stored in a Float32Array)
+    const f32 = (x, y, z) => new Float32Array([x, y, z]);
+    const normalize = (a) => { let len = a[0] * a[0] + a[1] * a[1] + a[2] * a[2]; if (len > 0) len = 1 / Math.sqrt(len); return f32(a[0] * len, a[1] * len, a[2] * len); };
+    const cross = (a, b) => f32(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+    const position = this.getCameraPosition();
+    const forward = normalize(f32(this.target[0] - position[0], this.target[1] - position[1], this.target[2] - position[2]));
+    const right = normalize(cross(forward, f32(0, 1, 0)));
+    const up = normalize(cross(right, forward));
+    let offset = f32(0, 0, 0);
+    offset = f32(offset[0] + right[0] * deltaX, offset[1] + right[1] * deltaX, offset[2] + right[2] * deltaX); // vec3.scaleAndAdd
+    offset = f32(offset[0] + up[0] * deltaY, offset[1] + up[1] * deltaY, offset[2] + up[2] * deltaY);
+    this.target = f32(this.target[0] + offset[0], this.target[1] + offset[1], this.target[2] + offset[2]);
+    this.isDirty = true;
+  }
   getCameraPosition() {
     const x = this.distance * Math.cos(this.elevation) * Math.sin(this.azimuth), y = this.distance * Math.sin(this.elevation), z = this.distance * Math.cos(this.elevation) * Math.cos(this.azimuth);
     return new Float32Array([this.target[0] + x, this.target[1] + y, this.target[2] + z]);
@@ -324,6 +345,72 @@ class Camera {
   uniforms(width, height, time = 0) { const u = new Float32Array(22); u.set(this.getViewProjectionMatrix(), 0); u.set(this.getPosition(), 16); u[19] = time; u[20] = width; u[21] = height; return u; }
 }
 
-module.exports = { native, Device, Buffer: Buffer_, Camera, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
+/** src/PointManager.ts:41,220-252 — ping-pong position buffers.  The reference seeds points with unseeded Math.random on an
+ * SDF surface (out of scope: upstream splat generation); here `scene` is a Float32Array of vec4 positions, or
+ * {numPoints, seed} for a deterministic uniform cloud in [-1,1]^3, and reinitialize() uploads it again. */
+class PointManager {
+  constructor(device, scene) {
+    this.device = device;
+    if (scene instanceof Float32Array) { this.positions = scene; } else {
+      const n = scene.numPoints; let state = (scene.seed === undefined ? 1 : scene.seed) >>> 0 || 1;
+      const next = () => { state ^= state << 13; state >>>= 0; state ^= state >>> 17; state ^= state << 5; state >>>= 0; return state / 4294967296; }; // xorshift32
+      this.positions = new Float32Array(n * 4);
+      for (let i = 0; i < n; i++) { this.positions[i * 4] = next() * 2 - 1; this.positions[i * 4 + 1] = next() * 2 - 1; this.positions[i * 4 + 2] = next() * 2 - 1; this.positions[i * 4 + 3] = 1; }
+    }
+    this.numPoints = this.positions.length / 4;
+    this.buffers = [device.createBuffer(this.numPoints * 16), device.createBuffer(this.numPoints * 16)];
+    this.current = 0;
+    this.reinitialize();
+  }
+  reinitialize() { this.buffers[this.current].write(this.positions); } // :220-231
+  getCurrentPositionBuffer() { return this.buffers[this.current]; }     // :233-235
+  getNextPositionBuffer() { return this.buffers[1 - this.current]; }    // :236-238
+  swap() { this.current = 1 - this.current; }                           // :240-242
+  getNumPoints() { return this.numPoints; }                             // :244-246
+  destroy() { this.buffers.forEach((b) => b.destroy()); }              // :248-252
+}
+
+/** The multi-GPU frame's exchange (no reference counterpart: the reference is single-device): one process per GPU, an
+ * RCCL communicator behind the C ABI.  Rank 0 calls Comm.uniqueId() and hands the 128 bytes to the other ranks by
+ * any channel (a file, a socket, an environment variable); every rank then constructs Comm with the same bytes. */
+class Comm {
+  static uniqueId() { return new Uint8Array(native.comm_unique_id()); }
+  constructor(device, rank, world, idBytes) { this.device = device; this.rank = rank; this.world = world; this.handle = native.comm_init(device.ctx, rank, world, idBytes); }
+  allGather(shardBuffer, gatheredBuffer, bytesPerRank) { native.allgather_records(this.device.ctx, this.handle, shardBuffer.ptr, gatheredBuffer.ptr, bytesPerRank); }
+  destroy() { if (this.handle) native.comm_destroy(this.handle); this.handle = null; }
+}
+
+/** One rank of north_star's multi-GPU frame (SURVEY §8e): project my 1/world of the splats into 16-byte exchange records
+ * {centre x, y, radius, depth}, ONE all-gather, then my band of tile rows binned, depth-sorted and composited from the
+ * gathered records.  render() returns the full-size image buffer of which this rank owns pixel rows pixelRows().
+ * Everything is enqueued on the device's stream: no host synchronisation inside a frame. */
+class BandRenderer {
+  constructor(device, comm, numPoints, width, height, tileSize = 16) {
+    this.device = device; this.comm = comm; this.numPoints = numPoints; this.width = width; this.height = height; this.tileSize = tileSize;
+    const world = comm ? comm.world : 1, rank = comm ? comm.rank : 0;
+    this.per = Math.ceil(numPoints / world); this.first = Math.min(rank * this.per, numPoints); this.count = Math.min(this.per, numPoints - this.first);
+    const nty = Math.ceil(height / tileSize);
+    this.row0 = Math.floor(nty * rank / world); this.row1 = Math.floor(nty * (rank + 1) / world);
+    this.sorter = new RadixSorter(device, this.per * world); this.binner = new GPUTileBinner(device, tileSize);
+    this.shard = device.createBuffer(this.per * 16); this.shard.write(new Float32Array(this.per * 4).fill(NaN)); // padding records bin nowhere
+    this.gathered = world > 1 ? device.createBuffer(this.per * world * 16) : this.shard;
+    this.output = device.createBuffer(width * height * 4); this.output.zero();
+  }
+  render(uniformData, propertyBuffer, normalsBuffer) {
+    const u = uniformFloats(uniformData), d = this.device, world = this.comm ? this.comm.world : 1;
+    native.project_slice_compact(d.ctx, u, propertyBuffer.ptr, 2, this.first, this.count, this.shard.ptr);
+    if (world > 1) this.comm.allGather(this.shard, this.gathered, this.per * 16);
+    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, this.row0, this.row1, RECORDS_COMPACT, 0, FOOTPRINT_ISOTROPIC];
+    native.band_frame(d.ctx, this.sorter.handle, this.binner.handle, cfg, propertyBuffer.ptr, normalsBuffer.ptr, this.gathered.ptr, this.per * world,
+      this.width, this.height, this.output.ptr, null);
+    return this.output;
+  }
+  settle() { return native.band_settle(this.device.ctx, this.sorter.handle, this.binner.handle); }
+  pixelRows() { return [this.row0 * this.tileSize, Math.min(this.row1 * this.tileSize, this.height)]; }
+  readPixels() { this.settle(); return this.output.read(new Uint8Array(this.width * this.height * 4)); }
+  destroy() { this.sorter.destroy(); this.binner.destroy(); this.shard.destroy(); if (this.gathered !== this.shard) this.gathered.destroy(); this.output.destroy(); }
+}
+
+module.exports = { native, Device, Buffer: Buffer_, Camera, PointManager, Comm, BandRenderer, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
   GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, SequentialRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL,
-  FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC };
+  FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC, RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_LIT32 };

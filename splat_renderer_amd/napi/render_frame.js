@@ -33,13 +33,39 @@ if (!threw) throw new Error('getter before binSplats did not throw');
   if (orderPath) fs.writeFileSync(orderPath, Buffer.from(sorter.getSortedIndicesBuffer().read(new Uint32Array(n)).buffer));
   if (countsPath) fs.writeFileSync(countsPath, Buffer.from(binner.getTileCountsBuffer().read(new Uint32Array(binner.numTiles)).buffer));
   if (indicesPath) fs.writeFileSync(indicesPath, Buffer.from(binner.getTileIndicesBuffer().read(new Uint32Array(binner.getTotalIndices())).buffer));
-  let framePairs = -1;
+  let framePairs = -1, recordFormat = -1, bandEqualsFrame = null, bandPairs = -1, pointManagerOk = null;
   if (framePath) { // the whole-frame facade (tile-first order inside), fed the native two-plane property layout, twice (2nd: sync-free)
     const whole = new sr.Renderer(device, null, 'rgba8unorm', n, 16);
     whole.binner.setFrameOrder('tileFirst');
     for (let k = 0; k < 2; k++) whole.render(uniforms, props.getPropertyPlanes(), normals, null, W, H);
-    fs.writeFileSync(framePath, Buffer.from(whole.readPixels().buffer));
+    const framePixels = whole.readPixels();
+    fs.writeFileSync(framePath, Buffer.from(framePixels.buffer));
     framePairs = whole.binner.getTotalIndices();
+    recordFormat = whole.recordFormat;
+    // north_star's multi-GPU frame from JS, on the one GPU there is: a one-rank RCCL communicator behind the C ABI,
+    // project my slice -> all-gather -> my band (= every tile row) from the gathered 16-byte records
+    const comm = new sr.Comm(device, 0, 1, sr.Comm.uniqueId());
+    const band = new sr.BandRenderer(device, comm, n, W, H, 16);
+    for (let k = 0; k < 2; k++) band.render(uniforms, props.getPropertyBuffer(), normals);
+    const bandPixels = band.readPixels();
+    bandPairs = band.settle();
+    bandEqualsFrame = bandPixels.length === framePixels.length && bandPixels.every((v, i) => v === framePixels[i]);
+    // a real exchange through the communicator: gather a buffer onto a second one
+    const probe = new Float32Array(1024).map((_, i) => i * 0.5), a = device.createBufferFrom(probe), b = device.createBuffer(4096);
+    comm.allGather(a, b, 4096);
+    const back = b.read(new Float32Array(1024));
+    if (!back.every((v, i) => v === probe[i])) throw new Error('Comm.allGather did not deliver the shard');
+    band.destroy(); comm.destroy(); a.destroy(); b.destroy();
+    // PointManager: ping-pong position buffers
+    const pos = new Float32Array(n * 4); for (let i = 0; i < n; i++) { pos[i * 4] = i; pos[i * 4 + 3] = 1; }
+    const pm = new sr.PointManager(device, pos);
+    const cur = pm.getCurrentPositionBuffer(), nxt = pm.getNextPositionBuffer();
+    pm.swap();
+    const seeded = new sr.PointManager(device, { numPoints: 100, seed: 7 });
+    const sp = seeded.getCurrentPositionBuffer().read(new Float32Array(400));
+    pointManagerOk = pm.getNumPoints() === n && pm.getCurrentPositionBuffer() === nxt && pm.getNextPositionBuffer() === cur &&
+      cur.read(new Float32Array(n * 4)).every((v, i) => v === pos[i]) && sp.every((v, i) => (i % 4 === 3 ? v === 1 : v >= -1 && v <= 1));
+    pm.destroy(); seeded.destroy();
   }
   let seqPairs = -1, discFramePairs = -1;
   if (seqPath) { // SequentialRenderer with its own footprint (the oriented disc), fed RadixSorter's near-to-far order
@@ -55,5 +81,6 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     fs.writeFileSync(discFramePath, Buffer.from(whole.readPixels().buffer));
     discFramePairs = whole.binner.getTotalIndices();
   }
-  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, seqPairs, discFramePairs, uniforms: Array.from(uniforms) }));
+  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, seqPairs, discFramePairs, recordFormat, bandEqualsFrame, bandPairs,
+    pointManagerOk, uniforms: Array.from(uniforms) }));
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -297,6 +297,49 @@ FN(render_frame_planes) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), pos
     return check(env, x, splat_render_frame_planes(x, s, b, &cfg, u, pr, co, nrm, n, w, h, proj, o8, of), mk_undefined(env));
 }
 
+/* ---- multi-GPU band path (include/splat.h: "multi-GPU band path", "the multi-GPU frame's one exchange") ---- */
+FN(project_slice_compact) { /* (ctx, Float32Array(22), posRadius, strideVec4, first, count, records16) */
+    ARGS(7); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
+    void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3), first = (uint32_t)arg_number(&c, 4), count = (uint32_t)arg_number(&c, 5);
+    void *rec = arg_dptr(&c, 6); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_project_slice_compact(x, u, pr, st, first, count, rec), mk_undefined(env));
+}
+FN(band_frame) { /* (ctx, sorter, binner, cfg[8], props, normals|null, records, nRecords, W, H, out8|null, outF|null) */
+    ARGS(12); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); splat_binner *b = arg_external(&c, 2);
+    splat_composite_cfg cfg; fill_cfg(&c, 3, &cfg);
+    void *props = arg_dptr(&c, 4), *nrm = arg_dptr(&c, 5), *rec = arg_dptr(&c, 6);
+    uint32_t n = (uint32_t)arg_number(&c, 7), w = (uint32_t)arg_number(&c, 8), h = (uint32_t)arg_number(&c, 9);
+    void *o8 = arg_dptr(&c, 10), *of = arg_dptr(&c, 11); BAIL;
+    return check(env, x, splat_band_frame(x, s, b, &cfg, props, nrm, rec, n, w, h, o8, of, NULL), mk_undefined(env));
+}
+FN(band_settle) { /* (ctx, sorter, binner) -> pairs of the last band frame (waits for it; throws if it overflowed: render it again) */
+    ARGS(3); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); splat_binner *b = arg_external(&c, 2); BAIL;
+    uint32_t kept = 0; uint64_t pairs = 0;
+    int rc = splat_band_settle(x, s, b, &kept, &pairs);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_number(env, (double)pairs) : NULL);
+}
+FN(comm_unique_id) { /* () -> ArrayBuffer(128): rank 0 makes it, every rank passes the same bytes to comm_init */
+    (void)info;
+    void *data = NULL; napi_value ab;
+    if (napi_create_arraybuffer(env, SPLAT_COMM_ID_BYTES, &data, &ab) != napi_ok) return NULL;
+    return check(env, NULL, splat_comm_unique_id(data), ab);
+}
+FN(comm_init) { /* (ctx, rank, world, idBytes) -> comm */
+    ARGS(4); splat_ctx *x = arg_external(&c, 0); int rank = (int)arg_number(&c, 1), world = (int)arg_number(&c, 2);
+    size_t nb = 0; void *id = arg_hostbuf(&c, 3, &nb); BAIL;
+    if (nb < SPLAT_COMM_ID_BYTES) { napi_throw_range_error(env, NULL, "the communicator id is 128 bytes"); return NULL; }
+    splat_comm *comm = NULL;
+    int rc = splat_comm_init(x, rank, world, id, &comm);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_external(env, comm) : NULL);
+}
+FN(comm_destroy) { ARGS(1); splat_comm_destroy((splat_comm *)arg_external(&c, 0)); return mk_undefined(env); }
+FN(allgather_records) { /* (ctx, comm, shard, gathered, bytesPerRank) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); splat_comm *comm = arg_external(&c, 1);
+    void *shard = arg_dptr(&c, 2), *all = arg_dptr(&c, 3); size_t nb = (size_t)arg_number(&c, 4); BAIL;
+    return check(env, x, splat_allgather_records(x, comm, shard, all, nb), mk_undefined(env));
+}
+
 static napi_value init(napi_env env, napi_value exports) {
 #define EXPORT(name) { #name, NULL, name, NULL, NULL, NULL, napi_enumerable, NULL }
     napi_property_descriptor d[] = {
@@ -306,6 +349,8 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
+        EXPORT(project_slice_compact), EXPORT(band_frame), EXPORT(band_settle), EXPORT(comm_unique_id), EXPORT(comm_init), EXPORT(comm_destroy),
+        EXPORT(allgather_records),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

@@ -1183,3 +1183,61 @@ def test_prelit_colour_plane_gives_the_same_image_bit_for_bit(device):
     assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
     for o in (a, b, pm, nbuf, nbuf2):
         o.destroy()
+
+
+def test_abi_communicator_one_rank_self_test(device):
+    """splat_comm_* / splat_allgather_records on RCCL (the multi-GPU frame's one exchange behind the C ABI): a
+    one-rank communicator on this device gathers a shard onto itself, out of place and in place, timed as the
+    EXCHANGE stage; bad arguments come back as errors.  (More ranks need more GPUs: the driver's scaling run.)"""
+    lib, ctx = device.lib, device.ctx
+    ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+    _lib.check(lib.splat_comm_unique_id(ident.ctypes.data))
+    assert ident.any()
+    comm = C.c_void_p()
+    assert lib.splat_comm_init(ctx, 1, 1, ident.ctypes.data, C.byref(comm)) == -1  # rank out of range
+    _lib.check(lib.splat_comm_init(ctx, 0, 1, ident.ctypes.data, C.byref(comm)), ctx)
+    rank, world = C.c_int(-1), C.c_int(-1)
+    _lib.check(lib.splat_comm_rank(comm, C.byref(rank), C.byref(world)))
+    assert (rank.value, world.value) == (0, 1)
+    rec = np.random.default_rng(3).standard_normal((5000, 4)).astype(np.float32)
+    shard, out = device.createBufferFrom(rec), device.createBuffer(rec.nbytes)
+    out.zero()
+    device.setTiming(True)
+    _lib.check(lib.splat_allgather_records(ctx, comm, shard.ptr, out.ptr, rec.nbytes), ctx)
+    assert np.array_equal(out.read(np.float32).reshape(rec.shape), rec)
+    assert device.stageTimeMs(_lib.STAGE_EXCHANGE) >= 0.0
+    device.setTiming(False)
+    _lib.check(lib.splat_allgather_records(ctx, comm, shard.ptr, shard.ptr, rec.nbytes), ctx)  # in place
+    assert np.array_equal(shard.read(np.float32).reshape(rec.shape), rec)
+    assert lib.splat_allgather_records(ctx, None, shard.ptr, out.ptr, rec.nbytes) == -1
+    lib.splat_comm_destroy(comm)
+    shard.destroy()
+    out.destroy()
+
+
+def test_abi_all_gather_serves_the_band_renderer(device):
+    """dist.AbiAllGather — the C ABI's RCCL communicator as BandRenderer's all_gather — on a one-rank communicator: the
+    collective runs on the ctx of the current torch stream (main stream and a second, registered stream, as
+    FramePipeline uses it) and delivers the shard."""
+    import torch
+    from splat_renderer_amd import dist
+    n, w, h = 20000, 320, 200
+    stages = dist.HipStages(torch, 0, n, w, h)
+    gather = dist.AbiAllGather(torch, stages, 0, 1, lambda ident: ident)
+    shard = torch.randn((n, 4), device="cuda")
+    out = torch.zeros_like(shard)
+    gather(out, shard)
+    torch.cuda.synchronize()
+    assert torch.equal(out, shard)
+    side = torch.cuda.Stream()
+    proj = dist.ProjectStage(torch, 0, side)
+    gather.register(side, proj.ctx)
+    out.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        gather(out, shard)
+    side.synchronize()
+    assert torch.equal(out, shard)
+    proj.destroy()
+    gather.destroy()
+    stages.destroy()

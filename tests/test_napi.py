@@ -40,8 +40,13 @@ def test_addon_loads_and_exports():
     d = json.loads(r.stdout)
     assert d["abi"] == 2
     for name in ("ctx_create", "project", "extract_keys", "sort_run", "scan_u32", "bin_run", "composite", "render_frame",
-                 "update_props", "buf_upload", "buf_download"):
+                 "update_props", "buf_upload", "buf_download", "project_slice_compact", "band_frame", "band_settle",
+                 "comm_unique_id", "comm_init", "comm_destroy", "allgather_records"):
         assert name in d["names"]
+    r = node("const sr=require('./index.js');console.log(JSON.stringify(Object.keys(sr)))")
+    assert r.returncode == 0, r.stderr
+    for cls in ("Camera", "PointManager", "SplatPropertyManager", "Renderer", "Comm", "BandRenderer"):  # north_star's API surface
+        assert cls in json.loads(r.stdout)
 
 
 def test_js_camera_matches_oracle():
@@ -53,6 +58,26 @@ def test_js_camera_matches_oracle():
     vp, eye = O.camera(aspect=16 / 9)
     assert np.array_equal(u[:16].view(np.uint32), vp.view(np.uint32)) and np.array_equal(u[16:19], eye)
     assert u[20] == 1920 and u[21] == 1080
+
+
+def test_js_camera_pan_rotate_zoom_match_python_camera():
+    """Camera.pan (src/Camera.ts:61-83) and the other verbs from JS against splat_renderer_amd/camera.py, bit for bit:
+    both restate gl-matrix's Float32Array-store semantics."""
+    ensure_built()
+    import splat_renderer_amd as sr
+    steps = [("pan", 0.3, -0.2), ("rotate", 0.7, -0.4), ("pan", -1.25, 0.5), ("zoom", 1.5, 0), ("pan", 0.01, 2.0), ("rotate", 2.0, 1.9)]
+    js = "const sr=require('./index.js');const c=new sr.Camera();c.setAspect(1.5);const out=[];" + "".join(
+        f"c.{v}({a}{'' if v == 'zoom' else ',' + str(b)});out.push(Array.from(c.uniforms(300,200)).concat(Array.from(c.target)));" for v, a, b in steps) + \
+        "console.log(JSON.stringify(out))"
+    r = node(js)
+    assert r.returncode == 0, r.stderr
+    got = np.array(json.loads(r.stdout), np.float32)
+    cam = sr.Camera()
+    cam.setAspect(1.5)
+    for k, (v, a, b) in enumerate(steps):
+        getattr(cam, v)(*((a,) if v == "zoom" else (a, b)))
+        want = np.concatenate([cam.uniforms(300, 200), cam.target]).astype(np.float32)
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (k, v)
 
 
 def test_js_no_cpu_fallback():
@@ -93,6 +118,10 @@ def test_js_frame_matches_oracle(tmp_path):
     assert info["framePairs"] == ref["indices"].shape[0]
     frame8 = np.fromfile(tmp_path / "frame.rgba8", np.uint8).reshape(h, w, 4)
     assert np.array_equal(frame8, got8)  # same lists, same composite: same bytes as the staged path
+    assert info["recordFormat"] == 3  # the facade's projector wrote lit composite records (SPLAT_RECORDS_LIT32)
+    # north_star's multi-GPU frame from JS (one-rank RCCL communicator behind the C ABI) and PointManager
+    assert info["bandEqualsFrame"] is True and info["bandPairs"] == ref["indices"].shape[0]
+    assert info["pointManagerOk"] is True
     # SequentialRenderer from JS draws its own footprint (the oriented disc): against the oracle's per-pixel restatement
     # (early-out on, as the class renders) and, off the rims, against the software rasteriser of SequentialRenderer.ts
     dproj, discs = O.project_disc(u, props, normals)
