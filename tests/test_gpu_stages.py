@@ -1241,3 +1241,47 @@ def test_abi_all_gather_serves_the_band_renderer(device):
     proj.destroy()
     gather.destroy()
     stages.destroy()
+
+
+def test_headless_frame_loop_orbits_the_camera(device, tmp_path):
+    """the frame loop of src/main.ts:110-193 without a browser.  Four frames of an orbit
+    (Camera.rotate, then a pan, a zoom and a drag through OrbitCameraController), enqueued back to back — the second
+    onwards sync-free, each with a different camera — and every frame's lists and pixels against the oracle run with
+    that frame's uniforms; the frames written as PNG read back identical."""
+    n, w, h = 12000, 320, 208
+    props, normals, _ = make_case(n, w, h, 61, 1.5)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    loop = sr.FrameLoop(device, n, w, h)
+    ctl = sr.OrbitCameraController(loop.camera)
+    moves = [lambda: loop.camera.rotate(2 * np.pi / 4, 0.0), lambda: loop.camera.pan(0.2, -0.1),
+             lambda: ctl.onWheel(sr.MouseEvent(deltaY=400.0)),
+             lambda: (ctl.onMouseDown(sr.MouseEvent(10, 10, button=0)), ctl.onMouseMove(sr.MouseEvent(70, 40)), ctl.onMouseUp())]
+    shots = []
+    for k, move in enumerate(moves):
+        u = loop.camera.uniforms(w, h, time=k / 60.0).copy()
+        loop.render(pbuf, nbuf)
+        shots.append((u, loop.readPixels().copy(), loop.renderer.binner.getTotalIndices(),
+                      loop.renderer.binner.getTileIndicesBuffer().read(np.uint32, loop.renderer.binner.getTotalIndices())))
+        move()
+    assert len({s[1].tobytes() for s in shots}) == len(shots)  # the camera really moved
+    for k, (u, got8, total, idx) in enumerate(shots):
+        ref = oracle_pipeline(props, normals, u, w, h)
+        assert total == ref["indices"].shape[0] and np.array_equal(idx, ref["indices"]), k
+        _, want8, _, _, near = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
+                                           ref["offsets"], w, h, want_stops=True)
+        d8 = np.abs(got8.astype(int) - want8.astype(int)).max(axis=2)
+        assert d8[near == 0].max() <= 1 and d8.max() <= 3, k
+        path = tmp_path / f"frame_{k}.png"
+        sr.write_png(path, got8)
+        assert np.array_equal(sr.read_png(path), got8)
+    # the same frames without reading anything back in between (all sync-free): same last image
+    cam2 = sr.Camera()
+    loop2 = sr.FrameLoop(device, n, w, h, camera=cam2)
+    ctl2 = sr.OrbitCameraController(cam2)
+    for k in range(4):
+        loop2.render(pbuf, nbuf)
+        if k < 3:
+            [lambda: cam2.rotate(2 * np.pi / 4, 0.0), lambda: cam2.pan(0.2, -0.1), lambda: ctl2.onWheel(sr.MouseEvent(deltaY=400.0))][k]()
+    assert np.array_equal(loop2.readPixels(), shots[3][1])
+    for o in (loop, loop2, pbuf, nbuf):
+        o.destroy()
