@@ -339,6 +339,37 @@ int splat_band_settle(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner
 /* Number of splats the last splat_band_frame / splat_band_keys kept (synchronises). */
 int splat_band_kept(splat_ctx *ctx, splat_sorter *sorter, uint32_t *n_kept_host);
 
+/* ---- SDF splat generation: the producer of the positions and normals this path consumes ----------
+ * src/sdf/CodeGenerator.ts:97-225,276-353 (primitive / operation library, sceneSDF), src/GradientSampler.ts,
+ * src/shaders/update-positions.wgsl:22-50, src/CurvatureSampler.ts:84-141.  The reference generates one WGSL function
+ * per scene graph; here the graph is DATA: a postfix program (children first, then their operation — the order
+ * CodeGenerator's traverse() emits) of at most SPLAT_SDF_MAX_INSTR instructions, handed over with every call (host
+ * memory; it travels in the kernel arguments).  A value is vec4(distance, gradient).  Bit-exact against oracle/oracle.c. */
+#define SPLAT_SDF_SPHERE 0u        /* a = {center.xyz, radius}                    sdgSphere  :100-106 */
+#define SPLAT_SDF_BOX 1u           /* a = {center.xyz, half size.xyz}             sdgBox     :109-133 */
+#define SPLAT_SDF_TORUS 2u         /* a = {center.xyz, major radius, minor radius} sdgTorus   :136-157 */
+#define SPLAT_SDF_CAPSULE 3u       /* a = {center.xyz, height, radius}            sdgCapsule :160-176 */
+#define SPLAT_SDF_UNION 16u        /* pops b, a; pushes the nearer               opUnion        :181-187 */
+#define SPLAT_SDF_INTERSECTION 17u /*                                             opIntersection :190-196 */
+#define SPLAT_SDF_SUBTRACTION 18u  /*                                             opSubtraction  :199-202 */
+#define SPLAT_SDF_SMOOTH_UNION 19u /* a = {k}                                     opSmoothUnion  :206-224 */
+#define SPLAT_SDF_MAX_INSTR 32u
+typedef struct splat_sdf_instr {
+    uint32_t op;
+    float a[7];
+} splat_sdf_instr;
+/* GradientSampler.evaluateGradients: gradients[i] = sceneSDF(positions[i].xyz) (vec4 in, vec4 out). */
+int splat_sdf_gradients(splat_ctx *ctx, const splat_sdf_instr *program, uint32_t n_instr, const void *positions, uint32_t n,
+                        void *gradients);
+/* PositionUpdater.updatePositions: next = vec4(pos - normalize(gradient) * distance, 0) (pos where the gradient vanishes). */
+int splat_sdf_update_positions(splat_ctx *ctx, const void *positions, const void *gradients, uint32_t n, void *next_positions);
+/* CurvatureSampler.computeScaleFactors: one f32 per point from the normals at six offsets of 0.02. */
+int splat_sdf_scale_factors(splat_ctx *ctx, const splat_sdf_instr *program, uint32_t n_instr, const void *positions, uint32_t n,
+                            void *scale_factors);
+/* vec4(normalize(gradient), scale factor): the "curvatureData" layout splat_update_props reads
+ * (src/SplatPropertyManager.ts:70-72; the reference's samplers write the two halves to separate buffers). */
+int splat_sdf_curvature(splat_ctx *ctx, const void *gradients, const void *scale_factors, uint32_t n, void *curvature);
+
 /* ---- the multi-GPU frame's one exchange (no reference equivalent): RCCL over xGMI ------------------
  * One process per GPU.  Rank 0 makes a unique id (splat_comm_unique_id) and hands its SPLAT_COMM_ID_BYTES to the
  * other ranks by any channel the host has (a file, a socket, MPI, torch.distributed.broadcast); every rank then

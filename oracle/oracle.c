@@ -796,3 +796,150 @@ int orc_frame(int mode, int early_out, const float uniforms[22], const float *pr
     free(proj); free(keys); free(pay); free(counts); free(offsets); free(indices);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* SDF splat generation (src/sdf/CodeGenerator.ts, GradientSampler.ts, update-positions.wgsl,   */
+/* CurvatureSampler.ts) — SURVEY §8f row 4.  WGSL built-ins spelled out: length(v) =            */
+/* sqrt((x*x + y*y) + z*z), normalize(v) = v / length(v), mix(a,b,t) = a*(1-t) + b*t,           */
+/* smoothstep(lo,hi,x) = t*t*(3 - 2t), t = clamp((x-lo)/(hi-lo), 0, 1), sign(0) = 0.            */
+/* ------------------------------------------------------------------------------------------ */
+static float sdf_len3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+static float sdf_len2(float x, float y) { return sqrtf(x * x + y * y); }
+static float sdf_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+static void sdg_sphere(const float p[3], float r, float o[4]) { /* CodeGenerator.ts:100-106 */
+    float d = sdf_len3(p[0], p[1], p[2]);
+    float m = fmaxf(d, 0.0001f);
+    o[0] = d - r; o[1] = p[0] / m; o[2] = p[1] / m; o[3] = p[2] / m;
+}
+
+static void sdg_box(const float p[3], const float b[3], float o[4]) { /* :109-133 */
+    float qx = fabsf(p[0]) - b[0], qy = fabsf(p[1]) - b[1], qz = fabsf(p[2]) - b[2];
+    float wx = fmaxf(qx, 0.0f), wy = fmaxf(qy, 0.0f), wz = fmaxf(qz, 0.0f);
+    float g = fmaxf(qx, fmaxf(qy, qz));
+    float sx = sdf_sign(p[0]), sy = sdf_sign(p[1]), sz = sdf_sign(p[2]);
+    o[0] = sdf_len3(wx, wy, wz) + fminf(g, 0.0f);
+    if (g > 0.0f) {
+        float l = sdf_len3(wx, wy, wz);
+        o[1] = sx * (wx / l); o[2] = sy * (wy / l); o[3] = sz * (wz / l);
+    } else if (qx > qy && qx > qz) {
+        o[1] = sx; o[2] = 0.0f; o[3] = 0.0f;
+    } else if (qy > qz) {
+        o[1] = 0.0f; o[2] = sy; o[3] = 0.0f;
+    } else {
+        o[1] = 0.0f; o[2] = 0.0f; o[3] = sz;
+    }
+}
+
+static void sdg_torus(const float p[3], float major, float minor, float o[4]) { /* :136-157 */
+    float lxz = sdf_len2(p[0], p[2]);
+    float dx = lxz - major, dy = p[1];
+    float ldir = sdf_len2(dx, dy);
+    o[0] = ldir - minor; o[1] = 0.0f; o[2] = 1.0f; o[3] = 0.0f;
+    if (lxz > 0.0001f && ldir > 0.0001f) {
+        float ux = p[0] / lxz, uz = p[2] / lxz, ddx = dx / ldir, ddy = dy / ldir;
+        o[1] = ux * ddx; o[2] = ddy; o[3] = uz * ddx;
+    }
+}
+
+static void sdg_capsule(const float p[3], float h, float r, float o[4]) { /* :160-176 */
+    float half = h * 0.5f;
+    float cy = fminf(fmaxf(p[1], -half), half);
+    float qx = p[0], qy = p[1] - cy, qz = p[2];
+    float d = sdf_len3(qx, qy, qz);
+    o[0] = d - r; o[1] = 0.0f; o[2] = sdf_sign(p[1]); o[3] = 0.0f;
+    if (d > 0.0001f) { o[1] = qx / d; o[2] = qy / d; o[3] = qz / d; }
+}
+
+static void op_smooth_union(const float a[4], const float b[4], float k, float o[4]) { /* :206-224 */
+    float k4 = k * 4.0f;
+    float diff = fabsf(a[0] - b[0]);
+    float h = fmaxf(k4 - diff, 0.0f) / k4;
+    float hg = fmaxf(k4 - diff, 0.0f) / (2.0f * k4);
+    float t = (a[0] < b[0]) ? hg : (1.0f - hg);
+    float u = 1.0f - t;
+    o[0] = fminf(a[0], b[0]) - ((h * h) * k4) * 0.25f;
+    for (int c = 1; c < 4; ++c) o[c] = a[c] * u + b[c] * t;
+}
+
+void orc_sdf_scene(const orc_sdf_instr *prog, uint32_t n_instr, const float p[3], float out[4]) { /* :276-353 */
+    float stack[16][4];
+    int sp = 0;
+    for (uint32_t k = 0; k < n_instr; ++k) {
+        const orc_sdf_instr *in = &prog[k];
+        float v[4];
+        if (in->op < 16u) {
+            float q[3] = {p[0] - in->a[0], p[1] - in->a[1], p[2] - in->a[2]};
+            if (in->op == 0u) sdg_sphere(q, in->a[3], v);
+            else if (in->op == 1u) sdg_box(q, &in->a[3], v);
+            else if (in->op == 2u) sdg_torus(q, in->a[3], in->a[4], v);
+            else sdg_capsule(q, in->a[3], in->a[4], v);
+        } else {
+            const float *b = stack[--sp];
+            const float *a = stack[--sp];
+            if (in->op == 16u) memcpy(v, (a[0] < b[0]) ? a : b, sizeof v);      /* opUnion :181-187 */
+            else if (in->op == 17u) memcpy(v, (a[0] > b[0]) ? a : b, sizeof v); /* opIntersection :190-196 */
+            else if (in->op == 18u) {                                           /* opSubtraction :199-202 */
+                float nb[4] = {-b[0], -b[1], -b[2], -b[3]};
+                memcpy(v, (a[0] > nb[0]) ? a : nb, sizeof v);
+            } else op_smooth_union(a, b, in->a[0], v);
+        }
+        memcpy(stack[sp++], v, sizeof v);
+    }
+    if (sp == 0) { out[0] = 1000.0f; out[1] = 0.0f; out[2] = 1.0f; out[3] = 0.0f; return; } /* empty scene :282-286 */
+    memcpy(out, stack[sp - 1], 4 * sizeof(float));
+}
+
+void orc_sdf_gradients(const orc_sdf_instr *prog, uint32_t n_instr, const float *positions, uint32_t n, float *gradients) {
+    for (uint32_t i = 0; i < n; ++i) orc_sdf_scene(prog, n_instr, positions + (size_t)i * 4, gradients + (size_t)i * 4);
+}
+
+void orc_sdf_update_positions(const float *positions, const float *gradients, uint32_t n, float *next_positions) {
+    for (uint32_t i = 0; i < n; ++i) { /* update-positions.wgsl:22-50 */
+        const float *p = positions + (size_t)i * 4, *g = gradients + (size_t)i * 4;
+        float *o = next_positions + (size_t)i * 4;
+        float len = sdf_len3(g[1], g[2], g[3]);
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 0.0f;
+        if (len > 0.0001f) {
+            o[0] = p[0] - (g[1] / len) * g[0];
+            o[1] = p[1] - (g[2] / len) * g[0];
+            o[2] = p[2] - (g[3] / len) * g[0];
+        }
+    }
+}
+
+void orc_sdf_scale_factors(const orc_sdf_instr *prog, uint32_t n_instr, const float *positions, uint32_t n, float *scale_factors) {
+    const float r = 0.02f; /* sampleRadius, CurvatureSampler.ts:98 */
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *c = positions + (size_t)i * 4;
+        float cr[4];
+        orc_sdf_scene(prog, n_instr, c, cr);
+        float cl = sdf_len3(cr[1], cr[2], cr[3]);
+        float nx = cr[1] / cl, ny = cr[2] / cl, nz = cr[3] / cl;
+        float total = 0.0f;
+        for (int k = 0; k < 6; ++k) { /* offsets in the reference's order :100-107 */
+            float q[3] = {c[0] + ((k == 0) ? r : (k == 1) ? -r : 0.0f), c[1] + ((k == 2) ? r : (k == 3) ? -r : 0.0f),
+                          c[2] + ((k == 4) ? r : (k == 5) ? -r : 0.0f)};
+            float s[4];
+            orc_sdf_scene(prog, n_instr, q, s);
+            float sl = sdf_len3(s[1], s[2], s[3]);
+            float d = (nx * (s[1] / sl) + ny * (s[2] / sl)) + nz * (s[3] / sl);
+            total = total + (1.0f - d);
+        }
+        float avg = total / 6.0f;
+        float t = fminf(fmaxf((avg - 0.0f) / (0.5f - 0.0f), 0.0f), 1.0f);
+        float sm = (t * t) * (3.0f - 2.0f * t);
+        float sf = 1.0f - sm;
+        scale_factors[i] = 0.01f * (1.0f - sf) + 1.0f * sf;
+    }
+}
+
+void orc_sdf_curvature(const float *gradients, const float *scale_factors, uint32_t n, float *curvature) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *g = gradients + (size_t)i * 4;
+        float *o = curvature + (size_t)i * 4;
+        float len = sdf_len3(g[1], g[2], g[3]);
+        o[0] = 0.0f; o[1] = 1.0f; o[2] = 0.0f; o[3] = scale_factors[i];
+        if (len > 0.0001f) { o[0] = g[1] / len; o[1] = g[2] / len; o[2] = g[3] / len; }
+    }
+}

@@ -131,6 +131,20 @@ uint64_t orc_composite_disc(int early_out, const float *lit_or_color, size_t col
  * curvature are vec4 arrays; props is the interleaved 8-float record. */
 void orc_update_props(const float *positions, const float *curvature, uint32_t n, float *props);
 
+/* ---- SDF splat generation --------------------------------------------------------------------
+ * src/sdf/CodeGenerator.ts:97-225 (sdgSphere/Box/Torus/Capsule, opUnion/Intersection/Subtraction/SmoothUnion),
+ * :276-353 (sceneSDF: post-order walk), src/GradientSampler.ts (gradients[i] = sceneSDF(p_i)),
+ * src/shaders/update-positions.wgsl:22-50, src/CurvatureSampler.ts:84-141.
+ * The scene graph is a postfix program of {op, a[7]} instructions (op codes as in include/splat.h; restated here so that
+ * the checker does not include the product's header): 0 sphere {c, r}, 1 box {c, half size}, 2 torus {c, major, minor},
+ * 3 capsule {c, height, radius}, 16 union, 17 intersection, 18 subtraction, 19 smooth union {k}. */
+typedef struct { uint32_t op; float a[7]; } orc_sdf_instr;
+void orc_sdf_scene(const orc_sdf_instr *prog, uint32_t n_instr, const float p[3], float out[4]);
+void orc_sdf_gradients(const orc_sdf_instr *prog, uint32_t n_instr, const float *positions, uint32_t n, float *gradients);
+void orc_sdf_update_positions(const float *positions, const float *gradients, uint32_t n, float *next_positions);
+void orc_sdf_scale_factors(const orc_sdf_instr *prog, uint32_t n_instr, const float *positions, uint32_t n, float *scale_factors);
+void orc_sdf_curvature(const float *gradients, const float *scale_factors, uint32_t n, float *curvature);
+
 /* Whole frame for timing (project -> keys -> sort -> binSorted -> composite model A). Scratch is
  * allocated inside; returns 0 or -1 on allocation failure. P is written to *total_pairs. */
 int orc_frame(int mode, int early_out, const float uniforms[22], const float *props,

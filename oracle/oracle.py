@@ -64,6 +64,10 @@ def lib():
         L.orc_frame.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_int, fp, u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.orc_frame.restype = C.c_int
+        L.orc_sdf_gradients.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_uint32, fp]
+        L.orc_sdf_update_positions.argtypes = [fp, fp, C.c_uint32, fp]
+        L.orc_sdf_scale_factors.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_uint32, fp]
+        L.orc_sdf_curvature.argtypes = [fp, fp, C.c_uint32, fp]
         L.orc_unorm8.argtypes = [C.c_float]
         L.orc_unorm8.restype = C.c_uint8
         _lib = L
@@ -290,3 +294,44 @@ def frame(u, props, normals, width, height, tile=16, mode=MODE_FRONT_TO_BACK, ea
     if rc != 0:
         raise MemoryError("orc_frame allocation failed")
     return dict(out_f32=out, out_u8=out8, total_pairs=int(total.value), stage_ms=list(ms))
+
+
+# ---- SDF splat generation -------------------------------------------------------------------------
+def _sdf_program(program):
+    """program: sequence of (op, [params]) in postfix order -> packed {u32 op, f32 a[7]} records."""
+    rec = np.zeros(len(program), dtype=[("op", np.uint32), ("a", np.float32, 7)])
+    for k, (op, a) in enumerate(program):
+        rec[k]["op"] = op
+        rec[k]["a"][:len(a)] = np.asarray(a, np.float32)
+    return rec
+
+
+def sdf_gradients(program, positions):
+    rec = _sdf_program(program)
+    positions = _c32(positions)
+    out = np.zeros_like(positions)
+    lib().orc_sdf_gradients(rec.ctypes.data, len(rec), _f(positions), positions.shape[0], _f(out))
+    return out
+
+
+def sdf_update_positions(positions, gradients):
+    positions, gradients = _c32(positions), _c32(gradients)
+    out = np.zeros_like(positions)
+    lib().orc_sdf_update_positions(_f(positions), _f(gradients), positions.shape[0], _f(out))
+    return out
+
+
+def sdf_scale_factors(program, positions):
+    rec = _sdf_program(program)
+    positions = _c32(positions)
+    out = np.zeros(positions.shape[0], np.float32)
+    lib().orc_sdf_scale_factors(rec.ctypes.data, len(rec), _f(positions), positions.shape[0], _f(out))
+    return out
+
+
+def sdf_curvature(gradients, scale_factors):
+    gradients = _c32(gradients)
+    scale_factors = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros_like(gradients)
+    lib().orc_sdf_curvature(_f(gradients), _f(scale_factors), gradients.shape[0], _f(out))
+    return out

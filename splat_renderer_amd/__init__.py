@@ -11,4 +11,6 @@ from .camera import Camera  # noqa: F401
 from .host import (Buffer, CommandEncoder, ComputeShaderRenderer, DepthKeyExtractor, Device, GPUTileBinner,  # noqa: F401
                    PerTileSorter, PointManager, PrefixSumScanner, PropertyPlanes, RadixSorter, Renderer, SequentialRenderer,
                    SplatProjector, SplatPropertyManager, TileRenderer)
-from .frameloop import FrameLoop, MouseEvent, OrbitCameraController, read_png, write_png  # noqa: F401
+from .frameloop import FrameLoop, MouseEvent, OrbitCameraController, SdfSplatSource, read_png, write_png  # noqa: F401
+from . import sdf  # noqa: F401
+from .sdf import CurvatureSampler, GradientSampler, PositionUpdater, SDFScene  # noqa: F401

@@ -27,6 +27,14 @@ class SplatError(RuntimeError):
         self.code = code
 
 
+SDF_SPHERE, SDF_BOX, SDF_TORUS, SDF_CAPSULE, SDF_UNION, SDF_INTERSECTION, SDF_SUBTRACTION, SDF_SMOOTH_UNION = 0, 1, 2, 3, 16, 17, 18, 19
+SDF_MAX_INSTR = 32
+
+
+class SdfInstr(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("a", C.c_float * 7)]
+
+
 class CompositeCfg(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("early_out", C.c_uint32), ("tile_size", C.c_uint32),
                 ("tile_row0", C.c_uint32), ("tile_row1", C.c_uint32), ("record_format", C.c_uint32),
@@ -99,6 +107,10 @@ SIGNATURES = {
     "splat_band_settle": (_i, [_vp, _vp, _vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "splat_band_kept": (_i, [_vp, _vp, C.POINTER(_u32)]),
     "splat_band_keys": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, C.POINTER(_u32)]),
+    "splat_sdf_gradients": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "splat_sdf_update_positions": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "splat_sdf_scale_factors": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "splat_sdf_curvature": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_comm_unique_id": (_i, [_vp]),
     "splat_comm_init": (_i, [_vp, _i, _i, _vp, _pvp]),
     "splat_comm_destroy": (None, [_vp]),

@@ -291,9 +291,10 @@ int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted) {
     binner_free(b);
     if (hipMalloc((void **)&b->counts, (size_t)tc * 4 + 16) != hipSuccess ||
         hipMalloc((void **)&b->offsets, (size_t)tc * 4 + 16) != hipSuccess ||
-        hipMalloc((void **)&b->blocksums, (size_t)div_up(sc, BIN_BLOCK) * 4 + 16) != hipSuccess ||
+        hipMalloc((void **)&b->blocksums, ((size_t)div_up(sc, BIN_BLOCK) + TF_SMALL_FRAME_SPLATS / TF_BLOCK_SMALL) * 4 + 16) != hipSuccess ||
         hipMalloc((void **)&b->ranges, (size_t)sc * 8 + 16) != hipSuccess ||
-        hipMalloc((void **)&b->tf_hist, ((size_t)256 * div_up(sc, BIN_BLOCK) + 256) * 4) != hipSuccess) {
+        // (first-pass histograms: one column per 1024-splat block, or per 256-splat block of a small frame)
+        hipMalloc((void **)&b->tf_hist, ((size_t)256 * (div_up(sc, BIN_BLOCK) + TF_SMALL_FRAME_SPLATS / TF_BLOCK_SMALL) + 256) * 4) != hipSuccess) {
         binner_free(b);
         return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc");
     }
@@ -345,7 +346,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     if (n_sorted > 0) {
         if (tile_first) {
             // (tf_hist: per 1024-splat block its pairs per low tile-id digit, the first sort pass's histogram)
-            rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, BIN_BLOCK), 1u << tf_lo_bits);
+            rc = radix_rowscan_launch(ctx, b->tf_hist, div_up(n_splats, b->tf_block), 1u << tf_lo_bits);
             if (rc != SPLAT_OK) return rc;
         } else if (range32)
             hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const float4 *)projected, range32,
@@ -359,7 +360,8 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         // block bases + pair total (PrefixSumScanner.scan :296-303).  A sync-free tile-first frame needs
         // neither: positions come from the digit histogram and k_tf_scatter sums the total itself.
         if (!(tile_first && async)) {
-            rc = scan_exclusive_u32(ctx, b->blocksums, b->blocksums, blocks, b->d_total);
+            // (tile-first: one count per block of the projector's histogram, which is 256 splats for small frames)
+            rc = scan_exclusive_u32(ctx, b->blocksums, b->blocksums, tile_first ? div_up(n_splats, b->tf_block) : blocks, b->d_total);
             if (rc != SPLAT_OK) return rc;
         }
         if (async) {
@@ -390,7 +392,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         // first pass of the tile-id sort, fused with the expansion (tile_first.hip); later kernels take
         // their pair count from d_total[2], which k_tf_scatter sets (0 if the pairs do not fit)
         rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
-                               b->d_total + 1, b->pairs.keys, b->wide_a);
+                               b->d_total + 1, b->pairs.keys, b->wide_a, b->tf_block);
         if (rc != SPLAT_OK) return rc;
         const uint32_t *p_dev = b->d_total + 2;
         bool primary = true;

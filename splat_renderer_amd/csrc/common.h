@@ -122,6 +122,7 @@ struct splat_binner {
     void *discs = nullptr;                          // frame path, oriented-disc footprint: the projector's 32-byte disc records
     uint32_t discs_cap = 0;
     bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
+    uint32_t tf_block = 1024;                       // splats per block of that histogram (TF_BLOCK_SMALL for small frames)
     uint64_t total = 0;
     bool ran = false;
     // sync-free operation: when the previous frame's pair total is known and 1.125x of it fits the
@@ -146,11 +147,16 @@ struct BinParams {
     uint32_t skip_outside; // frame of a strict band of tile rows: splats that provably cannot reach it are not projected in full
 };
 
+// Splats per block of the tile-first binner's first pass: 1024, or 256 for small frames — a 10 000-splat frame in
+// 1024-splat blocks is a ten-workgroup kernel expanding 14 pairs per splat in four rounds on an otherwise idle device
+// (64 of that frame's 120 us).
+constexpr uint32_t TF_BLOCK_LARGE = 1024, TF_BLOCK_SMALL = 256, TF_SMALL_FRAME_SPLATS = 131072;
 // Where the frame path's projector leaves the first sort pass's histogram (tile_first.hip): per
-// 1024-splat block the pairs per low tile-id digit (digit-major, num_parts columns) and in total.
+// block of splats the pairs per low tile-id digit (digit-major, num_parts columns) and in total.
 struct TfHistOut {
     uint32_t *hist, *blocksums, *overflow_flag;
     uint32_t mask, num_parts;
+    uint32_t block = TF_BLOCK_LARGE; // splats per block
 };
 // tile-id bits and their split over the two sort passes (13 bits -> 6 + 7: longer digit runs than 8 + 5)
 static inline uint32_t tile_id_bits(uint32_t tiles) {
@@ -172,7 +178,7 @@ int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-t
 // tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
-                      uint2 *out_val);
+                      uint2 *out_val, uint32_t block_splats);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
                      uint32_t *counts);

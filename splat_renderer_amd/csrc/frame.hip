@@ -296,6 +296,7 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
         binner->tf_hist_ready = true;
+        binner->tf_block = BTF_BLOCK;
         sorter->ran = false;
         sorter->count_pending = false;
         sorter->kept_blocks = blocks; // the kept count is summed on demand (splat_band_kept / splat_band_settle)
@@ -459,7 +460,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     if (tile_first) { // the projector also counts each 1024-splat block's pairs per low tile-id digit
         rc = binner_reserve(binner, ntx * nty, n);
         if (rc != SPLAT_OK) return rc;
-        ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, 1024)};
+        // small frames: 256-splat blocks, so that the first pass is more than a handful of workgroups
+        const uint32_t block = (n <= TF_SMALL_FRAME_SPLATS && !bp.skip_outside) ? TF_BLOCK_SMALL : TF_BLOCK_LARGE;
+        ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, block), block};
+        binner->tf_block = block;
     }
     if (disc && n > binner->discs_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

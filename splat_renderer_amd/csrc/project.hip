@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
 // rectangle is in registers the block's pairs are counted per low tile-id digit — the histogram the
 // first pass of the tile-id sort needs (tile_first.hip; k_band_prepare_tf in frame.hip does the same for
 // the gathered records of a multi-GPU band).  The kernel is HBM-bound; the LDS counting hides under the stores.
-template <bool DISC, bool LIT>
+template <bool DISC, bool LIT, uint32_t PER>
 __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                       uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
     __syncthreads();
     uint32_t local = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t i = blockIdx.x * 1024u + k * 256u + tid;
+    for (uint32_t k = 0; k < PER; ++k) { // (PER * 256 splats per workgroup: the binner's block)
+        const uint32_t i = blockIdx.x * (PER * 256u) + k * 256u + tid;
         if (i >= n) {
             if (i < n_padded) keys[i] = 0xffffffffu;
             continue;
@@ -389,13 +389,23 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
 #define SPLAT_PROJECT_HIST_LAUNCH(KERNEL, D, L)                                                                               \
     hipLaunchKernelGGL((KERNEL<D, L>), dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, \
                        (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio)
+#define SPLAT_PROJECT_HIST_LAUNCH_PER(D, L)                                                                                                \
+    do {                                                                                                                                   \
+        if (hist_out->block == TF_BLOCK_SMALL)                                                                                             \
+            hipLaunchKernelGGL((k_project_hist<D, L, 1>), dim3(div_up(work, 256)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, \
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio);                                  \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((k_project_hist<D, L, 4>), dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, \
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio);                                  \
+    } while (0)
     if (hist_out && keys && range32 && !payload && index_base == 0) {
+        // (a strict band's kernel works in 1024-splat blocks only: the caller keeps hist_out->block at TF_BLOCK_LARGE for it)
         if (disc && bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, true, false);
-        else if (disc) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist, true, false);
+        else if (disc) SPLAT_PROJECT_HIST_LAUNCH_PER(true, false);
         else if (bp->skip_outside && with_lit) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, false, true);
         else if (bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, false, false);
-        else if (with_lit) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist, false, true);
-        else SPLAT_PROJECT_HIST_LAUNCH(k_project_hist, false, false);
+        else if (with_lit) SPLAT_PROJECT_HIST_LAUNCH_PER(false, true);
+        else SPLAT_PROJECT_HIST_LAUNCH_PER(false, false);
     } else if (keys && range32) {
         if (disc) SPLAT_PROJECT_LAUNCH(true, true, true, false, range32, *bp);
         else if (with_lit) SPLAT_PROJECT_LAUNCH(true, true, false, true, range32, *bp);
@@ -409,6 +419,7 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
     }
 #undef SPLAT_PROJECT_LAUNCH
 #undef SPLAT_PROJECT_HIST_LAUNCH
+#undef SPLAT_PROJECT_HIST_LAUNCH_PER
     LAUNCH_CHECK(ctx, "k_project");
     stage_end(ctx, SPLAT_STAGE_PROJECT);
     return SPLAT_OK;

@@ -22,9 +22,9 @@
 #include "common.h"
 #include "tile_range.h"
 
-constexpr uint32_t TF_THREADS = 256, TF_PER_THREAD = 4, TF_BLOCK = TF_THREADS * TF_PER_THREAD;
+constexpr uint32_t TF_THREADS = 256;
 constexpr uint32_t TF_STAGE = 4096; // pairs staged per block for contiguous stores
-static_assert(TF_BLOCK == 1024, "the stage word packs the block-local slot in 10 bits");
+static_assert(TF_BLOCK_LARGE == 1024 && TF_BLOCK_SMALL == 256, "the stage word packs the block-local slot in 10 bits; blocks are 256 x {4, 1}");
 
 __device__ __forceinline__ uint32_t range32_hits(uint32_t r) {
     const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
@@ -131,7 +131,8 @@ struct TfScatterShared {
 // d_total (out): [0] = pair total of this frame (the sum of the digit totals); [2] = the count the
 // later kernels work on: the total, or 0 when it exceeds pair_limit (then nothing is written and
 // the overflow flag is raised: the frame is rendered again with room).
-template <bool RANK_ATOMIC>
+// TF_PER_THREAD splats per thread: 4 (1024-splat blocks) or 1 (256-splat blocks of small frames, common.h).
+template <bool RANK_ATOMIC, uint32_t TF_PER_THREAD>
 __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__restrict__ range32,
                                                            const uint32_t *__restrict__ depth_keys, uint32_t n, uint32_t ntx,
                                                            uint32_t mask, uint32_t num_parts,
@@ -142,16 +143,18 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     __shared__ TfScatterShared sh;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
-    __shared__ uint32_t s_key[TF_BLOCK];
+    __shared__ uint32_t s_key[TF_THREADS * TF_PER_THREAD];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t first = blockIdx.x * TF_BLOCK;
+    const uint32_t first = blockIdx.x * (TF_THREADS * TF_PER_THREAD);
     // every global load of the prologue is issued before anything waits on one: the block's ranges and
     // keys, the digit totals, and this block's row of scanned histogram (measured per phase, a workgroup
     // spent 15 % of its life on the totals alone when they were loaded, scanned and waited for first)
-    static_assert(TF_PER_THREAD == 4, "uint4 loads");
-    const uint32_t i0 = first + tid * 4; // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
+    static_assert(TF_PER_THREAD == 4 || TF_PER_THREAD == 1, "uint4 or scalar loads");
+    const uint32_t i0 = first + tid * TF_PER_THREAD; // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
     uint4 rr = make_uint4(1u, 1u, 1u, 1u), kk = make_uint4(0, 0, 0, 0); // 1 = empty range
-    if (i0 + 3 < n) {
+    if (TF_PER_THREAD == 1) {
+        if (i0 < n) { rr.x = range32[i0]; kk.x = depth_keys[i0]; }
+    } else if (i0 + 3 < n) {
         rr = reinterpret_cast<const uint4 *>(range32)[i0 >> 2];
         kk = reinterpret_cast<const uint4 *>(depth_keys)[i0 >> 2];
     } else {
@@ -182,8 +185,13 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     __syncthreads(); // wave_sums is reused below
 
     uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
-    reinterpret_cast<uint4 *>(s_key)[tid] = kk;
-    r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
+    if constexpr (TF_PER_THREAD == 4) {
+        reinterpret_cast<uint4 *>(s_key)[tid] = kk;
+        r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
+    } else {
+        s_key[tid] = kk.x;
+        r[0] = rr.x;
+    }
 #pragma unroll
     for (uint32_t k = 0; k < TF_PER_THREAD; ++k) h[k] = range32_hits(r[k]);
     // offsets of every splat's pairs inside the block, in ascending splat index: one block scan of the
@@ -191,7 +199,9 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     uint32_t off[TF_PER_THREAD];
     uint32_t carry;
     {
-        const uint32_t mine = (h[0] + h[1]) + (h[2] + h[3]);
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < TF_PER_THREAD; ++k) mine += h[k];
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -202,9 +212,8 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
         __syncthreads();
         const uint32_t s0 = wsum[0], s1 = wsum[1], s2 = wsum[2], s3 = wsum[3];
         off[0] = (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u) + incl - mine;
-        off[1] = off[0] + h[0];
-        off[2] = off[1] + h[1];
-        off[3] = off[2] + h[2];
+#pragma unroll
+        for (uint32_t k = 1; k < TF_PER_THREAD; ++k) off[k] = off[k - 1] + h[k - 1];
         carry = s0 + s1 + s2 + s3;
     }
     const uint32_t total = carry;
@@ -480,19 +489,25 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
 // radix_rowscan_launch (rows scanned in place, digit totals behind them)
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
-                      uint2 *out_val) {
-    const uint32_t parts = div_up(n, TF_BLOCK);
+                      uint2 *out_val, uint32_t block_splats) {
+    const uint32_t parts = div_up(n, block_splats);
     const uint32_t *totals = hist + (size_t)256 * parts;
     {
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
     }
-    if (ctx->lds_atomic_ordered == 1)
-        hipLaunchKernelGGL(k_tf_scatter<true>, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, hist,
-                           totals, d_total, pair_limit, overflow, out_tile, out_val);
-    else
-        hipLaunchKernelGGL(k_tf_scatter<false>, dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, hist,
-                           totals, d_total, pair_limit, overflow, out_tile, out_val);
+    const bool ra = ctx->lds_atomic_ordered == 1;
+#define SPLAT_TF_SCATTER(RA, PER)                                                                                                 \
+    hipLaunchKernelGGL((k_tf_scatter<RA, PER>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
+                       hist, totals, d_total, pair_limit, overflow, out_tile, out_val)
+    if (block_splats == TF_BLOCK_SMALL) {
+        if (ra) SPLAT_TF_SCATTER(true, 1);
+        else SPLAT_TF_SCATTER(false, 1);
+    } else {
+        if (ra) SPLAT_TF_SCATTER(true, 4);
+        else SPLAT_TF_SCATTER(false, 4);
+    }
+#undef SPLAT_TF_SCATTER
     LAUNCH_CHECK(ctx, "k_tf_scatter");
     return SPLAT_OK;
 }

@@ -134,6 +134,47 @@ def read_png(path):
     return out.reshape(h, w, 4)
 
 
+class SdfSplatSource:
+    """The producer half of the reference's frame (src/main.ts:146-180): fresh points, five rounds of
+    {evaluate gradients, step onto the surface, swap}, curvature scale factors — then, for the tile-raster path,
+    SplatPropertyManager.updateFromCurvature (position + colour from the normal).  step() returns the property buffer
+    and the vec4(normal, scale) buffer Renderer.render takes."""
+
+    ITERATIONS = 5  # main.ts:149
+
+    def __init__(self, device, scene, seed=0):
+        from .host import PointManager, SplatPropertyManager
+        from .sdf import CurvatureSampler, GradientSampler, PositionUpdater
+        self.device, self.scene = device, scene
+        self.pointManager = PointManager(device, scene, seed)
+        n = self.numPoints = self.pointManager.getNumPoints()
+        self.gradientSampler = GradientSampler(device, scene, n)
+        self.curvatureSampler = CurvatureSampler(device, scene, n)
+        self.positionUpdater = PositionUpdater(device, None, n)
+        self.properties = SplatPropertyManager(device, n)
+
+    def step(self, reinitialize=True):
+        pm, gs, cs = self.pointManager, self.gradientSampler, self.curvatureSampler
+        gs.updateSceneParameters()  # :119-120 (the caller may have animated the primitives)
+        cs.updateSceneParameters()
+        if reinitialize:
+            pm.reinitialize()       # :147
+        for _ in range(self.ITERATIONS):  # :149-172
+            gs.evaluateGradients(None, None, pm.getCurrentPositionBuffer())
+            self.positionUpdater.updatePositions(None, None, pm.getCurrentPositionBuffer(), gs.getGradientBuffer(), pm.getNextPositionBuffer())
+            pm.swap()
+        cs.computeScaleFactors(None, pm.getCurrentPositionBuffer())  # :175-180
+        # (the gradients are those of the last evaluation, one step behind the positions, exactly as main.ts hands
+        # gradientSampler.getGradientBuffer() to its renderer at :186)
+        curvature = cs.getCurvatureBuffer(gs.getGradientBuffer())
+        self.properties.updateFromCurvature(None, pm.getCurrentPositionBuffer(), curvature)
+        return self.properties.getPropertyBuffer(), curvature
+
+    def destroy(self):
+        for o in (self.pointManager, self.gradientSampler, self.curvatureSampler, self.properties):
+            o.destroy()
+
+
 class FrameLoop:
     """The render loop of src/main.ts:110-193 for the tile-raster path: per frame the camera's uniform block
     (VP, eye, time, W, H — :126-144) and one Renderer.render call (:183-190)."""

@@ -149,23 +149,38 @@ def _uniform_floats(u):
 
 # ------------------------------------------------------------------------------------------------
 class PointManager:
-    """src/PointManager.ts:41,220-252 — ping-pong position buffers.  The reference seeds points
-    with unseeded Math.random on an SDF surface (out of scope); here `scene` is an (n,4) f32
-    position array (or a seed) and reinitialize() re-uploads it."""
+    """src/PointManager.ts:10-252 — ping-pong position buffers.  `scene` is
+      * an SDFScene (splat_renderer_amd.sdf): the reference's constructor — point count from the primitives' surface
+        areas (:22-39), positions on the faces of the scene's global AABB (:96-189), fresh ones at every
+        reinitialize() (:220-231) — from a SEEDED generator (`seed`, then seed+1, ...: the reference's Math.random
+        clouds cannot be reproduced);
+      * an (n,4) f32 position array, which reinitialize() uploads again; or an int: the bench scene of that seed."""
 
-    def __init__(self, device, scene):
+    def __init__(self, device, scene, seed=0):
         self.device = device
-        if isinstance(scene, (int, np.integer)):
-            from .scene import make_scene
-            props, _ = make_scene(int(scene))
-            scene = np.concatenate([props[:, :3], np.ones((props.shape[0], 1), np.float32)], axis=1)
-        self._positions = np.ascontiguousarray(scene, dtype=np.float32)
-        self.numPoints = self._positions.shape[0]
+        self.scene, self._seed, self._positions = None, seed, None
+        if hasattr(scene, "getPrimitives"):
+            from . import sdf
+            if not scene.getPrimitives():
+                raise SplatError(-1, "Scene must have at least one primitive")  # :47-49
+            self.scene = scene
+            self.numPoints = sdf.point_count(scene)
+        else:
+            if isinstance(scene, (int, np.integer)):
+                from .scene import make_scene
+                props, _ = make_scene(int(scene))
+                scene = np.concatenate([props[:, :3], np.ones((props.shape[0], 1), np.float32)], axis=1)
+            self._positions = np.ascontiguousarray(scene, dtype=np.float32)
+            self.numPoints = self._positions.shape[0]
         self._buffers = [device.createBuffer(self.numPoints * 16), device.createBuffer(self.numPoints * 16)]
         self._current = 0
         self.reinitialize()
 
     def reinitialize(self):  # :220-231
+        if self.scene is not None:
+            from . import sdf
+            self._positions = sdf.seed_positions(self.scene, self.numPoints, self._seed)
+            self._seed += 1
         self._buffers[self._current].write(self._positions)
 
     def swap(self):  # :240-242
