@@ -9,7 +9,7 @@ from ._lib import (MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL, STAGE_BIN, STAGE_
                    STAGE_PROJECT, STAGE_SORT, CompositeCfg, SplatError)
 from .camera import Camera  # noqa: F401
 from .host import (Buffer, CommandEncoder, ComputeShaderRenderer, DepthKeyExtractor, Device, GPUTileBinner,  # noqa: F401
-                   PerTileSorter, PointManager, PrefixSumScanner, PropertyPlanes, RadixSorter, Renderer, SequentialRenderer,
+                   PerTileSorter, PipelinedRenderer, PointManager, PrefixSumScanner, PropertyPlanes, RadixSorter, Renderer, SequentialRenderer,
                    SplatProjector, SplatPropertyManager, TileRenderer)
 from .frameloop import FrameLoop, MouseEvent, OrbitCameraController, SdfSplatSource, read_png, write_png  # noqa: F401
 from . import sdf  # noqa: F401

@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     const uint32_t px = tx * CT + (w & 1) * 8 + (lane & 7), py = ty * CT + (w >> 1) * 8 + (lane >> 3);
     const bool pixel_ok = px < p.width && py < p.height;
     const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f; // :169
-    const float tile_cx = (float)(tx * CT) + 0.5f, tile_cy = (float)(ty * CT) + 0.5f;
+    const float tile_x0 = (float)(tx * CT), tile_y0 = (float)(ty * CT);
+    const float tile_cx = tile_x0 + 0.5f, tile_cy = tile_y0 + 0.5f;
+    const v2f p_local = {(float)((w & 1) * 8 + (lane & 7)) + 0.5f, (float)((w >> 1) * 8 + (lane >> 3)) + 0.5f}; // pixel centre in the tile
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     float acc = (MODE == SPLAT_COMPOSITE_REFERENCE_LITERAL) ? 0.0f : 1.0f; // alpha (literal) or transmittance T
@@ -226,8 +228,14 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 if (!(r < 0.5f)) { // :127-129 "too small"
                     const float4 c = (LIT32 || p.prelit) ? f_c : lit_color(f_c, f_n);
                     col = make_float2(c.x, c.y);
-                    // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(dist^2 * scale)
-                    geo = make_float4((b.x + b.z) * 0.5f, (b.y + b.w) * 0.5f, -2.885390081777927f / (r * r), c.z); // :124
+                    // gaussian = exp(-0.5 nd^2 / 0.25), nd = dist / r  ->  exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r,
+                    // evaluated per pixel as (p k - c k)^2 in TILE-LOCAL coordinates (|p|, |c| of the order of the tile, so the
+                    // difference loses nothing that matters: < 1e-5 relative in the Gaussian for the smallest splat the
+                    // reference draws): one packed multiply-add, one packed square and an add per (entry, quadrant) instead of
+                    // two subtractions, two multiplies and a scale — the kernel is bound by vector-ALU issue slots
+                    const float k = 1.6986436005760381f / r;                                     // sqrt(2.885390081777927)
+                    const float lx = (b.x + b.z) * 0.5f - tile_x0, ly = (b.y + b.w) * 0.5f - tile_y0; // :124, then exact
+                    geo = make_float4(lx * k, ly * k, k, c.z);
                     xm = span_mask16(b.x, b.z, tile_cx);
                     ym = span_mask16(b.y, b.w, tile_cy);
                 }
@@ -276,7 +284,8 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
             // independent work, and the loop/branch overhead is paid once per pair; the second
             // entry's coverage is re-masked with the pixels the first one has just saturated, so the
             // per-pixel stop is exactly sequential
-            while (hits) {
+            bool saturated = false; // (one loop exit: the accumulators then stay in the registers they live in)
+            while (hits && !saturated) {
                 const uint32_t j0 = (uint32_t)__builtin_ctzll(hits);
                 hits &= hits - 1;
                 const bool two = hits != 0;
@@ -310,9 +319,10 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                     C1 = *reinterpret_cast<const float2 *>(&s_par[c0 + j1][1]);
                     B0 = G0.w;
                     B1 = G1.w;
-                    const float dx0 = pxf - G0.x, dy0 = pyf - G0.y, dx1 = pxf - G1.x, dy1 = pyf - G1.y;
-                    g0 = __builtin_amdgcn_exp2f((dx0 * dx0 + dy0 * dy0) * G0.z);
-                    g1 = __builtin_amdgcn_exp2f((dx1 * dx1 + dy1 * dy1) * G1.z);
+                    const v2f t0 = p_local * (v2f){G0.z, G0.z} - (v2f){G0.x, G0.y}, t1 = p_local * (v2f){G1.z, G1.z} - (v2f){G1.x, G1.y};
+                    const v2f q0 = t0 * t0, q1 = t1 * t1;
+                    g0 = __builtin_amdgcn_exp2f(-(q0.x + q0.y));
+                    g1 = __builtin_amdgcn_exp2f(-(q1.x + q1.y));
                 }
                 unsigned long long lv = uniform64(live); // pinned at the use: see uniform64()
                 g0 = __builtin_amdgcn_inverse_ballot_w64(cover0 & lv) ? g0 : 0.0f;
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 live = lv;
                 if (EARLY_OUT && uniform64(live) == 0) {
                     needed = base + c0 + (first_saturated ? j0 : j1) + 1;
-                    break;
+                    saturated = true;
                 }
             }
         }

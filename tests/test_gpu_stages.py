@@ -1285,3 +1285,34 @@ def test_headless_frame_loop_orbits_the_camera(device, tmp_path):
     assert np.array_equal(loop2.readPixels(), shots[3][1])
     for o in (loop, loop2, pbuf, nbuf):
         o.destroy()
+
+
+def test_pipelined_renderer_keeps_frames_identical(device):
+    """Two frames in flight (frames alternate between two streams): every frame — a different camera each — is the frame
+    the one-stream Renderer gives, bit for bit, including the sync-free ones."""
+    n, w, h = 30000, 400, 240
+    props, normals, _ = make_case(n, w, h, 71, 1.5)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    cam = sr.Camera()
+    cam.setAspect(w / h)
+    uniforms = []
+    for k in range(6):
+        uniforms.append(cam.uniforms(w, h).copy())
+        cam.rotate(0.3, 0.05)
+    one = sr.Renderer(device, None, "rgba8unorm", n)
+    want = []
+    for u in uniforms:
+        one.render(u, pbuf, nbuf, None, w, h)
+        want.append(one.readPixels().copy())
+    pr = sr.PipelinedRenderer(0, 2, n)
+    got = []
+    for k, u in enumerate(uniforms):
+        pr.render(u, pbuf, nbuf, None, w, h)
+        if k >= 3:  # the first three go unread: frames 1 and 2 are enqueued while frame 0 is in flight
+            got.append((k, pr.readPixels().copy()))
+    pr.finish()
+    for k, img in got:
+        assert np.array_equal(img, want[k]), k
+    assert len({w_.tobytes() for w_ in want}) == len(want)
+    for o in (pr, one, pbuf, nbuf):
+        o.destroy()

@@ -1,0 +1,44 @@
+#!/bin/bash
+# tools/collect_evidence.sh <outdir>: everything profiles/ is built from, in ONE call on the GPU box (run from the
+# repository root): bench lines of all four configurations, rocprofv3 kernel trace + stats of the default bench
+# command, FETCH_SIZE / WRITE_SIZE and SQ / GRBM counters in separate --pmc passes, virtual-rank times, layout A/B.
+out=$1
+root=$(pwd)
+mkdir -p "$out"
+for c in C2 C0 C1 C3; do
+  python3 bench.py --config $c --steps 40 > "$out/bench_$c.json" 2> "$out/bench_$c.err" || echo "bench $c failed"
+  echo "bench $c done"
+done
+python3 bench.py --records projected --steps 40 --no-cpu-baseline > "$out/bench_C2_projected_records.json" 2>/dev/null
+python3 bench.py --layout planes --steps 40 --no-cpu-baseline > "$out/bench_C2_planes_prelit.json" 2>/dev/null
+python3 bench.py --footprint disc --steps 40 > "$out/bench_C2_disc.json" 2>/dev/null
+echo "bench variants done"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out/trace" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 100 > "$root/$out/bench_under_trace.json" 2> "$root/$out/trace.err"
+echo "trace done"
+for pmc in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $pmc --output-format csv -d "$root/$out/pmc_$pmc" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_$pmc.err"
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d "$root/$out/pmc_SQ" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_SQ.err"
+for c in C0 C1 C3; do
+  for pmc in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $pmc --output-format csv -d "$root/$out/pmc_${c}_$pmc" -- python3 "$root/bench.py" --config $c --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_${c}_$pmc.err"
+  done
+done
+echo "pmc done"
+cd "$root"
+python3 tools/kstats.py $(ls $out/trace/*/*_kernel_trace.csv | head -1) 120 > "$out/kernel_breakdown.txt"
+cp $(ls $out/trace/*/*_kernel_stats.csv | head -1) "$out/kernel_stats.csv"
+python3 tools/pmc_merge.py $(ls $out/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls $out/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1) > "$out/pmc_fetch_write.csv"
+python3 tools/pmc_avg.py --valu $(ls $out/pmc_SQ/*/*_counter_collection.csv | head -1) $(ls $out/pmc_GRBM_GUI_ACTIVE/*/*_counter_collection.csv | head -1) > "$out/sq_counters.csv"
+for c in C0 C1 C3; do
+  python3 tools/pmc_merge.py $(ls $out/pmc_${c}_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls $out/pmc_${c}_WRITE_SIZE/*/*_counter_collection.csv | head -1) > "$out/pmc_fetch_write_$c.csv"
+done
+python3 tools/band_bench.py C2 1 2 4 8 > "$out/virtual_rank_times.txt" 2>&1
+python3 tools/band_bench.py C3 1 8 >> "$out/virtual_rank_times.txt" 2>&1
+python3 tools/replicated_bench.py C2 1 2 4 8 > "$out/exchange_free_rank_times.txt" 2>&1
+python3 tools/layout_ab.py C2 100 > "$out/layout_ab_C2.txt" 2>&1
+python3 tools/two_in_flight.py C2 > "$out/frames_in_flight.txt" 2>&1
+python3 tools/two_in_flight.py C1 >> "$out/frames_in_flight.txt" 2>&1
+rm -rf "$out"/pmc_*/ "$out/trace"
+echo "evidence collected in $out"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Frame time with the reference's interleaved property records vs the two-plane layout vs planes with the colour
-plane pre-lit, alternating on
-one renderer (same box, same clocks): python tools/layout_ab.py [C2]"""
+"""Frame time of the property layouts (the reference's interleaved records | two planes | planes with the colour plane
+pre-lit) x the records the frame's projector writes (lit composite records | ProjectedSplat), alternating on one box
+in one process (same clocks): python tools/layout_ab.py [C2] [frames=100]"""
 import os
 import sys
 import time
@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import splat_renderer_amd as sr
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n, w, h = sr.scene.CONFIGS[name]
 props, normals = sr.scene.make_scene(n)
 cam = sr.Camera()
@@ -19,13 +20,16 @@ dev = sr.Device(0)
 pm = sr.SplatPropertyManager(dev, n)
 pm.setFromArrays(props)
 nbuf = dev.createBufferFrom(normals)
-r = sr.Renderer(dev, None, "rgba8unorm", n)
-for label, pb in (("interleaved", pm.getPropertyBuffer()), ("planes", pm.getPropertyPlanes()), ("planes, colour pre-lit", pm.getLitPlanes(nbuf))) * 2:
-    for _ in range(5):
-        r.render(u, pb, nbuf, None, w, h)
-    dev.sync()
-    t0 = time.perf_counter()
-    for _ in range(100):
-        r.render(u, pb, nbuf, None, w, h)
-    dev.sync()
-    print(name, label, round((time.perf_counter() - t0) / 100 * 1e3, 4), "ms/frame", flush=True)
+renderers = {rec: sr.Renderer(dev, None, "rgba8unorm", n, records=rec) for rec in ("lit", "projected")}
+layouts = (("interleaved", pm.getPropertyBuffer()), ("planes", pm.getPropertyPlanes()), ("planes, colour pre-lit", pm.getLitPlanes(nbuf)))
+for _ in range(2):
+    for label, pb in layouts:
+        for rec, r in renderers.items():
+            for _ in range(5):
+                r.render(u, pb, nbuf, None, w, h)
+            dev.sync()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                r.render(u, pb, nbuf, None, w, h)
+            dev.sync()
+            print(f"{name} {label:24s} records={rec:9s} {(time.perf_counter() - t0) / frames * 1e3:.4f} ms/frame", flush=True)
