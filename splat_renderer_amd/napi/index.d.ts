@@ -14,6 +14,19 @@ export class Camera {
   getViewProjectionMatrix(): Float32Array; getPosition(): Float32Array; uniforms(width: number, height: number, time?: number): Float32Array;
 }
 export class PointManager { constructor(device: Device, scene: Float32Array | { numPoints: number; seed?: number }); reinitialize(): void; swap(): void; getCurrentPositionBuffer(): Buffer; getNextPositionBuffer(): Buffer; getNumPoints(): number; destroy(): void; }
+export interface SceneNode { type: "primitive" | "operation"; }
+export class Sphere { constructor(params?: { id?: string; position?: ArrayLike<number>; radius?: number }); id: string; position: Float32Array; radius: number; }
+export class Box { constructor(params?: { id?: string; position?: ArrayLike<number>; size?: ArrayLike<number> }); id: string; position: Float32Array; size: Float32Array; }
+export class Torus { constructor(params?: { id?: string; position?: ArrayLike<number>; majorRadius?: number; minorRadius?: number }); id: string; position: Float32Array; majorRadius: number; minorRadius: number; }
+export class Capsule { constructor(params?: { id?: string; position?: ArrayLike<number>; height?: number; radius?: number }); id: string; position: Float32Array; height: number; radius: number; }
+export type Primitive = Sphere | Box | Torus | Capsule;
+export class SmoothUnion { constructor(k?: number); k: number; id: string; }
+export function union(a: Primitive | SceneNode, b: Primitive | SceneNode): SceneNode; export function intersection(a: Primitive | SceneNode, b: Primitive | SceneNode): SceneNode;
+export function subtraction(a: Primitive | SceneNode, b: Primitive | SceneNode): SceneNode; export function smoothUnion(k: number, a: Primitive | SceneNode, b: Primitive | SceneNode): SceneNode;
+export class SDFScene { setRoot(node: Primitive | SceneNode): void; get(id: string): Primitive | undefined; getPrimitives(): Primitive[]; getRoot(): SceneNode | null; getOperations(): unknown[]; getStructureHash(): string; program(): Float32Array; }
+export class GradientSampler { constructor(device: Device, scene: SDFScene, numPoints: number); updateSceneParameters(): void; rebuildIfNeeded(): void; evaluateGradients(enc: CommandEncoder | null, uniformBuffer: Buffer | null, positionBuffer: Buffer): void; getGradientBuffer(): Buffer; getScene(): SDFScene; destroy(): void; }
+export class PositionUpdater { constructor(device: Device, shaderCode: string | null, numPoints: number); updatePositions(enc: CommandEncoder | null, uniformBuffer: Buffer | null, currentPositionBuffer: Buffer, gradientBuffer: Buffer, nextPositionBuffer: Buffer): void; }
+export class CurvatureSampler { constructor(device: Device, scene: SDFScene, numPoints: number); updateSceneParameters(): void; rebuildIfNeeded(): void; computeScaleFactors(enc: CommandEncoder | null, positionBuffer: Buffer): void; getScaleFactorsBuffer(): Buffer; getCurvatureBuffer(gradientBuffer: Buffer): Buffer; destroy(): void; }
 export class Comm { static uniqueId(): Uint8Array; constructor(device: Device, rank: number, world: number, idBytes: Uint8Array); readonly rank: number; readonly world: number; allGather(shardBuffer: Buffer, gatheredBuffer: Buffer, bytesPerRank: number): void; destroy(): void; }
 export class BandRenderer { constructor(device: Device, comm: Comm | null, numPoints: number, width: number, height: number, tileSize?: number); row0: number; row1: number; render(uniformData: Float32Array | Buffer, propertyBuffer: Buffer, normalsBuffer: Buffer): Buffer; settle(): number; pixelRows(): [number, number]; readPixels(): Uint8Array; destroy(): void; }
 export interface PropertyPlanes { posRadius: Buffer; colorOpacity: Buffer; isPlanes: true; prelit?: boolean; }

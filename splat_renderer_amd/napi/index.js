@@ -370,6 +370,75 @@ class PointManager {
   destroy() { this.buffers.forEach((b) => b.destroy()); }              // :248-252
 }
 
+/** SDF splat generation (src/sdf/{Primitive,Operation,Scene}.ts, src/GradientSampler.ts, src/PositionUpdater.ts,
+ * src/CurvatureSampler.ts).  The reference generates a WGSL function per scene graph (sdf/CodeGenerator.ts); here the graph
+ * becomes a postfix program — children first, then their operation, the order CodeGenerator's traverse() emits — that a
+ * stack machine in the HIP kernels evaluates: updateSceneParameters() re-encodes it, nothing is ever recompiled. */
+const SDF = { sphere: 0, box: 1, torus: 2, capsule: 3, union: 16, intersection: 17, subtraction: 18, smooth_union: 19 };
+let nextPrimId = 0, nextSminId = 0;
+class Primitive { constructor(id, position) { this.id = id || `prim_${nextPrimId++}`; this.position = Float32Array.from(position || [0, 0, 0]); } }
+class Sphere extends Primitive {
+  constructor(p = {}) { super(p.id, p.position); this.radius = p.radius === undefined ? 0.5 : p.radius; }
+  getType() { return 'sphere'; } getParamNames() { return [`${this.id}_center`, `${this.id}_radius`]; } getParamValues() { return [...this.position, this.radius]; }
+  getSurfaceArea() { return 4 * Math.PI * this.radius * this.radius; } instr() { return [SDF.sphere, ...this.position, this.radius]; }
+}
+class Box extends Primitive {
+  constructor(p = {}) { super(p.id, p.position); this.size = Float32Array.from(p.size || [0.5, 0.5, 0.5]); }
+  getType() { return 'box'; } getParamNames() { return [`${this.id}_center`, `${this.id}_size`]; } getParamValues() { return [...this.position, 0, ...this.size, 0]; }
+  getSurfaceArea() { const w = this.size[0] * 2, h = this.size[1] * 2, d = this.size[2] * 2; return 2 * (w * h + w * d + h * d); } instr() { return [SDF.box, ...this.position, ...this.size]; }
+}
+class Torus extends Primitive {
+  constructor(p = {}) { super(p.id, p.position); this.majorRadius = p.majorRadius === undefined ? 0.5 : p.majorRadius; this.minorRadius = p.minorRadius === undefined ? 0.2 : p.minorRadius; }
+  getType() { return 'torus'; } getParamNames() { return [`${this.id}_center`, `${this.id}_radii`]; } getParamValues() { return [...this.position, 0, this.majorRadius, this.minorRadius, 0, 0]; }
+  getSurfaceArea() { return 4 * Math.PI * Math.PI * this.majorRadius * this.minorRadius; } instr() { return [SDF.torus, ...this.position, this.majorRadius, this.minorRadius]; }
+}
+class Capsule extends Primitive {
+  constructor(p = {}) { super(p.id, p.position); this.height = p.height === undefined ? 1.0 : p.height; this.radius = p.radius === undefined ? 0.3 : p.radius; }
+  getType() { return 'capsule'; } getParamNames() { return [`${this.id}_center`, `${this.id}_params`]; } getParamValues() { return [...this.position, 0, this.height, this.radius, 0, 0]; }
+  getSurfaceArea() { return 2 * Math.PI * this.radius * this.height + 4 * Math.PI * this.radius * this.radius; } instr() { return [SDF.capsule, ...this.position, this.height, this.radius]; }
+}
+class Operation { constructor(type, params = []) { this.type = type; this.params = params; } getType() { return this.type; } getParamNames() { return []; } getParamValues() { return this.params; } }
+class SmoothUnion extends Operation { constructor(k = 0.1) { super('smooth_union', [k]); this.k = k; this.id = `smin_${nextSminId++}`; } getParamNames() { return [`${this.id}_k`]; } getParamValues() { return [this.k]; } }
+const primitive = (p) => (p && p.type === 'primitive') || (p && p.type === 'operation') ? p : { type: 'primitive', primitive: p };
+const binary = (op, a, b) => ({ type: 'operation', operation: op, children: [primitive(a), primitive(b)] });
+const union = (a, b) => binary(new Operation('union'), a, b), intersection = (a, b) => binary(new Operation('intersection'), a, b);
+const subtraction = (a, b) => binary(new Operation('subtraction'), a, b), smoothUnion = (k, a, b) => binary(new SmoothUnion(k), a, b);
+class SDFScene { // src/sdf/Scene.ts:72-152
+  constructor() { this.root = null; this.primitiveMap = new Map(); }
+  setRoot(node) { this.root = primitive(node); this.primitiveMap.clear(); const walk = (n) => { if (n.type === 'primitive') this.primitiveMap.set(n.primitive.id, n.primitive); else n.children.forEach(walk); }; walk(this.root); }
+  get(id) { return this.primitiveMap.get(id); } getPrimitives() { return Array.from(this.primitiveMap.values()); } getRoot() { return this.root; }
+  getOperations() { const ops = []; const walk = (n) => { if (n.type === 'operation') { ops.push(n.operation); n.children.forEach(walk); } }; if (this.root) walk(this.root); return ops; }
+  getStructureHash() { const walk = (n) => (n.type === 'primitive' ? `P:${n.primitive.getType()}:${n.primitive.id}` : `O:${n.operation.getType()}:(${n.children.map(walk).join(',')})`); return this.root ? walk(this.root) : ''; }
+  program() { // Float32Array, 8 floats per instruction: [op, a0..a6]
+    const rows = []; const walk = (n) => { if (n.type === 'primitive') rows.push(n.primitive.instr()); else { n.children.forEach(walk); rows.push([SDF[n.operation.getType()], ...n.operation.getParamValues()]); } };
+    if (this.root) walk(this.root);
+    const out = new Float32Array(rows.length * 8); rows.forEach((r, k) => out.set(r, k * 8)); return out;
+  }
+}
+class SceneStage {
+  constructor(device, scene, numPoints) { this.device = device; this.scene = scene; this.numPoints = numPoints; this.currentStructureHash = scene.getStructureHash(); this.updateSceneParameters(); }
+  updateSceneParameters() { this.program = this.scene.program(); }
+  rebuildIfNeeded() { const h = this.scene.getStructureHash(); if (h !== this.currentStructureHash) { this.currentStructureHash = h; this.updateSceneParameters(); } }
+  getScene() { return this.scene; }
+}
+class GradientSampler extends SceneStage { // src/GradientSampler.ts
+  constructor(device, scene, numPoints) { super(device, scene, numPoints); this.gradientBuffer = device.createBuffer(numPoints * 16); }
+  evaluateGradients(commandEncoder, uniformBuffer, positionBuffer) { native.sdf_gradients(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.gradientBuffer.ptr); }
+  getGradientBuffer() { return this.gradientBuffer; } destroy() { this.gradientBuffer.destroy(); }
+}
+class PositionUpdater { // src/PositionUpdater.ts
+  constructor(device, shaderCode, numPoints) { this.device = device; this.numPoints = numPoints; }
+  updatePositions(commandEncoder, uniformBuffer, currentPositionBuffer, gradientBuffer, nextPositionBuffer) { native.sdf_update_positions(this.device.ctx, currentPositionBuffer.ptr, gradientBuffer.ptr, this.numPoints, nextPositionBuffer.ptr); }
+}
+class CurvatureSampler extends SceneStage { // src/CurvatureSampler.ts
+  constructor(device, scene, numPoints) { super(device, scene, numPoints); this.scaleFactorsBuffer = device.createBuffer(numPoints * 4); this.curvatureBuffer = null; }
+  computeScaleFactors(commandEncoder, positionBuffer) { native.sdf_scale_factors(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.scaleFactorsBuffer.ptr); }
+  getScaleFactorsBuffer() { return this.scaleFactorsBuffer; }
+  // vec4(normal, scaleFactor): the curvatureData buffer SplatPropertyManager.updateFromCurvature binds (the reference's samplers write its halves apart)
+  getCurvatureBuffer(gradientBuffer) { if (!this.curvatureBuffer) this.curvatureBuffer = this.device.createBuffer(this.numPoints * 16); native.sdf_curvature(this.device.ctx, gradientBuffer.ptr, this.scaleFactorsBuffer.ptr, this.numPoints, this.curvatureBuffer.ptr); return this.curvatureBuffer; }
+  destroy() { this.scaleFactorsBuffer.destroy(); if (this.curvatureBuffer) this.curvatureBuffer.destroy(); }
+}
+
 /** The multi-GPU frame's exchange (no reference counterpart: the reference is single-device): one process per GPU, an
  * RCCL communicator behind the C ABI.  Rank 0 calls Comm.uniqueId() and hands the 128 bytes to the other ranks by
  * any channel (a file, a socket, an environment variable); every rank then constructs Comm with the same bytes. */
@@ -411,6 +480,7 @@ class BandRenderer {
   destroy() { this.sorter.destroy(); this.binner.destroy(); this.shard.destroy(); if (this.gathered !== this.shard) this.gathered.destroy(); this.output.destroy(); }
 }
 
-module.exports = { native, Device, Buffer: Buffer_, Camera, PointManager, Comm, BandRenderer, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
+module.exports = { native, Device, Buffer: Buffer_, Camera, PointManager, Comm, BandRenderer, SDFScene, Sphere, Box, Torus, Capsule, SmoothUnion,
+  union, intersection, subtraction, smoothUnion, GradientSampler, PositionUpdater, CurvatureSampler, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
   GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, SequentialRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL,
   FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC, RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_LIT32 };

@@ -297,6 +297,39 @@ FN(render_frame_planes) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), pos
     return check(env, x, splat_render_frame_planes(x, s, b, &cfg, u, pr, co, nrm, n, w, h, proj, o8, of), mk_undefined(env));
 }
 
+/* ---- SDF splat generation (include/splat.h: "SDF splat generation") ---- */
+static int sdf_program(call_t *c, size_t i, splat_sdf_instr *prog, uint32_t *count) { /* Float32Array of 8 floats per instruction: [op, a0..a6] */
+    size_t nb = 0; float *f = arg_hostbuf(c, i, &nb);
+    if (c->failed) return 0;
+    size_t n = nb / (8 * sizeof(float));
+    if (n > SPLAT_SDF_MAX_INSTR) { c->failed = 1; napi_throw_range_error(c->env, NULL, "SDF program: too many instructions"); return 0; }
+    for (size_t k = 0; k < n; k++) { prog[k].op = (uint32_t)f[k * 8]; for (int j = 0; j < 7; j++) prog[k].a[j] = f[k * 8 + 1 + j]; }
+    *count = (uint32_t)n;
+    return 1;
+}
+FN(sdf_gradients) { /* (ctx, program, positions, n, gradients) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); splat_sdf_instr prog[SPLAT_SDF_MAX_INSTR]; uint32_t cnt = 0;
+    if (!sdf_program(&c, 1, prog, &cnt)) return NULL;
+    void *pos = arg_dptr(&c, 2); uint32_t n = (uint32_t)arg_number(&c, 3); void *g = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_sdf_gradients(x, prog, cnt, pos, n, g), mk_undefined(env));
+}
+FN(sdf_update_positions) { /* (ctx, positions, gradients, n, nextPositions) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); void *pos = arg_dptr(&c, 1), *g = arg_dptr(&c, 2); uint32_t n = (uint32_t)arg_number(&c, 3);
+    void *nx = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_sdf_update_positions(x, pos, g, n, nx), mk_undefined(env));
+}
+FN(sdf_scale_factors) { /* (ctx, program, positions, n, scaleFactors) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); splat_sdf_instr prog[SPLAT_SDF_MAX_INSTR]; uint32_t cnt = 0;
+    if (!sdf_program(&c, 1, prog, &cnt)) return NULL;
+    void *pos = arg_dptr(&c, 2); uint32_t n = (uint32_t)arg_number(&c, 3); void *sf = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_sdf_scale_factors(x, prog, cnt, pos, n, sf), mk_undefined(env));
+}
+FN(sdf_curvature) { /* (ctx, gradients, scaleFactors, n, curvature) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); void *g = arg_dptr(&c, 1), *sf = arg_dptr(&c, 2); uint32_t n = (uint32_t)arg_number(&c, 3);
+    void *cur = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_sdf_curvature(x, g, sf, n, cur), mk_undefined(env));
+}
+
 /* ---- multi-GPU band path (include/splat.h: "multi-GPU band path", "the multi-GPU frame's one exchange") ---- */
 FN(project_slice_compact) { /* (ctx, Float32Array(22), posRadius, strideVec4, first, count, records16) */
     ARGS(7); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
@@ -350,7 +383,7 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
         EXPORT(project_slice_compact), EXPORT(band_frame), EXPORT(band_settle), EXPORT(comm_unique_id), EXPORT(comm_init), EXPORT(comm_destroy),
-        EXPORT(allgather_records),
+        EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

@@ -80,6 +80,29 @@ def test_js_camera_pan_rotate_zoom_match_python_camera():
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (k, v)
 
 
+def test_js_sdf_scene_encodes_like_the_python_host():
+    """The SDF scene graph from JS (src/sdf/Scene.ts builders): same structure hash and the same postfix program as
+    splat_renderer_amd/sdf.py, which the GPU tests hold against the oracle."""
+    ensure_built()
+    from tests.test_sdf_cpu import main_ts_scene
+    r = node("const sr=require('./index.js');const s=new sr.SDFScene();"
+             "const a=new sr.Sphere({id:'sphere1',radius:0.5}),b=new sr.Box({id:'box1',position:[0.6,0,0],size:[0.3,0.3,0.3]}),"
+             "c=new sr.Sphere({id:'sphere2',position:[0,0.6,0],radius:0.25});"
+             "s.setRoot(sr.smoothUnion(0.1,sr.smoothUnion(0.15,a,b),c));"
+             "console.log(JSON.stringify({hash:s.getStructureHash(),prog:Array.from(s.program()),ops:s.getOperations().map(o=>o.k),"
+             "names:s.get('box1').getParamNames(),area:new sr.Capsule().getSurfaceArea()}))")
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    scene = main_ts_scene()
+    assert d["hash"] == scene.getStructureHash() and d["ops"] == [0.1, 0.15] and d["names"] == ["box1_center", "box1_size"]
+    want = np.zeros((5, 8), np.float32)
+    for k, (op, a) in enumerate(scene.program()):
+        want[k, 0] = op
+        want[k, 1:1 + len(a)] = a
+    assert np.array_equal(np.array(d["prog"], np.float32).reshape(5, 8), want)
+    assert abs(d["area"] - (2 * np.pi * 0.3 + 4 * np.pi * 0.09)) < 1e-12
+
+
 def test_js_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
@@ -137,3 +160,29 @@ def test_js_frame_matches_oracle(tmp_path):
     assert np.abs(seq8.astype(int) - raster8.astype(int)).max(axis=2)[rim == 0].max() <= 3  # early-out: (1 - 0.99) * 255
     dframe8 = np.fromfile(tmp_path / "discframe.rgba8", np.uint8).reshape(h, w, 4)
     assert np.array_equal(dframe8, seq8)  # same lists, same composite
+
+
+@pytest.mark.gpu
+def test_js_sdf_generation_matches_oracle(tmp_path):
+    """GradientSampler / PositionUpdater / CurvatureSampler / PointManager driven from JS (src/main.ts:146-180): bit-exact
+    against the oracle's five projection steps, scale factors and vec4(normal, scale)."""
+    ensure_built()
+    from splat_renderer_amd import sdf
+    from tests.test_sdf_cpu import main_ts_scene
+    scene = main_ts_scene()
+    n = 5000
+    pos = sdf.seed_positions(scene, n, seed=21)
+    pos.tofile(tmp_path / "pos.f32")
+    r = subprocess.run([NODE, "sdf_generate.js", str(tmp_path / "pos.f32"), str(n), str(tmp_path / "out.f32")], cwd=NAPI,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["hash"] == scene.getStructureHash()
+    got = np.fromfile(tmp_path / "out.f32", np.float32).reshape(3, n, 4)
+    scene.get("sphere1").position[0] = np.float32(0.1)
+    prog = scene.program()
+    for _ in range(5):
+        grad = O.sdf_gradients(prog, pos)
+        pos = O.sdf_update_positions(pos, grad)
+    cur = O.sdf_curvature(grad, O.sdf_scale_factors(prog, pos))
+    for k, want in enumerate((pos, grad, cur)):
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), k
