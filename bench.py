@@ -255,7 +255,11 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     comp_s = stage_ms["composite"] / 1e3
     achieved = comp_bytes / comp_s / 1e9
     frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, disc)
-    pmc = load_traffic(name + ("_disc" if disc else "") + ("" if (args.records == "lit" or disc) else "_projected_records"))
+    # (profiles/traffic.json holds counters for: the default configuration, the disc footprint, and round 1's
+    # ProjectedSplat records + pre-lit planes; any other combination reports no PMC figures)
+    key = name + ("_disc" if disc else "" if (args.records == "lit" and not prelit) else
+                  "_projected_records_prelit_planes" if (args.records == "projected" and prelit) else "_unmeasured")
+    pmc = load_traffic(key)
     roofline = {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"],
@@ -366,6 +370,20 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
 
 
 def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world):
+    # stdout carries ONE JSON line: RCCL prints a version banner to it when a communicator is created, so the C-level
+    # stdout points at stderr until the line is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+
+def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world):
     import torch
     import torch.distributed as td
     torch.cuda.set_device(local_rank)
