@@ -169,6 +169,9 @@ def main():
                          "splat_allgather_records, default; falls back to torch if RCCL cannot be bound) or torch.distributed")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the next frame's projection + all-gather with the current frame's band work")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra measurements after the timed region (early-out-off composite, two frames in flight): for kernel "
+                         "traces of the timed frames alone — frames in flight on two streams overlap, which inflates every kernel's duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -257,7 +260,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     frame_bytes = frame_alg_bytes(n, n, ntx * nty, pairs, p_used, width, height, disc)
     # (profiles/traffic.json holds counters for: the default configuration, the disc footprint, and round 1's
     # ProjectedSplat records + pre-lit planes; any other combination reports no PMC figures)
-    key = name + ("_disc" if disc else "" if (args.records == "lit" and not prelit) else
+    key = name + (("_disc" if prelit else "_unmeasured") if disc else "" if (args.records == "lit" and not prelit) else
                   "_projected_records_prelit_planes" if (args.records == "projected" and prelit) else "_unmeasured")
     pmc = load_traffic(key)
     roofline = {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -297,7 +300,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                            "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "frac_of_measured_copy": frame_bytes / (dt / args.steps) / 1e9 / copy_gbs},
     }
-    if not disc:
+    if not disc and not args.no_extras:
         # SURVEY 8d's composite-only figure: early-out OFF, every entry of every list consumed (68 P + 4WH), the same
         # kernel on the same frame's records and lists, outside the timed region
         off = time_composite_alone(dev, r, u, pbuf, nbuf, width, height, tile, early_out=False)
@@ -308,7 +311,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                 "achieved_GBps": ob / (off["ms"] / 1e3) / 1e9, "frac": ob / (off["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
                 "traffic_model": composite_traffic_model(off["staged"], width, height, args.records, prelit),
                 "note": "k_composite alone with the alpha>=0.99 break disabled on the timed frame's lists: SURVEY 8d composite-only figure"}}
-    if not disc:
+    if not disc and not args.no_extras:
         # two frames in flight (PipelinedRenderer: frames alternate between two streams): the same frames, more of them
         # per second; NOT the timed region above (whose composite durations would be inflated by the overlap)
         try:

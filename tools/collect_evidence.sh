@@ -14,7 +14,7 @@ python3 bench.py --layout planes --steps 40 --no-cpu-baseline > "$out/bench_C2_p
 python3 bench.py --footprint disc --steps 40 > "$out/bench_C2_disc.json" 2>/dev/null
 echo "bench variants done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out/trace" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 100 > "$root/$out/bench_under_trace.json" 2> "$root/$out/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$root/$out/trace" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --no-extras --steps 100 > "$root/$out/bench_under_trace.json" 2> "$root/$out/trace.err"
 echo "trace done"
 for pmc in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $pmc --output-format csv -d "$root/$out/pmc_$pmc" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_$pmc.err"
