@@ -110,17 +110,37 @@ __device__ __forceinline__ bool cannot_reach_band(const FrameUniforms &u, float4
 // screen extent, screenRadius half the larger one, and the disc record goes to dio.discs.
 // LIT (isotropic frames): the 32-byte composite record {centre, radius, depth | lit colour} goes to lio.records
 // (shade.h) — everything the composite reads of a splat, in one line; the ProjectedSplat is then optional.
+// Everything the projector reads of one splat.  Kernels that project several splats per thread load all of them
+// before the first one's arithmetic (fourteen IEEE divides and two square roots deep) and stores: left to the
+// compiler the loads stay behind the previous splat's stores — the output pointers may alias the inputs for all it
+// knows — and every wave sits out two memory round trips per splat.
+struct SplatIn {
+    float4 pr, col, nrm;
+};
+template <bool DISC, bool LIT>
+__device__ __forceinline__ SplatIn load_splat(const float4 *__restrict__ pos_radius, uint32_t stride_vec4, uint32_t i, const DiscIO &dio,
+                                              const LitIO &lio) {
+    SplatIn s;
+    s.pr = pos_radius[(size_t)i * stride_vec4];
+    s.col = s.nrm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (DISC) s.nrm = dio.normals[(size_t)i * dio.normal_stride];
+    if (LIT) {
+        s.col = lio.color[(size_t)i * lio.color_stride];
+        if (!lio.prelit) s.nrm = lio.normals[(size_t)i * lio.normal_stride];
+    }
+    return s;
+}
+
 template <bool WITH_KEYS, bool WITH_RANGE, bool DISC, bool LIT = false>
-__device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
-                                                uint32_t i, uint32_t index_base, float4 *__restrict__ projected,
-                                                uint32_t *__restrict__ keys, uint32_t *__restrict__ payload,
-                                                uint32_t *__restrict__ range32, const BinParams &bp, const DiscIO &dio,
-                                                const LitIO &lio = LitIO{}) {
+__device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const SplatIn &in, uint32_t i, uint32_t index_base,
+                                                float4 *__restrict__ projected, uint32_t *__restrict__ keys,
+                                                uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, const BinParams &bp,
+                                                const DiscIO &dio, const LitIO &lio = LitIO{}) {
     float4 a, b;
     float depth;
     if (DISC) {
-        const float4 pr = pos_radius[(size_t)i * stride_vec4];
-        const DiscRecord d = disc_record(u.m, u.w, u.h, pr, dio.normals[(size_t)i * dio.normal_stride]);
+        const float4 pr = in.pr;
+        const DiscRecord d = disc_record(u.m, u.w, u.h, pr, in.nrm);
         dio.discs[(size_t)i * 2] = d.a;
         dio.discs[(size_t)i * 2 + 1] = d.b;
         disc_bounds(d, a);
@@ -128,16 +148,15 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const fl
         depth = sqrtf((dx * dx + dy * dy) + dz * dz); // SplatProjector.ts:77: the sort key does not depend on the footprint
         b = make_float4(depth, 0.5f * fmaxf(a.z - a.x, a.w - a.y), __uint_as_float(index_base + i), 0.0f);
     } else {
-        const float4 c = project_centre(u, pos_radius[(size_t)i * stride_vec4]);
+        const float4 c = project_centre(u, in.pr);
         const float scx = c.x, scy = c.y, max_r = c.z;
         depth = c.w;
         float padded = max_r * 1.5f; // :119
         a = make_float4(scx - padded, scy - padded, scx + padded, scy + padded);
         b = make_float4(depth, max_r, __uint_as_float(index_base + i), 0.0f); // :128 originalIndex
         if (LIT) {
-            const float4 col = lio.color[(size_t)i * lio.color_stride];
             lio.records[(size_t)i * 2] = c;
-            lio.records[(size_t)i * 2 + 1] = lio.prelit ? col : lit_color(col, lio.normals[(size_t)i * lio.normal_stride]);
+            lio.records[(size_t)i * 2 + 1] = lio.prelit ? in.col : lit_color(in.col, in.nrm);
         }
     }
     if ((!DISC && !LIT) || projected) { // (a disc or lit frame's composite reads its own records: the ProjectedSplat is optional there)
@@ -207,15 +226,15 @@ __global__ __launch_bounds__(256) void k_project(FrameUniforms u, const float4 *
         }
         return;
     }
-    project_one<WITH_KEYS, WITH_RANGE, DISC, LIT>(u, pos_radius, stride_vec4, i, index_base, projected, keys, payload, range32, bp, dio,
-                                                  lio);
+    const SplatIn in = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
+    project_one<WITH_KEYS, WITH_RANGE, DISC, LIT>(u, in, i, index_base, projected, keys, payload, range32, bp, dio, lio);
 }
 
 // Tile-first frame path: 1024 splats per workgroup (the binner's block), and while each splat's tile
 // rectangle is in registers the block's pairs are counted per low tile-id digit — the histogram the
 // first pass of the tile-id sort needs (tile_first.hip; k_band_prepare_tf in frame.hip does the same for
 // the gathered records of a multi-GPU band).  The kernel is HBM-bound; the LDS counting hides under the stores.
-template <bool DISC, bool LIT, uint32_t PER>
+template <bool DISC, bool LIT, uint32_t PER, uint32_t AHEAD = 1>
 __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
                                                       uint32_t n, uint32_t n_padded, float4 *__restrict__ projected,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ range32, BinParams bp,
@@ -223,19 +242,28 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
     __shared__ uint32_t lh[4][256];
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
+    SplatIn in[PER]; // (unrolled: a splat's registers are live from its load to its last use only)
+#pragma unroll
+    for (uint32_t k = 0; k < AHEAD; ++k) { // AHEAD splats' loads in flight before the first dependent instruction
+        const uint32_t i = blockIdx.x * (PER * 256u) + k * 256u + tid;
+        if (i < n) in[k] = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
+    }
     if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
     for (uint32_t j = tid; j < 4 * 256; j += 256) (&lh[0][0])[j] = 0;
     __syncthreads();
     uint32_t local = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) { // (PER * 256 splats per workgroup: the binner's block)
+        if (k + AHEAD < PER) { // ... and AHEAD of them in flight from then on
+            const uint32_t i = blockIdx.x * (PER * 256u) + (k + AHEAD) * 256u + tid;
+            if (i < n) in[k + AHEAD] = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
+        }
         const uint32_t i = blockIdx.x * (PER * 256u) + k * 256u + tid;
         if (i >= n) {
             if (i < n_padded) keys[i] = 0xffffffffu;
             continue;
         }
-        const uint32_t r = project_one<true, true, DISC, LIT>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio,
-                                                              lio);
+        const uint32_t r = project_one<true, true, DISC, LIT>(u, in[k], i, 0, projected, keys, nullptr, range32, bp, dio, lio);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
         local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
@@ -299,8 +327,8 @@ __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, cons
     uint32_t local = 0;
     for (uint32_t j = tid; j < kept; j += 256) {
         const uint32_t i = s_list[j];
-        const uint32_t r = project_one<true, true, DISC, LIT>(u, pos_radius, stride_vec4, i, 0, projected, keys, nullptr, range32, bp, dio,
-                                                              lio);
+        const SplatIn in = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
+        const uint32_t r = project_one<true, true, DISC, LIT>(u, in, i, 0, projected, keys, nullptr, range32, bp, dio, lio);
         const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
         if (tx0 > tx1 || ty0 > ty1) continue;
         local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);

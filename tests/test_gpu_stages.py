@@ -777,6 +777,38 @@ def test_tile_first_depth_ties_resolve_by_index(device, kind):
         o.destroy()
 
 
+@pytest.mark.parametrize("n,rs,cls", [(3000, 1.0, "short"), (8000, 1.0, "long")])
+def test_tile_first_wide_depth_range_inside_a_tile(device, n, rs, cls):
+    """The per-tile sort runs one 8-bit pass per byte of (largest - smallest depth key) of the tile: three at the bench
+    sizes.  A tile with splats both a hair's breadth from the eye and far away (depths 10^5 apart: keys 2^27 and more
+    apart) takes four — in either size class, with the same lists.  (A variant of the kernel that packed the
+    remaining key bits and a 13-bit list position into one LDS word had to send exactly these tiles down another
+    path; it measured no faster and was dropped, the case stays.)"""
+    w, h = 64, 64
+    props, normals, u = make_case(n, w, h, 71, rs)
+    eye = np.asarray(u[16:19], np.float32)
+    toward = -eye / np.linalg.norm(eye)
+    rng = np.random.default_rng(5)
+    near = rng.choice(n, 40, replace=False)
+    props[near, :3] = eye + toward * rng.uniform(2e-5, 6e-5, size=(40, 1)).astype(np.float32)  # the scene sits ~3 away
+    props[near, 3] = np.float32(2e-7)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    counts, offsets, idx, keys = ref["counts"], ref["offsets"], ref["indices"], ref["keys"]
+    wide = 0
+    for t in range(counts.size):
+        c = int(counts[t])
+        if c and ((c <= 2048) if cls == "short" else (2048 < c <= 6144)):
+            k = keys[idx[offsets[t]:offsets[t] + c]].astype(np.int64)
+            wide += int(k.max() - k.min() >= (1 << 27))
+    assert wide > 0, "the construction must put a wide depth range into a tile of this size class"
+    r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h, want_float=False)
+    total = idx.shape[0]
+    assert r.binner.getTotalIndices() == total
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), idx)
+    for o in (r, pbuf, nbuf):
+        o.destroy()
+
+
 def test_tile_first_sync_free_repeat_and_overflow(device):
     n, w, h = 20000, 320, 200
     small, normals, u = make_case(n, w, h, 61, 0.5)
