@@ -163,16 +163,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_expand(const uint32_t *__re
     }
 }
 
-// report: host-mapped pinned words that receive {pair total, overflow flag, frame sequence number} —
-// a sync-free frame's readback with no copy and no event in the stream (hipMemcpyAsync +
-// hipEventRecord left the GPU idle for ~14 us per frame between the binner and the composite).
-__device__ __forceinline__ void tile_report(const uint32_t *d_total, uint32_t *report, uint32_t seq) {
-    report[0] = d_total[0];
-    report[1] = d_total[1];
-    __threadfence_system();
-    __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls this word
-}
-
 // Tile offsets and counts from the tile-sorted pair keys: offsets[t] = index of the first pair whose
 // tile id is >= t (the same values as the exclusive scan of the counts, TileBinner.ts:452-459).
 // One WAVE per tile does a 65-ary search: every step the 64 lanes probe 64 evenly spaced positions of
@@ -267,17 +257,36 @@ int binner_reserve_range32(splat_binner *b, uint32_t n_splats) {
     return SPLAT_OK;
 }
 
+static void binner_free_wide(splat_binner *b) {
+    if (b->wide_a) (void)hipFree(b->wide_a);
+    if (b->wide_b) (void)hipFree(b->wide_b);
+    if (b->tf_hi) (void)hipFree(b->tf_hi);
+    if (b->tf2_hist) (void)hipFree(b->tf2_hist);
+    if (b->tf_runs_mem) (void)hipFree(b->tf_runs_mem);
+    b->wide_a = b->wide_b = nullptr;
+    b->tf_hi = nullptr;
+    b->tf2_hist = b->tf_runs_mem = nullptr;
+    b->tf_runs = TfRuns{};
+    b->wide_cap = 0;
+}
+
+// the tile-first path's pair buffers, sized with the pair capacity: the first pass's output (values + one byte of
+// tile id per pair, with room for the padding that aligns its runs), the second pass's output and workspace
 static int binner_reserve_wide(splat_binner *b) {
     splat_ctx *ctx = b->ctx;
     if (b->pairs.capacity <= b->wide_cap) return SPLAT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (b->wide_a) (void)hipFree(b->wide_a);
-    if (b->wide_b) (void)hipFree(b->wide_b);
-    b->wide_a = b->wide_b = nullptr;
-    b->wide_cap = 0;
-    const size_t bytes = (size_t)b->pairs.capacity * 8 + 256;
-    if (hipMalloc((void **)&b->wide_a, bytes) != hipSuccess || hipMalloc((void **)&b->wide_b, bytes) != hipSuccess)
+    binner_free_wide(b);
+    const size_t cap = b->pairs.capacity;
+    const size_t parts = (size_t)div_up(b->pairs.capacity, TF_RUN_ALIGN) + 256; // >= tf2_parts_bound(any pair count, any digit split)
+    const size_t runs_bytes = (256 + 256 + 4) * 4 + parts + 16;
+    if (hipMalloc((void **)&b->wide_a, (cap + TF_RUN_SLACK) * 8 + 256) != hipSuccess || hipMalloc((void **)&b->wide_b, cap * 8 + 256) != hipSuccess ||
+        hipMalloc((void **)&b->tf_hi, cap + TF_RUN_SLACK + 256) != hipSuccess ||
+        hipMalloc((void **)&b->tf2_hist, (256 * parts + 256) * 4) != hipSuccess || hipMalloc((void **)&b->tf_runs_mem, runs_bytes) != hipSuccess) {
+        binner_free_wide(b);
         return ctx_fail(ctx, SPLAT_ERR_OOM, "binner hipMalloc (pair values)");
+    }
+    b->tf_runs = {b->tf_runs_mem, b->tf_runs_mem + 256, reinterpret_cast<uint8_t *>(b->tf_runs_mem + 516), b->tf_runs_mem + 512};
     b->wide_cap = b->pairs.capacity;
     return SPLAT_OK;
 }
@@ -391,25 +400,23 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         if (rc != SPLAT_OK) return rc;
         // first pass of the tile-id sort, fused with the expansion (tile_first.hip); later kernels take
         // their pair count from d_total[2], which k_tf_scatter sets (0 if the pairs do not fit)
+        const uint32_t tf_hi_bits = tf_bits - tf_lo_bits;
         rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
-                               b->d_total + 1, b->pairs.keys, b->wide_a, b->tf_block);
+                               b->d_total + 1, b->tf_hi, b->wide_a, b->tf_block, tf_lo_bits, tf_hi_bits > 0, &b->tf_runs);
         if (rc != SPLAT_OK) return rc;
-        const uint32_t *p_dev = b->d_total + 2;
-        bool primary = true;
-        rc = radix_sort_wide(ctx, b->pairs.keys, b->wide_a, b->pairs.keys_b, b->wide_b, b->pairs.hist, total32, p_dev, tf_lo_bits, tf_bits,
-                             8, &primary);
+        // second pass (high digit) into wide_b, and the tile offsets out of its histogram; a screen of at most 256
+        // tiles is sorted by the first pass alone
+        const bool primary = tf_hi_bits == 0;
+        rc = tf_second_pass_launch(ctx, b->tf_hi, b->wide_a, b->wide_b, &b->tf_runs, total32, tiles, tf_lo_bits, tf_hi_bits, b->tf2_hist,
+                                   b->offsets, b->d_total, async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
         if (rc != SPLAT_OK) return rc;
-        const uint32_t *sorted_tiles = primary ? b->pairs.keys : b->pairs.keys_b;
-        hipLaunchKernelGGL(k_tile_offsets, dim3(div_up(tiles + 1, 4)), dim3(256), 0, ctx->stream, sorted_tiles, total32, p_dev,
-                           tiles, b->offsets, b->d_total, async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
-        LAUNCH_CHECK(ctx, "k_tile_offsets");
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
         // (its first launch also writes the tile counts)
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
                               b->counts);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
-        if (async) b->pending = true; // k_tile_offsets reported {total, overflow, seq} into b->pinned; examined at the next call
+        if (async) b->pending = true; // k_tf_offsets reported {total, overflow, seq} into b->pinned; examined at the next call
     } else if (total32 > 0) {
         hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
                            b->ranges, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys, b->pairs.payload);
@@ -521,8 +528,7 @@ void splat_bin_destroy(splat_binner *b) {
     sorter_free_members(&b->pairs);
     if (b->d_total) (void)hipFree(b->d_total);
     if (b->range32) (void)hipFree(b->range32);
-    if (b->wide_a) (void)hipFree(b->wide_a);
-    if (b->wide_b) (void)hipFree(b->wide_b);
+    binner_free_wide(b);
     if (b->expanded) (void)hipFree(b->expanded);
     if (b->discs) (void)hipFree(b->discs);
     if (b->pinned) (void)hipHostFree(b->pinned);

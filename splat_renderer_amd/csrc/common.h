@@ -102,6 +102,17 @@ struct splat_sorter {
 // grows the sorter's buffers (contents are NOT preserved)
 int sorter_reserve(splat_sorter *s, uint32_t capacity);
 
+// The tile-first binner's first sort pass (k_tf_scatter) leaves every low digit's run of pairs starting on a boundary
+// of the second pass's partitions (TF_RUN_ALIGN pairs; tile_first.hip says why), and describes the layout here:
+struct TfRuns {
+    uint32_t *start, *total; // per low digit (256 entries each): first slot of its run, pairs in it
+    uint8_t *part_digit;     // per partition of the second pass: the low digit whose run it lies in
+    uint32_t *parts;         // number of partitions in use
+};
+constexpr uint32_t TF_RUN_ALIGN = 4096;
+constexpr uint32_t TF_RUN_SLACK = 256 * TF_RUN_ALIGN; // slots the padding can add to the first pass's output, at most
+static inline uint32_t tf2_parts_bound(uint32_t pairs, uint32_t lo_bits) { return div_up(pairs, TF_RUN_ALIGN) + (1u << lo_bits); }
+
 struct splat_binner {
     splat_ctx *ctx = nullptr;
     uint32_t tile = 16;
@@ -115,6 +126,10 @@ struct splat_binner {
     splat_sorter pairs;                             // (tileId, splatIdx) ping-pong buffers
     uint2 *wide_a = nullptr, *wide_b = nullptr;     // tile-first path: (depth key, splat idx) per pair, ping-pong
     uint32_t wide_cap = 0;
+    uint8_t *tf_hi = nullptr;                       // tile-first path: high tile-id digit per pair of the first pass's output
+    uint32_t *tf2_hist = nullptr;                   // ... the second pass's histogram (256 rows of partitions + 256 totals)
+    uint32_t *tf_runs_mem = nullptr;                // ... TfRuns storage: start[256], total[256], parts, then part_digit bytes
+    TfRuns tf_runs = {};
     uint32_t *tf_hist = nullptr;                    // tile-first path: per 1024-splat block digit histograms (first sort pass)
     int frame_order = -1;                           // splat_bin_set_frame_order
     void *expanded = nullptr;                       // band frame: ProjectedSplat records rebuilt from compact exchange records
@@ -169,6 +184,16 @@ static inline uint32_t tile_id_low_bits(uint32_t tiles) {
     return bits <= 8 ? bits : bits / 2;
 }
 
+// report: host-mapped pinned words that receive {pair total, overflow flag, frame sequence number} —
+// a sync-free frame's readback with no copy and no event in the stream (hipMemcpyAsync +
+// hipEventRecord left the GPU idle for ~14 us per frame between the binner and the composite).
+__device__ __forceinline__ void tile_report(const uint32_t *d_total, uint32_t *report, uint32_t seq) {
+    report[0] = d_total[0];
+    report[1] = d_total[1];
+    __threadfence_system();
+    __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls this word
+}
+
 // bin.hip internals used by frame.hip
 int binner_reserve_range32(splat_binner *b, uint32_t n_splats);
 int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const void *sorted, uint32_t n_sorted, uint32_t width,
@@ -177,13 +202,14 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
 int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-tile and per-position buffers
 // tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
-                      const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
-                      uint2 *out_val, uint32_t block_splats);
+                      const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint8_t *out_hi,
+                      uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs);
+int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in, uint2 *val_out, const TfRuns *runs, uint32_t pairs_bound,
+                          uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total,
+                          uint32_t *report, uint32_t seq);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
                      uint32_t *counts);
-int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2 *v1, uint32_t *hist, uint32_t n,
-                    const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, uint32_t first_bits, bool *result_in_primary);
 int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_ERR_CAPACITY if that frame overflowed
 // project.hip internal: the projector with the optional per-index tile range output
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,

@@ -218,14 +218,10 @@ __device__ __forceinline__ uint32_t lookback(uint32_t *status, uint32_t part, ui
     return excl;
 }
 
-// PAY = uint32_t: the (key, payload) pairs of the RadixSorter contract.  PAY = uint2: an 8-byte payload
-// (the tile-first binner carries (depth key, splat index) behind each tile id); staged in LDS as a
-// key array followed by a payload array, always separate arrays in memory (IN_PAIRS/OUT_PAIRS unused).
-template <uint32_t ITEMS, bool FULL, bool ONESWEEP, bool RANK_ATOMIC, bool IN_PAIRS = false, bool OUT_PAIRS = false,
-          typename PAY = uint32_t>
+template <uint32_t ITEMS, bool FULL, bool ONESWEEP, bool RANK_ATOMIC, bool IN_PAIRS = false, bool OUT_PAIRS = false>
 __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__restrict__ s_kp, uint32_t part,
-                                               const uint32_t *__restrict__ keys_in, const PAY *__restrict__ pay_in,
-                                               uint32_t *__restrict__ keys_out, PAY *__restrict__ pay_out, uint32_t n,
+                                               const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in,
+                                               uint32_t *__restrict__ keys_out, uint32_t *__restrict__ pay_out, uint32_t n,
                                                uint32_t shift, uint32_t mask, uint32_t num_parts,
                                                const uint32_t *__restrict__ scanned_hist,
                                                const uint32_t *__restrict__ totals, uint32_t *status, uint32_t *err) {
@@ -245,18 +241,14 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     // (wave, item, lane), which is the order the ranking below preserves).  Padding lanes of the
     // last partition read the last real element and are given digit 255 below: they sit after
     // every real key in position order, so they also rank after every real key of digit 255.
-    constexpr bool WIDE = sizeof(PAY) == 8;
     uint32_t key[ITEMS];
-    PAY pay[ITEMS];
+    uint32_t pay[ITEMS];
     const uint32_t wbase = w * WAVE_KEYS + lane;
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; ++i) {
         const uint32_t p = wbase + i * 64;
         const uint32_t q = FULL ? p : ((p < valid) ? p : (valid - 1));
-        if constexpr (WIDE) {
-            key[i] = keys_in[base + q];
-            pay[i] = pay_in[base + q];
-        } else if (IN_PAIRS) { // one 8-byte load per element instead of two 4-byte ones
+        if (IN_PAIRS) { // one 8-byte load per element instead of two 4-byte ones
             const uint2 kp = reinterpret_cast<const uint2 *>(keys_in)[base + q];
             key[i] = kp.x;
             pay[i] = kp.y;
@@ -361,12 +353,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
         uint32_t d = (key[i] >> shift) & mask;
         if (!FULL) d = (wbase + i * 64 < valid) ? d : 255u;
         const uint32_t pos = sh.wave_hist[w][d] + rank[i];
-        if constexpr (WIDE) {
-            reinterpret_cast<uint32_t *>(s_kp)[pos] = key[i];
-            (s_kp + PART_KEYS / 2)[pos] = pay[i];
-        } else {
-            s_kp[pos] = make_uint2(key[i], pay[i]);
-        }
+        s_kp[pos] = make_uint2(key[i], pay[i]);
     }
     __syncthreads();
 
@@ -376,22 +363,14 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     for (uint32_t j = 0; j < ITEMS; ++j) {
         const uint32_t pos = j * RS_THREADS + tid;
         if (FULL || pos < valid) {
-            if constexpr (WIDE) {
-                const uint32_t k = reinterpret_cast<const uint32_t *>(s_kp)[pos];
-                const uint32_t d = (k >> shift) & mask;
-                const uint32_t g = sh.global_base[d] + pos;
-                keys_out[g] = k;
-                pay_out[g] = (s_kp + PART_KEYS / 2)[pos];
+            const uint2 kp = s_kp[pos];
+            const uint32_t d = (kp.x >> shift) & mask;
+            const uint32_t g = sh.global_base[d] + pos;
+            if (OUT_PAIRS) {
+                reinterpret_cast<uint2 *>(keys_out)[g] = kp; // one 8-byte store, 128-byte digit runs
             } else {
-                const uint2 kp = s_kp[pos];
-                const uint32_t d = (kp.x >> shift) & mask;
-                const uint32_t g = sh.global_base[d] + pos;
-                if (OUT_PAIRS) {
-                    reinterpret_cast<uint2 *>(keys_out)[g] = kp; // one 8-byte store, 128-byte digit runs
-                } else {
-                    keys_out[g] = kp.x;
-                    pay_out[g] = kp.y;
-                }
+                keys_out[g] = kp.x;
+                pay_out[g] = kp.y;
             }
         }
     }
@@ -419,30 +398,6 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radi
     else
         downsweep_body<ITEMS, false, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                             scanned_hist, totals, nullptr, nullptr);
-}
-
-// 8-byte payload variant.  Measured at C2 (11.28M pairs, 2 passes, whole frame): 8 keys per thread
-// (24 KiB staged, 5 workgroups per CU) 0.562 ms, 12 -> 0.528, 16 (48 KiB, 2 per CU) -> 0.523: longer
-// digit runs beat occupancy here as they do for the 4-byte payload.
-constexpr uint32_t RSW_ITEMS_DEFAULT = 16;
-template <uint32_t RSW_ITEMS, bool RANK_ATOMIC>
-__global__ __launch_bounds__(RS_THREADS, RSW_ITEMS <= 8 ? 4 : RSW_ITEMS <= 12 ? 3 : 2) void k_radix_downsweep_wide(
-    const uint32_t *__restrict__ keys_in, const uint2 *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
-    uint2 *__restrict__ pay_out, uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t shift, uint32_t mask,
-    uint32_t num_parts, const uint32_t *__restrict__ scanned_hist, const uint32_t *__restrict__ totals) {
-    __shared__ DownsweepShared sh;
-    constexpr uint32_t RSW_PART_KEYS = RSW_ITEMS * RS_THREADS;
-    __shared__ uint2 s_kp[RSW_PART_KEYS / 2 + RSW_PART_KEYS]; // keys (4 B each), then payloads (8 B each)
-    const uint32_t n = sort_count(n_host, n_dev);
-    if (blockIdx.x * RSW_PART_KEYS >= n) return;
-    if ((blockIdx.x + 1) * RSW_PART_KEYS <= n)
-        downsweep_body<RSW_ITEMS, true, false, RANK_ATOMIC, false, false, uint2>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n,
-                                                                                 shift, mask, num_parts, scanned_hist, totals, nullptr,
-                                                                                 nullptr);
-    else
-        downsweep_body<RSW_ITEMS, false, false, RANK_ATOMIC, false, false, uint2>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n,
-                                                                                  shift, mask, num_parts, scanned_hist, totals, nullptr,
-                                                                                  nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,50 +546,6 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows) {
     hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, hist + (size_t)256 * parts, rows);
     LAUNCH_CHECK(ctx, "k_radix_rowscan");
-    return SPLAT_OK;
-}
-
-// Stable sort of (u32 key, 8-byte payload) elements by key bits [bit_begin, bit_end): same three
-// kernels per pass (4096-element partitions).  hist needs 256*parts+256 words for parts = ceil(n / 4096).  Result side reported as for radix_sort_pairs.
-int radix_sort_wide(splat_ctx *ctx, uint32_t *k0, uint2 *v0, uint32_t *k1, uint2 *v1, uint32_t *hist, uint32_t n,
-                    const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, uint32_t first_bits, bool *result_in_primary) {
-    *result_in_primary = true;
-    if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
-    if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
-    if (first_bits < 1 || first_bits > 8) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: first_bits must be 1..8");
-    {
-        int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
-        if (prc != SPLAT_OK) return prc;
-    }
-    const uint32_t RSW_PART_KEYS = RSW_ITEMS_DEFAULT * RS_THREADS;
-    const uint32_t parts = div_up(n, RSW_PART_KEYS);
-    uint32_t *ki = k0, *ko = k1;
-    uint2 *vi = v0, *vo = v1;
-    bool primary = true;
-    uint32_t shift = bit_begin;
-    for (uint32_t pass = 0; shift < bit_end; ++pass) {
-        const uint32_t want = pass == 0 ? first_bits : 8u;
-        const uint32_t bits = bit_end - shift < want ? bit_end - shift : want;
-        const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_radix_upsweep<false>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
-                           RSW_PART_KEYS, hist);
-        LAUNCH_CHECK(ctx, "k_radix_upsweep");
-        uint32_t *totals = hist + (size_t)256 * parts;
-        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals, mask + 1);
-        LAUNCH_CHECK(ctx, "k_radix_rowscan");
-#define SPLAT_DSW(IT, RA)                                                                                                    \
-    hipLaunchKernelGGL((k_radix_downsweep_wide<IT, RA>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, n_dev, shift, \
-                       mask, parts, hist, totals)
-        const bool ra = ctx->lds_atomic_ordered == 1;
-        if (ra) SPLAT_DSW(RSW_ITEMS_DEFAULT, true); else SPLAT_DSW(RSW_ITEMS_DEFAULT, false);
-#undef SPLAT_DSW
-        LAUNCH_CHECK(ctx, "k_radix_downsweep_wide");
-        uint32_t *t = ki; ki = ko; ko = t;
-        uint2 *u = vi; vi = vo; vo = u;
-        primary = !primary;
-        shift += bits;
-    }
-    *result_in_primary = primary;
     return SPLAT_OK;
 }
 

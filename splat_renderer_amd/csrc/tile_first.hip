@@ -15,9 +15,10 @@
 //
 //   (projector)     per 1024-splat block: pairs per low tile-id digit (first-pass histogram)
 //   k_radix_rowscan digit rows -> block bases, digit totals
-//   k_tf_scatter    expansion fused with the first sort pass      N*8 B read, P*12 B written
-//   radix_sort_wide second (high digit) pass, 8-byte payload      P*(4 + 12 + 12) B
-//   k_tile_offsets / k_tile_counts
+//   k_tf_scatter    expansion fused with the first sort pass      N*8 B read, P*9 B written
+//   k_tf_upsweep2 / k_radix_rowscan / k_tf_downsweep2
+//                   second (high digit) pass, 8-byte payload      P*(1 + 9 + 8) B
+//   k_tf_offsets    tile offsets from the second pass's scanned histogram (no search, no sorted tile ids)
 //   k_tile_sort     per tile: LSD radix on (key - tile min key)    P*8 B read, P*4 B written
 #include "common.h"
 #include "tile_range.h"
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
                                                            const uint32_t *__restrict__ scanned_hist,
                                                            const uint32_t *__restrict__ totals, uint32_t *__restrict__ d_total,
                                                            uint32_t pair_limit, uint32_t *__restrict__ overflow,
-                                                           uint32_t *__restrict__ out_tile, uint2 *__restrict__ out_val) {
+                                                           uint8_t *__restrict__ out_hi, uint2 *__restrict__ out_val,
+                                                           uint32_t lo_bits, uint32_t align_m1, TfRuns runs) {
     __shared__ TfScatterShared sh;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
@@ -165,24 +167,45 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     const uint32_t digit_total = totals[tid];
     const uint32_t row_prefix = tid <= mask ? scanned_hist[(size_t)tid * num_parts + blockIdx.x] : 0u;
 
-    // digit starts = exclusive scan of the digit totals; their sum is this frame's pair total
-    uint32_t gincl = digit_total;
+    // digit starts = exclusive scan of the digit totals, each rounded up to whole partitions of the second pass when
+    // there is one (align_m1 = TF2_PART - 1: every partition then holds pairs of ONE low digit, see k_tf_downsweep2);
+    // the sum of the totals themselves is this frame's pair total
+    const uint32_t digit_room = (digit_total + align_m1) & ~align_m1;
+    uint32_t gincl = digit_total, aincl = digit_room;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t t = __shfl_up(gincl, s);
-        if ((int)lane >= s) gincl += t;
+        const uint32_t t = __shfl_up(gincl, s), a = __shfl_up(aincl, s);
+        if ((int)lane >= s) {
+            gincl += t;
+            aincl += a;
+        }
     }
-    if (lane == 63) sh.wave_sums[w] = gincl;
+    if (lane == 63) {
+        sh.wave_sums[w] = gincl;
+        wsum[w] = aincl;
+    }
     __syncthreads();
-    const uint32_t gprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+    const uint32_t aprefix = (w > 0 ? wsum[0] : 0u) + (w > 1 ? wsum[1] : 0u) + (w > 2 ? wsum[2] : 0u);
     const uint32_t all_pairs = sh.wave_sums[0] + sh.wave_sums[1] + sh.wave_sums[2] + sh.wave_sums[3];
-    if (blockIdx.x == 0 && tid == 0) {
-        d_total[0] = all_pairs;
-        d_total[2] = all_pairs > pair_limit ? 0u : all_pairs;
-        if (all_pairs > pair_limit) atomicOr(overflow, 1u);
+    const uint32_t run_start = aprefix + aincl - digit_room; // where digit tid's pairs start in the output
+    if (blockIdx.x == 0) {
+        const bool fits = all_pairs <= pair_limit;
+        if (tid == 0) {
+            d_total[0] = all_pairs;
+            d_total[2] = fits ? all_pairs : 0u;
+            if (!fits) atomicOr(overflow, 1u);
+        }
+        // the second pass's view of this output: per low digit where its run starts and how many pairs it holds,
+        // per partition the digit it belongs to, and the number of partitions (all zero when the pairs do not fit)
+        runs.start[tid] = fits ? run_start : 0u;
+        runs.total[tid] = fits ? digit_total : 0u;
+        if (align_m1 && fits)
+            for (uint32_t j = 0, first_part = run_start / (align_m1 + 1u); j < digit_room / (align_m1 + 1u); ++j)
+                runs.part_digit[first_part + j] = (uint8_t)tid;
+        if (tid == 255) *runs.parts = (align_m1 && fits) ? (run_start + digit_room) / (align_m1 + 1u) : 0u;
     }
     if (all_pairs > pair_limit) return;
-    __syncthreads(); // wave_sums is reused below
+    __syncthreads(); // wave_sums and wsum are reused below
 
     uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
     if constexpr (TF_PER_THREAD == 4) {
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     const uint32_t total = carry;
     if (total == 0) return;
     // where this block's pairs of digit tid start: digit start + the earlier blocks' share
-    sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix;
+    sh.global_base[tid] = run_start + row_prefix;
     // rounds of TF_STAGE pairs (one round unless the block's splats are unusually large)
     for (uint32_t c0 = 0; c0 < total; c0 += TF_STAGE) {
         const uint32_t cnt = (total - c0 < TF_STAGE) ? total - c0 : TF_STAGE;
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
         for (uint32_t pos = tid; pos < cnt; pos += TF_THREADS) {
             const uint32_t e = stage[pos], slot = e & 1023u, d = (e >> 10) & mask;
             const uint32_t g = sh.global_base[d] + (pos - sh.digit_base[d]);
-            out_tile[g] = e >> 10;
+            out_hi[g] = (uint8_t)(e >> (10u + lo_bits)); // (the low digit is the run the pair sits in)
             out_val[g] = make_uint2(s_key[slot], first + slot);
         }
         if (c0 + TF_STAGE >= total) break; // (the usual case: one round)
@@ -485,11 +508,229 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     return SPLAT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second pass of the tile-id sort (the high digit), for the layout k_tf_scatter leaves: every low digit's run starts
+// on a partition boundary, so a partition holds pairs of ONE low digit and
+//   * a pair carries one byte of tile id (the high digit) instead of four,
+//   * the pass writes no tile ids at all: with hist[h][p] = pairs of high digit h in partition p, scanned over p by
+//     k_radix_rowscan, tile (h, l) starts at  start(h) + scanned[h][first partition of run l]  — every pair with
+//     high digit h in an earlier run has a smaller tile id, every one in run l or later does not.  k_tf_offsets reads
+//     the tile offsets straight out of the scanned histogram; the 65-ary search over the sorted tile ids (10 us at
+//     C2) and the 45 MB of sorted ids it probed are gone, and so are 3 of every 4 key bytes the pass used to move.
+// The price is up to TF2_PART - 1 unused slots at the end of each run of the first pass's output (the second pass's
+// output is dense again).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t TF2_ITEMS = 16, TF2_PART = TF2_ITEMS * TF_THREADS; // 4096 pairs per partition
+static_assert(TF2_PART == TF_RUN_ALIGN, "k_tf_scatter rounds every run up to whole partitions of this pass");
+
+// partition p: which low digit's run it lies in and how many of its TF2_PART slots hold pairs (0: past the end)
+__device__ __forceinline__ uint32_t tf2_valid(const TfRuns &runs, uint32_t p) {
+    if (p >= *runs.parts) return 0u;
+    const uint32_t d = runs.part_digit[p];
+    const uint32_t left = runs.start[d] + runs.total[d] - p * TF2_PART;
+    return left < TF2_PART ? left : TF2_PART;
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_upsweep2(const uint8_t *__restrict__ hi, TfRuns runs, uint32_t hmask,
+                                                           uint32_t num_parts, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t lh[TS_WAVES][256];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, p = blockIdx.x;
+    const uint32_t valid = tf2_valid(runs, p);
+    if (valid == 0) { // (uniform) a column of zeros: the row scans run over all num_parts columns
+        if (tid <= hmask) hist[(size_t)tid * num_parts + p] = 0;
+        return;
+    }
+    const uint8_t *src = hi + (size_t)p * TF2_PART;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid == TF2_PART) v = reinterpret_cast<const uint4 *>(src)[tid]; // (runs start on 4096-byte boundaries)
+    for (uint32_t i = tid; i < TS_WAVES * 256; i += TF_THREADS) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    if (valid == TF2_PART) {
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = q[j] & 255u, b = (q[j] >> 8) & 255u, c = (q[j] >> 16) & 255u, d = q[j] >> 24;
+            if (a == b && b == c && c == d) { // neighbours in the run often share a tile row
+                atomicAdd(&lh[w][a], 4u);
+            } else {
+                atomicAdd(&lh[w][a], 1u);
+                atomicAdd(&lh[w][b], 1u);
+                atomicAdd(&lh[w][c], 1u);
+                atomicAdd(&lh[w][d], 1u);
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < valid; i += TF_THREADS) atomicAdd(&lh[w][src[i]], 1u);
+    }
+    __syncthreads();
+    if (tid <= hmask) hist[(size_t)tid * num_parts + p] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+}
+
+struct TfDownsweepShared {
+    uint32_t wave_hist[TS_WAVES][256];
+    uint32_t global_base[256]; // (where this partition's pairs of each digit start in the output) - (their local start)
+    uint32_t wave_sums[TS_WAVES], wave_gsums[TS_WAVES];
+};
+
+template <bool RANK_ATOMIC>
+__global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *__restrict__ hi_in, const uint2 *__restrict__ val_in,
+                                                                uint2 *__restrict__ val_out, TfRuns runs, uint32_t hmask,
+                                                                uint32_t num_parts, const uint32_t *__restrict__ scanned,
+                                                                const uint32_t *__restrict__ totals) {
+    __shared__ TfDownsweepShared sh;
+    __shared__ uint2 s_val[TF2_PART];
+    __shared__ uint8_t s_dig[TF2_PART];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, p = blockIdx.x;
+    const uint32_t valid = tf2_valid(runs, p);
+    if (valid == 0) return;
+    for (uint32_t i = tid; i < TS_WAVES * 256; i += TF_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+    const uint32_t row_prefix = tid <= hmask ? scanned[(size_t)tid * num_parts + p] : 0u; // digit tid in earlier partitions
+    const uint32_t digit_total = totals[tid];                                              // ... and in the whole frame
+    // wave-striped: item i of lane l of wave w is element w * 1024 + i * 64 + l, the order the ranking preserves.
+    // Slots past `valid` read the last pair and rank as digit 255 behind every real one: they end up past `valid`
+    // in the reordered partition and are not written.
+    const size_t base = (size_t)p * TF2_PART;
+    const uint32_t wbase = w * (TF2_ITEMS * 64) + lane;
+    uint32_t dig[TF2_ITEMS];
+    uint2 val[TF2_ITEMS];
+#pragma unroll
+    for (uint32_t i = 0; i < TF2_ITEMS; ++i) {
+        const uint32_t q = wbase + i * 64;
+        const uint32_t c = q < valid ? q : valid - 1;
+        dig[i] = q < valid ? (uint32_t)hi_in[base + c] : 255u;
+        val[i] = val_in[base + c];
+    }
+    // a partition dominated by one digit (a scene bunched up in a few tile rows) ranks faster with ballots: returning
+    // LDS atomics that collide on one counter serialise (see radix_sort.hip)
+    bool use_atomic = RANK_ATOMIC;
+    if (RANK_ATOMIC) {
+        const uint32_t next = tid > hmask ? 0u : (p + 1 < num_parts) ? scanned[(size_t)tid * num_parts + p + 1] : digit_total;
+        use_atomic = !__syncthreads_or((next - row_prefix) > TF2_PART / 4);
+    } else {
+        __syncthreads();
+    }
+    uint32_t rank[TF2_ITEMS];
+    if (use_atomic) {
+#pragma unroll
+        for (uint32_t i = 0; i < TF2_ITEMS; ++i) rank[i] = wave_rank<true>(sh.wave_hist[w], dig[i]);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < TF2_ITEMS; ++i) rank[i] = wave_rank<false>(sh.wave_hist[w], dig[i]);
+    }
+    __syncthreads();
+    const uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
+    const uint32_t dcount = (c0 + c1) + (c2 + c3);
+    // exclusive scans over the 256 digits of the partition's counts (local starts) and, in the same shuffles, of the
+    // frame's digit totals (where each digit's run starts in the output)
+    uint32_t incl = dcount, gincl = digit_total;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t t = __shfl_up(incl, s), g = __shfl_up(gincl, s);
+        if ((int)lane >= s) {
+            incl += t;
+            gincl += g;
+        }
+    }
+    if (lane == 63) {
+        sh.wave_sums[w] = incl;
+        sh.wave_gsums[w] = gincl;
+    }
+    __syncthreads();
+    const uint32_t wprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+    const uint32_t gprefix = (w > 0 ? sh.wave_gsums[0] : 0u) + (w > 1 ? sh.wave_gsums[1] : 0u) + (w > 2 ? sh.wave_gsums[2] : 0u);
+    const uint32_t local_start = wprefix + incl - dcount;
+    sh.wave_hist[0][tid] = local_start;
+    sh.wave_hist[1][tid] = local_start + c0;
+    sh.wave_hist[2][tid] = local_start + c0 + c1;
+    sh.wave_hist[3][tid] = local_start + c0 + c1 + c2;
+    sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix - local_start;
+    __syncthreads();
+    // reorder inside the partition: same-digit pairs become contiguous, stable
+#pragma unroll
+    for (uint32_t i = 0; i < TF2_ITEMS; ++i) {
+        const uint32_t pos = sh.wave_hist[w][dig[i]] + rank[i];
+        s_val[pos] = val[i];
+        s_dig[pos] = (uint8_t)dig[i];
+    }
+    __syncthreads();
+    // consecutive lanes write consecutive addresses inside each digit run
+#pragma unroll
+    for (uint32_t j = 0; j < TF2_ITEMS; ++j) {
+        const uint32_t pos = j * TF_THREADS + tid;
+        if (pos < valid) val_out[sh.global_base[s_dig[pos]] + pos] = s_val[pos];
+    }
+}
+
+// offsets[t] for t = 0 .. tiles (offsets[tiles] = the pair total), and the sync-free frame's report to the host.
+// hi_bits == 0: one pass sorted the pairs and left dense runs, one per tile: offsets = run starts.
+__global__ __launch_bounds__(256) void k_tf_offsets(uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, TfRuns runs,
+                                                    uint32_t num_parts, const uint32_t *__restrict__ scanned,
+                                                    const uint32_t *__restrict__ totals, uint32_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ d_total, uint32_t *report, uint32_t seq) {
+    __shared__ uint32_t hstart[256];
+    __shared__ uint32_t wsums[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (report && blockIdx.x == 0 && tid == 0) tile_report(d_total, report, seq);
+    const uint32_t t = blockIdx.x * 256u + tid;
+    const uint32_t total = d_total[2];
+    if (hi_bits == 0) {
+        if (t <= tiles) offsets[t] = t < tiles ? runs.start[t] : total;
+        return;
+    }
+    // start of every high digit's run in the sorted order: exclusive scan of the second pass's digit totals
+    const uint32_t mine = totals[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t v = __shfl_up(incl, s);
+        if ((int)lane >= s) incl += v;
+    }
+    if (lane == 63) wsums[w] = incl;
+    __syncthreads();
+    hstart[tid] = (w > 0 ? wsums[0] : 0u) + (w > 1 ? wsums[1] : 0u) + (w > 2 ? wsums[2] : 0u) + incl - mine;
+    __syncthreads();
+    if (t > tiles) return;
+    if (t == tiles) {
+        offsets[t] = total;
+        return;
+    }
+    const uint32_t h = t >> lo_bits, l = t & ((1u << lo_bits) - 1u);
+    const uint32_t first_part = runs.start[l] / TF2_PART; // (an empty run starts where the next one does)
+    offsets[t] = hstart[h] + (first_part < num_parts ? scanned[(size_t)h * num_parts + first_part] : totals[h]);
+}
+
+// The second pass and the tile offsets.  hist: 256 * num_parts + 256 words, num_parts = tf2_parts_bound(pairs bound,
+// low digits).  hi_bits == 0: only the offsets (the first pass's output is final).
+int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in, uint2 *val_out, const TfRuns *runs, uint32_t pairs_bound,
+                          uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total,
+                          uint32_t *report, uint32_t seq) {
+    const uint32_t num_parts = tf2_parts_bound(pairs_bound, lo_bits);
+    uint32_t *totals = hist + (size_t)256 * num_parts;
+    if (hi_bits > 0) {
+        const uint32_t hmask = (1u << hi_bits) - 1u;
+        hipLaunchKernelGGL(k_tf_upsweep2, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, *runs, hmask, num_parts, hist);
+        LAUNCH_CHECK(ctx, "k_tf_upsweep2");
+        int rc = radix_rowscan_launch(ctx, hist, num_parts, hmask + 1u);
+        if (rc != SPLAT_OK) return rc;
+        if (ctx->lds_atomic_ordered == 1)
+            hipLaunchKernelGGL(k_tf_downsweep2<true>, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask,
+                               num_parts, hist, totals);
+        else
+            hipLaunchKernelGGL(k_tf_downsweep2<false>, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask,
+                               num_parts, hist, totals);
+        LAUNCH_CHECK(ctx, "k_tf_downsweep2");
+    }
+    hipLaunchKernelGGL(k_tf_offsets, dim3(div_up(tiles + 1, 256)), dim3(256), 0, ctx->stream, tiles, lo_bits, hi_bits, *runs, num_parts, hist,
+                       totals, offsets, d_total, report, seq);
+    LAUNCH_CHECK(ctx, "k_tf_offsets");
+    return SPLAT_OK;
+}
+
 // hist: the digit histogram the projector (k_project_hist) or the band prepare kernel counted, after
 // radix_rowscan_launch (rows scanned in place, digit totals behind them)
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
-                      const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint32_t *out_tile,
-                      uint2 *out_val, uint32_t block_splats) {
+                      const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint8_t *out_hi,
+                      uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs) {
     const uint32_t parts = div_up(n, block_splats);
     const uint32_t *totals = hist + (size_t)256 * parts;
     {
@@ -499,7 +740,7 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
     const bool ra = ctx->lds_atomic_ordered == 1;
 #define SPLAT_TF_SCATTER(RA, PER)                                                                                                 \
     hipLaunchKernelGGL((k_tf_scatter<RA, PER>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
-                       hist, totals, d_total, pair_limit, overflow, out_tile, out_val)
+                       hist, totals, d_total, pair_limit, overflow, out_hi, out_val, lo_bits, second_pass ? TF_RUN_ALIGN - 1u : 0u, *runs)
     if (block_splats == TF_BLOCK_SMALL) {
         if (ra) SPLAT_TF_SCATTER(true, 1);
         else SPLAT_TF_SCATTER(false, 1);
