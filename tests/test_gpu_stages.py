@@ -809,6 +809,28 @@ def test_tile_first_wide_depth_range_inside_a_tile(device, n, rs, cls):
         o.destroy()
 
 
+def test_tile_first_sixteen_bit_tile_ids(device):
+    """The largest screen the fast path takes: 256 x 256 tiles, tile ids of 16 bits sorted as 8 + 8.  The bottom tile
+    row is high digit 255 — the digit the second pass's padding slots borrow (they rank behind every real pair of a
+    partition) — and with 65536 tiles for 390 000 pairs almost every partition of the second pass is a partial one."""
+    n, w, h = 6000, 4096, 4096
+    props, normals, u = make_case(n, w, h, 91, 0.1, camera=dict(distance=1.6))
+    ref = oracle_pipeline(props, normals, u, w, h)
+    counts = ref["counts"].reshape(256, 256)
+    assert counts[255].sum() > 500 and counts[0].sum() > 500 and counts[:, 255].sum() > 500
+    r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h, want_float=False)
+    total = ref["indices"].shape[0]
+    assert r.binner.getTotalIndices() == total
+    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
+    assert np.array_equal(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    r.render(u, pbuf, nbuf, None, w, h)  # and again, sync-free
+    r.finish()
+    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    for o in (r, pbuf, nbuf):
+        o.destroy()
+
+
 def test_tile_first_sync_free_repeat_and_overflow(device):
     n, w, h = 20000, 320, 200
     small, normals, u = make_case(n, w, h, 61, 0.5)
