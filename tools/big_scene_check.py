@@ -23,7 +23,9 @@ for order in ("tileFirst", "sortFirst"):
     assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32))
     idx = r.binner.getTileIndicesBuffer().read(np.uint32, total)
     proj = r.projector.getProjectedBuffer().read(np.float32).reshape(n, 8)
-    depth = proj[idx, 4]
+    # (the frame leaves lit composite records {centre.xy, radius, depth | lit rgb, opacity} by default: depth is float 3;
+    # ProjectedSplat records keep it in float 4)
+    depth = proj[idx, 3 if r.recordFormat == sr._lib.RECORDS_LIT32 else 4]
     dd = np.diff(depth); starts = offsets[counts > 0][1:]
     bad = np.nonzero((dd < 0) | ((dd == 0) & (np.diff(idx.astype(np.int64)) <= 0)))[0] + 1
     assert np.isin(bad, starts).all()
