@@ -1297,6 +1297,42 @@ def test_abi_all_gather_serves_the_band_renderer(device):
     stages.destroy()
 
 
+def test_frame_loop_dolly_in_and_out_sync_free(device):
+    """Thirty frames enqueued without reading anything back in between, the camera dollying in and out so that the pair
+    total swings by more than the sync-free headroom (12.5 %) frame over frame: frames whose pairs outgrow the limit
+    sized from the frame before are caught at the next call and rendered again.  Every seventh frame's lists (four
+    different camera distances) and the last checked frame's pixels against the oracle; the layout of the first sort pass (runs aligned to the second pass's
+    partitions) moves with every frame's digit totals."""
+    n, w, h = 60000, 480, 272
+    props, normals, _ = make_case(n, w, h, 77, 1.0)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    loop = sr.FrameLoop(device, n, w, h)
+    totals, overflowed = [], 0
+    for k in range(30):
+        u = loop.camera.uniforms(w, h, time=k / 60.0).copy()
+        loop.render(pbuf, nbuf)
+        overflowed += int(loop.renderer.previousFrameOverflowed)
+        loop.renderer.previousFrameOverflowed = False
+        if k % 7 == 6:
+            total = loop.renderer.finish()
+            overflowed += int(loop.renderer.previousFrameOverflowed)
+            loop.renderer.previousFrameOverflowed = False
+            ref = oracle_pipeline(props, normals, u, w, h)
+            assert total == ref["indices"].shape[0], k
+            assert np.array_equal(loop.renderer.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), k
+            totals.append(total)
+            if k == 27:
+                _, want8, _, _, near = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"],
+                                                   ref["counts"], ref["offsets"], w, h, want_stops=True)
+                d8 = np.abs(loop.readPixels().astype(int) - want8.astype(int)).max(axis=2)
+                assert d8[near == 0].max() <= 1 and d8.max() <= 3
+        loop.camera.zoom(-0.45 if (k // 3) % 2 == 0 else 0.45)  # three steps in, three steps out
+    assert overflowed >= 1, "the dolly must outgrow the sync-free limit at least once"
+    assert max(totals) > 1.2 * min(totals)
+    for o in (loop, pbuf, nbuf):
+        o.destroy()
+
+
 def test_headless_frame_loop_orbits_the_camera(device, tmp_path):
     """the frame loop of src/main.ts:110-193 without a browser.  Four frames of an orbit
     (Camera.rotate, then a pan, a zoom and a drag through OrbitCameraController), enqueued back to back — the second
