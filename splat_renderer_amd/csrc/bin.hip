@@ -401,14 +401,17 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         // first pass of the tile-id sort, fused with the expansion (tile_first.hip); later kernels take
         // their pair count from d_total[2], which k_tf_scatter sets (0 if the pairs do not fit)
         const uint32_t tf_hi_bits = tf_bits - tf_lo_bits;
+        uint32_t *report = async ? b->pinned_dev : nullptr;
+        const uint32_t seq = async ? ++b->seq : 0u;
         rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
-                               b->d_total + 1, b->tf_hi, b->wide_a, b->tf_block, tf_lo_bits, tf_hi_bits > 0, &b->tf_runs);
+                               b->d_total + 1, b->tf_hi, b->wide_a, b->tf_block, tf_lo_bits, tf_hi_bits > 0, &b->tf_runs, b->offsets, tiles,
+                               report, seq);
         if (rc != SPLAT_OK) return rc;
         // second pass (high digit) into wide_b, and the tile offsets out of its histogram; a screen of at most 256
-        // tiles is sorted by the first pass alone
+        // tiles is sorted by the first pass alone (which then writes the offsets too)
         const bool primary = tf_hi_bits == 0;
         rc = tf_second_pass_launch(ctx, b->tf_hi, b->wide_a, b->wide_b, &b->tf_runs, total32, tiles, tf_lo_bits, tf_hi_bits, b->tf2_hist,
-                                   b->offsets, b->d_total, async ? b->pinned_dev : nullptr, async ? ++b->seq : 0u);
+                                   b->offsets, b->d_total, report, seq);
         if (rc != SPLAT_OK) return rc;
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
         // (its first launch also writes the tile counts)

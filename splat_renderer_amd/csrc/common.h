@@ -203,7 +203,8 @@ int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-t
 // tile_first.hip (the frame path's bin-then-sort-per-tile kernels) and the wide-payload radix sort
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint8_t *out_hi,
-                      uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs);
+                      uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs,
+                      uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq);
 int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in, uint2 *val_out, const TfRuns *runs, uint32_t pairs_bound,
                           uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total,
                           uint32_t *report, uint32_t seq);

@@ -141,7 +141,9 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
                                                            const uint32_t *__restrict__ totals, uint32_t *__restrict__ d_total,
                                                            uint32_t pair_limit, uint32_t *__restrict__ overflow,
                                                            uint8_t *__restrict__ out_hi, uint2 *__restrict__ out_val,
-                                                           uint32_t lo_bits, uint32_t align_m1, TfRuns runs) {
+                                                           uint32_t lo_bits, uint32_t align_m1, TfRuns runs,
+                                                           uint32_t *__restrict__ offsets_out, uint32_t tiles, uint32_t *report,
+                                                           uint32_t seq) {
     __shared__ TfScatterShared sh;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
@@ -203,6 +205,15 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
             for (uint32_t j = 0, first_part = run_start / (align_m1 + 1u); j < digit_room / (align_m1 + 1u); ++j)
                 runs.part_digit[first_part + j] = (uint8_t)tid;
         if (tid == 255) *runs.parts = (align_m1 && fits) ? (run_start + digit_room) / (align_m1 + 1u) : 0u;
+        // a screen of at most 256 tiles is sorted by this pass alone and its (dense) runs ARE the tiles: the tile
+        // offsets and the sync-free frame's report go out from here, and no k_tf_offsets is launched for them
+        if (offsets_out) {
+            if (tid < tiles) offsets_out[tid] = fits ? run_start : 0u;
+            if (tid == 0) {
+                offsets_out[tiles] = fits ? all_pairs : 0u;
+                if (report) tile_report(d_total, report, seq);
+            }
+        }
     }
     if (all_pairs > pair_limit) return;
     __syncthreads(); // wave_sums and wsum are reused below
@@ -493,7 +504,18 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
         if (prc != SPLAT_OK) return prc;
     }
     const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
-    if (ctx->lds_atomic_ordered == 1) {
+    // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
+    // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
+    // a tenth of a C0 frame).
+    const bool one_class = tiles <= 3u * 256u;
+    if (one_class) {
+        if (ctx->lds_atomic_ordered == 1)
+            hipLaunchKernelGGL((k_tile_sort<true, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
+                               scratch, out_idx, counts);
+        else
+            hipLaunchKernelGGL((k_tile_sort<false, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
+                               scratch, out_idx, counts);
+    } else if (ctx->lds_atomic_ordered == 1) {
         hipLaunchKernelGGL((k_tile_sort<true, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
                            scratch, out_idx, counts);
         hipLaunchKernelGGL((k_tile_sort<true, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
@@ -662,7 +684,7 @@ __global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *
 }
 
 // offsets[t] for t = 0 .. tiles (offsets[tiles] = the pair total), and the sync-free frame's report to the host.
-// hi_bits == 0: one pass sorted the pairs and left dense runs, one per tile: offsets = run starts.
+// (A screen of at most 256 tiles has no second pass: its dense runs are the tiles, and k_tf_scatter writes both.)
 __global__ __launch_bounds__(256) void k_tf_offsets(uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, TfRuns runs,
                                                     uint32_t num_parts, const uint32_t *__restrict__ scanned,
                                                     const uint32_t *__restrict__ totals, uint32_t *__restrict__ offsets,
@@ -673,10 +695,6 @@ __global__ __launch_bounds__(256) void k_tf_offsets(uint32_t tiles, uint32_t lo_
     if (report && blockIdx.x == 0 && tid == 0) tile_report(d_total, report, seq);
     const uint32_t t = blockIdx.x * 256u + tid;
     const uint32_t total = d_total[2];
-    if (hi_bits == 0) {
-        if (t <= tiles) offsets[t] = t < tiles ? runs.start[t] : total;
-        return;
-    }
     // start of every high digit's run in the sorted order: exclusive scan of the second pass's digit totals
     const uint32_t mine = totals[tid];
     uint32_t incl = mine;
@@ -720,6 +738,7 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
                                num_parts, hist, totals);
         LAUNCH_CHECK(ctx, "k_tf_downsweep2");
     }
+    if (hi_bits == 0) return SPLAT_OK; // (k_tf_scatter wrote the offsets and the report itself)
     hipLaunchKernelGGL(k_tf_offsets, dim3(div_up(tiles + 1, 256)), dim3(256), 0, ctx->stream, tiles, lo_bits, hi_bits, *runs, num_parts, hist,
                        totals, offsets, d_total, report, seq);
     LAUNCH_CHECK(ctx, "k_tf_offsets");
@@ -730,7 +749,8 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
 // radix_rowscan_launch (rows scanned in place, digit totals behind them)
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint8_t *out_hi,
-                      uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs) {
+                      uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs,
+                      uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq) {
     const uint32_t parts = div_up(n, block_splats);
     const uint32_t *totals = hist + (size_t)256 * parts;
     {
@@ -740,7 +760,8 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
     const bool ra = ctx->lds_atomic_ordered == 1;
 #define SPLAT_TF_SCATTER(RA, PER)                                                                                                 \
     hipLaunchKernelGGL((k_tf_scatter<RA, PER>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
-                       hist, totals, d_total, pair_limit, overflow, out_hi, out_val, lo_bits, second_pass ? TF_RUN_ALIGN - 1u : 0u, *runs)
+                       hist, totals, d_total, pair_limit, overflow, out_hi, out_val, lo_bits, second_pass ? TF_RUN_ALIGN - 1u : 0u, *runs,         \
+                       second_pass ? nullptr : offsets_if_final, tiles, report, seq)
     if (block_splats == TF_BLOCK_SMALL) {
         if (ra) SPLAT_TF_SCATTER(true, 1);
         else SPLAT_TF_SCATTER(false, 1);
