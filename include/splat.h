@@ -369,6 +369,14 @@ int splat_sdf_scale_factors(splat_ctx *ctx, const splat_sdf_instr *program, uint
 /* vec4(normalize(gradient), scale factor): the "curvatureData" layout splat_update_props reads
  * (src/SplatPropertyManager.ts:70-72; the reference's samplers write the two halves to separate buffers). */
 int splat_sdf_curvature(splat_ctx *ctx, const void *gradients, const void *scale_factors, uint32_t n, void *curvature);
+/* PointManager.generateRandomPositions (src/PointManager.ts:96-189) on the device: n points on the faces of the box
+ * [aabb_min, aabb_max] (the caller's scaled global AABB of the scene: host floats), a face chosen with probability
+ * proportional to its area, uniform on the face, w = 0.  The reference draws them from an unseeded Math.random on the
+ * CPU and uploads them every frame (:220-231); here point i of a cloud is a pure function of (seed, i) — a 64-bit
+ * counter hash (splitmix64 of seed * 0x9E3779B97F4A7C15 + 2 i and + 2 i + 1), 24 bits per uniform — so a frame's fresh
+ * cloud costs one small kernel and no transfer, and the oracle restates it bit for bit (orc_sdf_seed_positions). */
+int splat_sdf_seed_positions(splat_ctx *ctx, const float *aabb_min3, const float *aabb_max3, uint32_t n, uint64_t seed,
+                             void *positions);
 
 /* ---- the multi-GPU frame's one exchange (no reference equivalent): RCCL over xGMI ------------------
  * One process per GPU.  Rank 0 makes a unique id (splat_comm_unique_id) and hands its SPLAT_COMM_ID_BYTES to the

@@ -943,3 +943,35 @@ void orc_sdf_curvature(const float *gradients, const float *scale_factors, uint3
         if (len > 0.0001f) { o[0] = g[1] / len; o[1] = g[2] / len; o[2] = g[3] / len; }
     }
 }
+
+/* PointManager.generateRandomPositions (/root/reference/src/PointManager.ts:96-189) with the product's seeded generator
+ * (include/splat.h: splat_sdf_seed_positions): the reference draws from an unseeded Math.random, so only the
+ * distribution can follow it — a face of the box by area (:108-131), uniform on it (:133-186), w = 0 — and the draw itself
+ * is defined here: point i of cloud `seed` uses two splitmix64 outputs of the counter seed * 0x9E3779B97F4A7C15 + 2 i (+ 1),
+ * 24 bits per uniform.  One rounding per operation (built with -ffp-contract=off). */
+static uint64_t orc_splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void orc_sdf_seed_positions(const float *mn, const float *mx, uint32_t n, uint64_t seed, float *positions) {
+    const float k24 = 1.0f / 16777216.0f;
+    const float d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    const float ax = d[1] * d[2], ay = d[0] * d[2], az = d[0] * d[1];
+    const float c0 = ax, c1 = c0 + ax, c2 = c1 + ay, c3 = c2 + ay, c4 = c3 + az, c5 = c4 + az;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t base = seed * 0x9E3779B97F4A7C15ull + 2ull * i;
+        const uint64_t a = orc_splitmix64(base), b = orc_splitmix64(base + 1ull);
+        const float u0 = (float)(uint32_t)(a >> 40) * k24, u1 = (float)(uint32_t)((a >> 16) & 0xffffffu) * k24;
+        const float u2 = (float)(uint32_t)(b >> 40) * k24, u3 = (float)(uint32_t)((b >> 16) & 0xffffffu) * k24;
+        const float t = u0 * c5;
+        const uint32_t face = t < c0 ? 0u : t < c1 ? 1u : t < c2 ? 2u : t < c3 ? 3u : t < c4 ? 4u : 5u;
+        float p[3] = {mn[0] + u1 * d[0], mn[1] + u2 * d[1], mn[2] + u3 * d[2]};
+        p[face >> 1] = (face & 1u) ? mx[face >> 1] : mn[face >> 1];
+        positions[4 * i] = p[0];
+        positions[4 * i + 1] = p[1];
+        positions[4 * i + 2] = p[2];
+        positions[4 * i + 3] = 0.0f;
+    }
+}

@@ -144,6 +144,7 @@ void orc_sdf_gradients(const orc_sdf_instr *prog, uint32_t n_instr, const float 
 void orc_sdf_update_positions(const float *positions, const float *gradients, uint32_t n, float *next_positions);
 void orc_sdf_scale_factors(const orc_sdf_instr *prog, uint32_t n_instr, const float *positions, uint32_t n, float *scale_factors);
 void orc_sdf_curvature(const float *gradients, const float *scale_factors, uint32_t n, float *curvature);
+void orc_sdf_seed_positions(const float *mn, const float *mx, uint32_t n, uint64_t seed, float *positions);
 
 /* Whole frame for timing (project -> keys -> sort -> binSorted -> composite model A). Scratch is
  * allocated inside; returns 0 or -1 on allocation failure. P is written to *total_pairs. */

@@ -68,6 +68,7 @@ def lib():
         L.orc_sdf_update_positions.argtypes = [fp, fp, C.c_uint32, fp]
         L.orc_sdf_scale_factors.argtypes = [C.c_void_p, C.c_uint32, fp, C.c_uint32, fp]
         L.orc_sdf_curvature.argtypes = [fp, fp, C.c_uint32, fp]
+        L.orc_sdf_seed_positions.argtypes = [fp, fp, C.c_uint32, C.c_uint64, fp]
         L.orc_unorm8.argtypes = [C.c_float]
         L.orc_unorm8.restype = C.c_uint8
         _lib = L
@@ -326,6 +327,14 @@ def sdf_scale_factors(program, positions):
     positions = _c32(positions)
     out = np.zeros(positions.shape[0], np.float32)
     lib().orc_sdf_scale_factors(rec.ctypes.data, len(rec), _f(positions), positions.shape[0], _f(out))
+    return out
+
+
+def sdf_seed_positions(aabb_min, aabb_max, n, seed):
+    """(n, 4) f32 points on the faces of the box, the product's seeded generator (splat_sdf_seed_positions)."""
+    mn, mx = np.ascontiguousarray(aabb_min, np.float32), np.ascontiguousarray(aabb_max, np.float32)
+    out = np.zeros((n, 4), np.float32)
+    lib().orc_sdf_seed_positions(_f(mn), _f(mx), n, int(seed) & 0xFFFFFFFFFFFFFFFF, _f(out))
     return out
 
 

@@ -226,6 +226,40 @@ static int sdf_load(splat_ctx *ctx, const splat_sdf_instr *program, uint32_t n_i
     return SPLAT_OK;
 }
 
+// ---- PointManager.generateRandomPositions on the device (splat.h: splat_sdf_seed_positions) ------------------------
+struct SeedBox {
+    float mn[3], mx[3];
+};
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_sdf_seed_positions(SeedBox box, uint32_t n, uint64_t seed, float4 *__restrict__ positions) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t base = seed * 0x9E3779B97F4A7C15ull + 2ull * i;
+    const uint64_t a = splitmix64(base), b = splitmix64(base + 1ull);
+    const float k24 = 1.0f / 16777216.0f; // 24 bits per uniform: exact in binary32, [0, 1)
+    const float u0 = (float)(uint32_t)(a >> 40) * k24, u1 = (float)(uint32_t)((a >> 16) & 0xffffffu) * k24;
+    const float u2 = (float)(uint32_t)(b >> 40) * k24, u3 = (float)(uint32_t)((b >> 16) & 0xffffffu) * k24;
+    const float d[3] = {box.mx[0] - box.mn[0], box.mx[1] - box.mn[1], box.mx[2] - box.mn[2]};
+    // faces -x, +x, -y, +y, -z, +z, each with its area (PointManager.ts:108-131); one rounding per operation
+    const float ax = d[1] * d[2], ay = d[0] * d[2], az = d[0] * d[1];
+    const float c0 = ax, c1 = c0 + ax, c2 = c1 + ay, c3 = c2 + ay, c4 = c3 + az, c5 = c4 + az;
+    const float t = u0 * c5;
+    const uint32_t face = t < c0 ? 0u : t < c1 ? 1u : t < c2 ? 2u : t < c3 ? 3u : t < c4 ? 4u : 5u;
+    float p[3] = {box.mn[0] + u1 * d[0], box.mn[1] + u2 * d[1], box.mn[2] + u3 * d[2]};
+    const uint32_t axis = face >> 1;
+    const float pinned = (face & 1u) ? box.mx[axis] : box.mn[axis];
+    if (axis == 0) p[0] = pinned;
+    else if (axis == 1) p[1] = pinned;
+    else p[2] = pinned;
+    positions[i] = make_float4(p[0], p[1], p[2], 0.0f);
+}
+
 extern "C" {
 
 int splat_sdf_gradients(splat_ctx *ctx, const splat_sdf_instr *program, uint32_t n_instr, const void *positions, uint32_t n,
@@ -274,6 +308,22 @@ int splat_sdf_curvature(splat_ctx *ctx, const void *gradients, const void *scale
     hipLaunchKernelGGL(k_sdf_curvature, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, (const float4 *)gradients,
                        (const float *)scale_factors, n, (float4 *)curvature);
     LAUNCH_CHECK(ctx, "k_sdf_curvature");
+    return SPLAT_OK;
+}
+
+int splat_sdf_seed_positions(splat_ctx *ctx, const float *aabb_min3, const float *aabb_max3, uint32_t n, uint64_t seed,
+                             void *positions) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, aabb_min3 && aabb_max3 && (n == 0 || positions));
+    ARG_CHECK(ctx, (((uintptr_t)positions) & 15) == 0);
+    if (n == 0) return SPLAT_OK;
+    SeedBox box;
+    for (int a = 0; a < 3; ++a) {
+        box.mn[a] = aabb_min3[a];
+        box.mx[a] = aabb_max3[a];
+    }
+    hipLaunchKernelGGL(k_sdf_seed_positions, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, box, n, seed, (float4 *)positions);
+    LAUNCH_CHECK(ctx, "k_sdf_seed_positions");
     return SPLAT_OK;
 }
 

@@ -142,11 +142,11 @@ class SdfSplatSource:
 
     ITERATIONS = 5  # main.ts:149
 
-    def __init__(self, device, scene, seed=0):
+    def __init__(self, device, scene, seed=0, seeding="device"):
         from .host import PointManager, SplatPropertyManager
         from .sdf import CurvatureSampler, GradientSampler, PositionUpdater
         self.device, self.scene = device, scene
-        self.pointManager = PointManager(device, scene, seed)
+        self.pointManager = PointManager(device, scene, seed, seeding)
         n = self.numPoints = self.pointManager.getNumPoints()
         self.gradientSampler = GradientSampler(device, scene, n)
         self.curvatureSampler = CurvatureSampler(device, scene, n)

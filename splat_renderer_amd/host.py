@@ -153,12 +153,18 @@ class PointManager:
       * an SDFScene (splat_renderer_amd.sdf): the reference's constructor — point count from the primitives' surface
         areas (:22-39), positions on the faces of the scene's global AABB (:96-189), fresh ones at every
         reinitialize() (:220-231) — from a SEEDED generator (`seed`, then seed+1, ...: the reference's Math.random
-        clouds cannot be reproduced);
+        clouds cannot be reproduced).  seeding="device" (default): the cloud is drawn by a kernel
+        (splat_sdf_seed_positions: point i a pure function of (seed, i); nothing crosses PCIe — the reference's
+        per-frame CPU draw + upload was 4.6 of the 4.7 ms its own demo frame took here); seeding="host": NumPy's
+        PCG64 on the CPU and an upload (sdf.seed_positions);
       * an (n,4) f32 position array, which reinitialize() uploads again; or an int: the bench scene of that seed."""
 
-    def __init__(self, device, scene, seed=0):
+    def __init__(self, device, scene, seed=0, seeding="device"):
         self.device = device
         self.scene, self._seed, self._positions = None, seed, None
+        if seeding not in ("device", "host"):
+            raise SplatError(-1, f"seeding must be 'device' or 'host', not {seeding!r}")
+        self.seeding = seeding
         if hasattr(scene, "getPrimitives"):
             from . import sdf
             if not scene.getPrimitives():
@@ -179,6 +185,14 @@ class PointManager:
     def reinitialize(self):  # :220-231
         if self.scene is not None:
             from . import sdf
+            if self.seeding == "device":
+                mn, mx = sdf.seeding_box(self.scene)
+                fp = C.POINTER(C.c_float)
+                check(self.device.lib.splat_sdf_seed_positions(self.device.ctx, mn.ctypes.data_as(fp), mx.ctypes.data_as(fp), self.numPoints,
+                                                               int(self._seed) & 0xFFFFFFFFFFFFFFFF, self._buffers[self._current].ptr),
+                      self.device.ctx)
+                self._seed += 1
+                return
             self._positions = sdf.seed_positions(self.scene, self.numPoints, self._seed)
             self._seed += 1
         self._buffers[self._current].write(self._positions)

@@ -13,7 +13,7 @@ export class Camera {
   setAspect(aspect: number): void; rotate(deltaAzimuth: number, deltaElevation: number): void; zoom(deltaDistance: number): void; pan(deltaX: number, deltaY: number): void;
   getViewProjectionMatrix(): Float32Array; getPosition(): Float32Array; uniforms(width: number, height: number, time?: number): Float32Array;
 }
-export class PointManager { constructor(device: Device, scene: Float32Array | { numPoints: number; seed?: number }); reinitialize(): void; swap(): void; getCurrentPositionBuffer(): Buffer; getNextPositionBuffer(): Buffer; getNumPoints(): number; destroy(): void; }
+export class PointManager { constructor(device: Device, scene: Float32Array | { numPoints: number; seed?: number } | SDFScene, seed?: number); reinitialize(): void; swap(): void; getCurrentPositionBuffer(): Buffer; getNextPositionBuffer(): Buffer; getNumPoints(): number; destroy(): void; }
 export interface SceneNode { type: "primitive" | "operation"; }
 export class Sphere { constructor(params?: { id?: string; position?: ArrayLike<number>; radius?: number }); id: string; position: Float32Array; radius: number; }
 export class Box { constructor(params?: { id?: string; position?: ArrayLike<number>; size?: ArrayLike<number> }); id: string; position: Float32Array; size: Float32Array; }

@@ -349,20 +349,40 @@ class Camera {
  * SDF surface (out of scope: upstream splat generation); here `scene` is a Float32Array of vec4 positions, or
  * {numPoints, seed} for a deterministic uniform cloud in [-1,1]^3, and reinitialize() uploads it again. */
 class PointManager {
-  constructor(device, scene) {
-    this.device = device;
-    if (scene instanceof Float32Array) { this.positions = scene; } else {
+  // (device, Float32Array of vec4 positions) | (device, { numPoints, seed }) | (device, SDFScene[, seed]): the reference's constructor —
+  // point count from the primitives' surface areas (src/PointManager.ts:22-39), a fresh cloud on the faces of the scene's scaled box
+  // at every reinitialize() (:96-189, :220-231), drawn on the device (native.sdf_seed_positions: point i a pure function of (seed, i))
+  constructor(device, scene, seed = 0) {
+    this.device = device; this.scene = null; this.seed = seed;
+    if (scene instanceof Float32Array) { this.positions = scene; this.numPoints = scene.length / 4; } else if (scene && typeof scene.getPrimitives === 'function') {
+      const prims = scene.getPrimitives();
+      if (!prims.length) throw new Error('Scene must have at least one primitive'); // :47-49
+      this.scene = scene;
+      this.numPoints = Math.max(10000, Math.min(prims.reduce((t, p) => t + Math.floor(30000 * Math.sqrt(p.getSurfaceArea())), 0), 200000)); // :22-39
+    } else {
       const n = scene.numPoints; let state = (scene.seed === undefined ? 1 : scene.seed) >>> 0 || 1;
       const next = () => { state ^= state << 13; state >>>= 0; state ^= state >>> 17; state ^= state << 5; state >>>= 0; return state / 4294967296; }; // xorshift32
       this.positions = new Float32Array(n * 4);
       for (let i = 0; i < n; i++) { this.positions[i * 4] = next() * 2 - 1; this.positions[i * 4 + 1] = next() * 2 - 1; this.positions[i * 4 + 2] = next() * 2 - 1; this.positions[i * 4 + 3] = 1; }
+      this.numPoints = n;
     }
-    this.numPoints = this.positions.length / 4;
     this.buffers = [device.createBuffer(this.numPoints * 16), device.createBuffer(this.numPoints * 16)];
     this.current = 0;
     this.reinitialize();
   }
-  reinitialize() { this.buffers[this.current].write(this.positions); } // :220-231
+  // the box PointManager seeds on (:96-107): the primitives' AABBs merged, scaled 1.5x by the reference's scaleAABB AS WRITTEN
+  // (centre = min + max / 2: src/sdf/Primitive.ts:283-290), in double precision, then rounded to float32
+  seedingBox() {
+    const mn = [Infinity, Infinity, Infinity], mx = [-Infinity, -Infinity, -Infinity];
+    for (const p of this.scene.getPrimitives()) { const [a, b] = p.getAABB(); for (let k = 0; k < 3; k++) { mn[k] = Math.min(mn[k], a[k]); mx[k] = Math.max(mx[k], b[k]); } }
+    const lo = new Float32Array(3), hi = new Float32Array(3);
+    for (let k = 0; k < 3; k++) { const c = mn[k] + mx[k] * 0.5, e = mx[k] - mn[k]; lo[k] = c + e * (-1.5 / 2); hi[k] = c + e * (1.5 / 2); }
+    return [lo, hi];
+  }
+  reinitialize() { // :220-231
+    if (this.scene) { const [lo, hi] = this.seedingBox(); native.sdf_seed_positions(this.device.ctx, lo, hi, this.numPoints, this.seed++, this.buffers[this.current].ptr); return; }
+    this.buffers[this.current].write(this.positions);
+  }
   getCurrentPositionBuffer() { return this.buffers[this.current]; }     // :233-235
   getNextPositionBuffer() { return this.buffers[1 - this.current]; }    // :236-238
   swap() { this.current = 1 - this.current; }                           // :240-242
@@ -376,26 +396,32 @@ class PointManager {
  * stack machine in the HIP kernels evaluates: updateSceneParameters() re-encodes it, nothing is ever recompiled. */
 const SDF = { sphere: 0, box: 1, torus: 2, capsule: 3, union: 16, intersection: 17, subtraction: 18, smooth_union: 19 };
 let nextPrimId = 0, nextSminId = 0;
+// a primitive's box (src/sdf/Primitive.ts: getAABB): position -/+ extent in double precision, rounded to float32 like the reference's vec3
+const aabb = (p, e) => [Float32Array.from([p[0] - e[0], p[1] - e[1], p[2] - e[2]]), Float32Array.from([p[0] + e[0], p[1] + e[1], p[2] + e[2]])];
 class Primitive { constructor(id, position) { this.id = id || `prim_${nextPrimId++}`; this.position = Float32Array.from(position || [0, 0, 0]); } }
 class Sphere extends Primitive {
   constructor(p = {}) { super(p.id, p.position); this.radius = p.radius === undefined ? 0.5 : p.radius; }
   getType() { return 'sphere'; } getParamNames() { return [`${this.id}_center`, `${this.id}_radius`]; } getParamValues() { return [...this.position, this.radius]; }
   getSurfaceArea() { return 4 * Math.PI * this.radius * this.radius; } instr() { return [SDF.sphere, ...this.position, this.radius]; }
+  getAABB() { return aabb(this.position, [this.radius, this.radius, this.radius]); }
 }
 class Box extends Primitive {
   constructor(p = {}) { super(p.id, p.position); this.size = Float32Array.from(p.size || [0.5, 0.5, 0.5]); }
   getType() { return 'box'; } getParamNames() { return [`${this.id}_center`, `${this.id}_size`]; } getParamValues() { return [...this.position, 0, ...this.size, 0]; }
   getSurfaceArea() { const w = this.size[0] * 2, h = this.size[1] * 2, d = this.size[2] * 2; return 2 * (w * h + w * d + h * d); } instr() { return [SDF.box, ...this.position, ...this.size]; }
+  getAABB() { return aabb(this.position, this.size); }
 }
 class Torus extends Primitive {
   constructor(p = {}) { super(p.id, p.position); this.majorRadius = p.majorRadius === undefined ? 0.5 : p.majorRadius; this.minorRadius = p.minorRadius === undefined ? 0.2 : p.minorRadius; }
   getType() { return 'torus'; } getParamNames() { return [`${this.id}_center`, `${this.id}_radii`]; } getParamValues() { return [...this.position, 0, this.majorRadius, this.minorRadius, 0, 0]; }
   getSurfaceArea() { return 4 * Math.PI * Math.PI * this.majorRadius * this.minorRadius; } instr() { return [SDF.torus, ...this.position, this.majorRadius, this.minorRadius]; }
+  getAABB() { return aabb(this.position, [this.majorRadius + this.minorRadius, this.minorRadius, this.majorRadius + this.minorRadius]); }
 }
 class Capsule extends Primitive {
   constructor(p = {}) { super(p.id, p.position); this.height = p.height === undefined ? 1.0 : p.height; this.radius = p.radius === undefined ? 0.3 : p.radius; }
   getType() { return 'capsule'; } getParamNames() { return [`${this.id}_center`, `${this.id}_params`]; } getParamValues() { return [...this.position, 0, this.height, this.radius, 0, 0]; }
   getSurfaceArea() { return 2 * Math.PI * this.radius * this.height + 4 * Math.PI * this.radius * this.radius; } instr() { return [SDF.capsule, ...this.position, this.height, this.radius]; }
+  getAABB() { return aabb(this.position, [this.radius, this.height / 2 + this.radius, this.radius]); }
 }
 class Operation { constructor(type, params = []) { this.type = type; this.params = params; } getType() { return this.type; } getParamNames() { return []; } getParamValues() { return this.params; } }
 class SmoothUnion extends Operation { constructor(k = 0.1) { super('smooth_union', [k]); this.k = k; this.id = `smin_${nextSminId++}`; } getParamNames() { return [`${this.id}_k`]; } getParamValues() { return [this.k]; } }

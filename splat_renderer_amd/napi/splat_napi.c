@@ -329,6 +329,12 @@ FN(sdf_curvature) { /* (ctx, gradients, scaleFactors, n, curvature) */
     void *cur = arg_dptr(&c, 4); BAIL;
     return check(env, x, splat_sdf_curvature(x, g, sf, n, cur), mk_undefined(env));
 }
+FN(sdf_seed_positions) { /* (ctx, Float32Array(3) boxMin, Float32Array(3) boxMax, n, seed (integer < 2^53), positions) */
+    ARGS(6); splat_ctx *x = arg_external(&c, 0); size_t b0 = 0, b1 = 0; float *mn = arg_hostbuf(&c, 1, &b0), *mx = arg_hostbuf(&c, 2, &b1);
+    uint32_t n = (uint32_t)arg_number(&c, 3); double seed = arg_number(&c, 4); void *pos = arg_dptr(&c, 5); BAIL;
+    if (b0 < 12 || b1 < 12) { napi_throw_range_error(env, NULL, "sdf_seed_positions: the box corners are three floats each"); return NULL; }
+    return check(env, x, splat_sdf_seed_positions(x, mn, mx, n, (uint64_t)seed, pos), mk_undefined(env));
+}
 
 /* ---- multi-GPU band path (include/splat.h: "multi-GPU band path", "the multi-GPU frame's one exchange") ---- */
 FN(project_slice_compact) { /* (ctx, Float32Array(22), posRadius, strideVec4, first, count, records16) */
@@ -383,7 +389,7 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
         EXPORT(project_slice_compact), EXPORT(band_frame), EXPORT(band_settle), EXPORT(comm_unique_id), EXPORT(comm_init), EXPORT(comm_destroy),
-        EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature),
+        EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature), EXPORT(sdf_seed_positions),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

@@ -275,6 +275,19 @@ def _encode(program):
     return arr, len(program)
 
 
+def seeding_box(scene):
+    """The box PointManager seeds on (src/PointManager.ts:96-107): every primitive's AABB, merged, scaled 1.5x with the
+    reference's scaleAABB as written; (-1,-1,-1)..(1,1,1) for a scene without primitives.  Two (3,) f32 arrays."""
+    prims = scene.getPrimitives()
+    if not prims:
+        return np.full(3, -1.0, np.float32), np.full(3, 1.0, np.float32)
+    boxes = [p.getAABB() for p in prims]
+    mn = np.min([b[0] for b in boxes], axis=0).astype(np.float64)
+    mx = np.max([b[1] for b in boxes], axis=0).astype(np.float64)
+    mn, mx = scaleAABB((mn, mx), 1.5)
+    return mn.astype(np.float32), mx.astype(np.float32)
+
+
 def seed_positions(scene, numPoints, seed=0):
     """PointManager.generateRandomPositions (src/PointManager.ts:96-189): points on the faces of the scene's global AABB
     (every primitive's box, scaled 1.5x), a face chosen with probability proportional to its area — with a SEEDED

@@ -115,6 +115,35 @@ def test_sdf_program_errors_and_animation(device):
         sr.PointManager(device, sr.SDFScene())  # "Scene must have at least one primitive" (PointManager.ts:47-49)
 
 
+@pytest.mark.parametrize("seeding", ["device", "host"])
+def test_point_manager_seeds_on_the_scene_box(device, seeding):
+    """PointManager.generateRandomPositions (src/PointManager.ts:96-189): points on the faces of the scene's scaled box, a face by
+    area.  Drawn on the device (the default: splat_sdf_seed_positions, bit for bit the oracle's restatement of the same
+    counter hash) or on the host (NumPy) — fresh at every reinitialize()."""
+    scene = main_ts_scene()
+    pm = sr.PointManager(device, scene, seed=5, seeding=seeding)
+    n = pm.getNumPoints()
+    mn, mx = sdf.seeding_box(scene)
+    clouds = []
+    for k in range(3):
+        got = pm.getCurrentPositionBuffer().read(np.float32).reshape(n, 4)
+        want = O.sdf_seed_positions(mn, mx, n, 5 + k) if seeding == "device" else sdf.seed_positions(scene, n, seed=5 + k)
+        assert np.array_equal(bits(got), bits(want)), k
+        on_face = np.isclose(got[:, :3], mn).any(axis=1) | np.isclose(got[:, :3], mx).any(axis=1)
+        assert on_face.all() and (got[:, :3] >= mn - 1e-6).all() and (got[:, :3] <= mx + 1e-6).all() and (got[:, 3] == 0).all()
+        clouds.append(got.copy())
+        pm.reinitialize()
+    assert not np.array_equal(clouds[0], clouds[1]) and not np.array_equal(clouds[1], clouds[2])
+    # faces in proportion to their areas (six faces, 124k points: a percent is many sigmas)
+    d = (mx - mn).astype(np.float64)
+    areas = np.array([d[1] * d[2], d[1] * d[2], d[0] * d[2], d[0] * d[2], d[0] * d[1], d[0] * d[1]])
+    g = clouds[0]
+    counts = np.array([(g[:, 0] == mn[0]).sum(), (g[:, 0] == mx[0]).sum(), (g[:, 1] == mn[1]).sum(), (g[:, 1] == mx[1]).sum(),
+                       (g[:, 2] == mn[2]).sum(), (g[:, 2] == mx[2]).sum()])
+    assert np.abs(counts / n - areas / areas.sum()).max() < 0.01
+    pm.destroy()
+
+
 def test_frame_from_generated_splats(device):
     """The reference's whole frame (src/main.ts:110-193) with the tile-raster path as its renderer: seeded points on the
     scene's box, five projection steps, curvature, SplatPropertyManager.updateFromCurvature, Renderer.render — against the
@@ -132,7 +161,8 @@ def test_frame_from_generated_splats(device):
         props_buf, cur_buf = src.step()
         r.render(u, props_buf, cur_buf, None, w, h, wantFloat=True)
         prog = scene.program()
-        pos = sdf.seed_positions(scene, n, seed=11 + frame + 1)  # (PointManager's constructor drew seed 11 already)
+        # (the cloud is drawn on the device: point i a pure function of (seed, i); PointManager's constructor drew seed 11)
+        pos = O.sdf_seed_positions(*sdf.seeding_box(scene), n, 11 + frame + 1)
         for _ in range(5):
             grad = O.sdf_gradients(prog, pos)
             pos = O.sdf_update_positions(pos, grad)

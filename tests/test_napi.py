@@ -173,10 +173,17 @@ def test_js_sdf_generation_matches_oracle(tmp_path):
     n = 5000
     pos = sdf.seed_positions(scene, n, seed=21)
     pos.tofile(tmp_path / "pos.f32")
-    r = subprocess.run([NODE, "sdf_generate.js", str(tmp_path / "pos.f32"), str(n), str(tmp_path / "out.f32")], cwd=NAPI,
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([NODE, "sdf_generate.js", str(tmp_path / "pos.f32"), str(n), str(tmp_path / "out.f32"), str(tmp_path / "seeded.f32")],
+                       cwd=NAPI, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert json.loads(r.stdout.strip().splitlines()[-1])["hash"] == scene.getStructureHash()
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["hash"] == scene.getStructureHash()
+    # new PointManager(device, scene, seed) in JS: the reference's point count, clouds drawn on the device = the oracle's
+    ns = sdf.point_count(scene)
+    assert info["seededCount"] == ns
+    clouds = np.fromfile(tmp_path / "seeded.f32", np.float32).reshape(2, ns, 4)
+    for k in range(2):
+        assert np.array_equal(clouds[k].view(np.uint32), O.sdf_seed_positions(*sdf.seeding_box(scene), ns, 33 + k).view(np.uint32)), k
     got = np.fromfile(tmp_path / "out.f32", np.float32).reshape(3, n, 4)
     scene.get("sphere1").position[0] = np.float32(0.1)
     prog = scene.program()

@@ -98,3 +98,16 @@ def test_oracle_points_settle_on_the_surface_and_curvature_marks_edges():
     assert sfb[0] > 0.999 and sfb[1] < 0.9
     cur = O.sdf_curvature(O.sdf_gradients(box.program(), face), sfb)
     assert np.allclose(cur[0], [1, 0, 0, sfb[0]])
+
+
+def test_oracle_seeding_is_a_pure_function_of_seed_and_index():
+    """orc_sdf_seed_positions (the restatement of splat_sdf_seed_positions): point i of cloud s does not depend on n, clouds
+    differ, every point lies on a face of the box and the uniforms fill the faces."""
+    mn, mx = np.array([-1.0, -0.5, -2.0], np.float32), np.array([1.5, 0.75, 0.25], np.float32)
+    a, b = O.sdf_seed_positions(mn, mx, 5000, 7), O.sdf_seed_positions(mn, mx, 20000, 7)
+    assert np.array_equal(a, b[:5000]) and not np.array_equal(a, O.sdf_seed_positions(mn, mx, 5000, 8))
+    on_face = (b[:, :3] == mn).any(axis=1) | (b[:, :3] == mx).any(axis=1)
+    assert on_face.all() and (b[:, :3] >= mn).all() and (b[:, :3] <= mx).all() and (b[:, 3] == 0).all()
+    free = b[(b[:, 0] == mn[0])][:, 1:3]  # the -x face: y and z uniform over the box
+    lo, hi = np.array([mn[1], mn[2]]), np.array([mx[1], mx[2]])
+    assert np.abs(free.mean(axis=0) - (lo + hi) / 2).max() < 0.05 * (hi - lo).max()
