@@ -377,6 +377,16 @@ int splat_sdf_curvature(splat_ctx *ctx, const void *gradients, const void *scale
  * cloud costs one small kernel and no transfer, and the oracle restates it bit for bit (orc_sdf_seed_positions). */
 int splat_sdf_seed_positions(splat_ctx *ctx, const float *aabb_min3, const float *aabb_max3, uint32_t n, uint64_t seed,
                              void *positions);
+/* The producer half of the reference's frame (src/main.ts:146-180) in one launch: per point its fresh position
+ * (aabb_min3 / aabb_max3 != NULL: drawn as splat_sdf_seed_positions draws point i of cloud `seed`; NULL: read from
+ * positions_in), `steps` >= 1 rounds of {splat_sdf_gradients, splat_sdf_update_positions} (main.ts runs five), then
+ * splat_sdf_scale_factors at the final position, splat_sdf_curvature with the gradient of the LAST evaluation (one step
+ * behind the position, as main.ts:186 hands it on) and splat_update_props.  Outputs: final positions, that gradient
+ * (optional), vec4(normal, scale), the 32-byte property records (optional) — bit for bit what the stage-by-stage calls
+ * give (tests/test_gpu_sdf.py), without their thirteen launches. */
+int splat_sdf_generate(splat_ctx *ctx, const splat_sdf_instr *program, uint32_t n_instr, const float *aabb_min3, const float *aabb_max3,
+                       uint64_t seed, const void *positions_in, uint32_t n, uint32_t steps, void *positions_out, void *gradients_out,
+                       void *curvature_out, void *props_out);
 
 /* ---- the multi-GPU frame's one exchange (no reference equivalent): RCCL over xGMI ------------------
  * One process per GPU.  Rank 0 makes a unique id (splat_comm_unique_id) and hands its SPLAT_COMM_ID_BYTES to the

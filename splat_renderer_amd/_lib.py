@@ -112,6 +112,7 @@ SIGNATURES = {
     "splat_sdf_scale_factors": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
     "splat_sdf_curvature": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_sdf_seed_positions": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _u32, C.c_uint64, _vp]),
+    "splat_sdf_generate": (_i, [_vp, _vp, _u32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "splat_comm_unique_id": (_i, [_vp]),
     "splat_comm_init": (_i, [_vp, _i, _i, _vp, _pvp]),
     "splat_comm_destroy": (None, [_vp]),

@@ -104,9 +104,13 @@ __device__ __forceinline__ float4 op_smooth_union(float4 a, float4 b, float k) {
     return make_float4(dist, a.y * u + b.y * t, a.z * u + b.z * t, a.w * u + b.w * t);
 }
 
-// sceneSDF (CodeGenerator.ts:276-353): the post-order walk of the scene graph, as a stack machine
-__device__ __forceinline__ float4 scene_sdf(const SdfProgram &prog, float px, float py, float pz) {
-    float4 stack[SDF_STACK];
+// sceneSDF (CodeGenerator.ts:276-353): the post-order walk of the scene graph, as a stack machine.
+// The operand stack lives in LDS, one column per lane (`stack` = the lane's slot of level 0, levels SDF_LANES apart): as a
+// local array it is indexed by a run-time stack pointer and the compiler spills it to scratch — 144 bytes per lane of
+// global memory behind every push and pop, which made the producer kernels several times slower than their arithmetic.
+constexpr int SDF_LANES = 64; // threads per workgroup of every kernel that evaluates the scene
+#define SDF_STACK_DECL __shared__ float4 s_sdf_stack[SDF_STACK * SDF_LANES]; float4 *sdf_stack = s_sdf_stack + threadIdx.x
+__device__ __forceinline__ float4 scene_sdf(const SdfProgram &prog, float px, float py, float pz, float4 *stack) {
     int sp = 0;
     for (uint32_t k = 0; k < prog.count; ++k) {
         const splat_sdf_instr &in = prog.instr[k];
@@ -117,9 +121,9 @@ __device__ __forceinline__ float4 scene_sdf(const SdfProgram &prog, float px, fl
             else if (in.op == SPLAT_SDF_BOX) v = sdg_box(x, y, z, in.a[3], in.a[4], in.a[5]);
             else if (in.op == SPLAT_SDF_TORUS) v = sdg_torus(x, y, z, in.a[3], in.a[4]);
             else v = sdg_capsule(x, y, z, in.a[3], in.a[4]);
-            stack[sp++] = v;
+            stack[(sp++) * SDF_LANES] = v;
         } else {
-            const float4 b = stack[--sp], a = stack[--sp];
+            const float4 b = stack[(--sp) * SDF_LANES], a = stack[(--sp) * SDF_LANES];
             float4 v;
             if (in.op == SPLAT_SDF_UNION) v = (a.x < b.x) ? a : b;             // :181-187
             else if (in.op == SPLAT_SDF_INTERSECTION) v = (a.x > b.x) ? a : b;  // :190-196
@@ -127,28 +131,25 @@ __device__ __forceinline__ float4 scene_sdf(const SdfProgram &prog, float px, fl
                 const float4 nb = make_float4(-b.x, -b.y, -b.z, -b.w);
                 v = (a.x > nb.x) ? a : nb;
             } else v = op_smooth_union(a, b, in.a[0]);
-            stack[sp++] = v;
+            stack[(sp++) * SDF_LANES] = v;
         }
     }
     if (sp == 0) return make_float4(1000.0f, 0.0f, 1.0f, 0.0f); // empty scene (:282-286)
-    return stack[sp - 1];
+    return stack[(sp - 1) * SDF_LANES];
 }
 
 // GradientSampler (CodeGenerator.ts:72-90)
 __global__ __launch_bounds__(64) void k_sdf_gradients(SdfProgram prog, const float4 *__restrict__ positions, uint32_t n,
                                                       float4 *__restrict__ gradients) {
+    SDF_STACK_DECL;
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n) return;
     const float4 p = positions[i];
-    gradients[i] = scene_sdf(prog, p.x, p.y, p.z);
+    gradients[i] = scene_sdf(prog, p.x, p.y, p.z, sdf_stack);
 }
 
 // PositionUpdater (update-positions.wgsl:22-50)
-__global__ __launch_bounds__(64) void k_sdf_update_positions(const float4 *__restrict__ positions, const float4 *__restrict__ gradients,
-                                                             uint32_t n, float4 *__restrict__ next_positions) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = positions[i], g = gradients[i];
+__device__ __forceinline__ float4 sdf_step_position(float4 p, float4 g) {
     const float len = sdf_len3(g.y, g.z, g.w);
     float x = p.x, y = p.y, z = p.z;
     if (len > 0.0001f) { // :42-45: newPos = pos - normalize(grad) * distance
@@ -156,17 +157,20 @@ __global__ __launch_bounds__(64) void k_sdf_update_positions(const float4 *__res
         y = p.y - (g.z / len) * g.x;
         z = p.z - (g.w / len) * g.x;
     }
-    next_positions[i] = make_float4(x, y, z, 0.0f);
+    return make_float4(x, y, z, 0.0f);
+}
+
+__global__ __launch_bounds__(64) void k_sdf_update_positions(const float4 *__restrict__ positions, const float4 *__restrict__ gradients,
+                                                             uint32_t n, float4 *__restrict__ next_positions) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    next_positions[i] = sdf_step_position(positions[i], gradients[i]);
 }
 
 // CurvatureSampler (CurvatureSampler.ts:84-141)
-__global__ __launch_bounds__(64) void k_sdf_scale_factors(SdfProgram prog, const float4 *__restrict__ positions, uint32_t n,
-                                                          float *__restrict__ scale_factors) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n) return;
-    const float4 c = positions[i];
+__device__ __forceinline__ float sdf_scale_factor(const SdfProgram &prog, float4 c, float4 *sdf_stack) {
     const float r = 0.02f; // sampleRadius
-    const float4 cr = scene_sdf(prog, c.x, c.y, c.z);
+    const float4 cr = scene_sdf(prog, c.x, c.y, c.z, sdf_stack);
     const float cl = sdf_len3(cr.y, cr.z, cr.w);
     const float nx = cr.y / cl, ny = cr.z / cl, nz = cr.w / cl;
     float total = 0.0f;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(64) void k_sdf_scale_factors(SdfProgram prog, const
         const float ox = (k == 0) ? r : (k == 1) ? -r : 0.0f;
         const float oy = (k == 2) ? r : (k == 3) ? -r : 0.0f;
         const float oz = (k == 4) ? r : (k == 5) ? -r : 0.0f;
-        const float4 s = scene_sdf(prog, c.x + ox, c.y + oy, c.z + oz);
+        const float4 s = scene_sdf(prog, c.x + ox, c.y + oy, c.z + oz, sdf_stack);
         const float sl = sdf_len3(s.y, s.z, s.w);
         const float d = (nx * (s.y / sl) + ny * (s.z / sl)) + nz * (s.w / sl);
         total = total + (1.0f - d); // :121-123
@@ -183,17 +187,21 @@ __global__ __launch_bounds__(64) void k_sdf_scale_factors(SdfProgram prog, const
     const float t = fminf(fmaxf((avg - 0.0f) / (0.5f - 0.0f), 0.0f), 1.0f); // smoothstep(0, 0.5, avg) :131
     const float sm = (t * t) * (3.0f - 2.0f * t);
     const float sf = 1.0f - sm;
-    scale_factors[i] = 0.01f * (1.0f - sf) + 1.0f * sf; // mix(0.01, 1.0, scaleFactor) :132
+    return 0.01f * (1.0f - sf) + 1.0f * sf; // mix(0.01, 1.0, scaleFactor) :132
+}
+
+__global__ __launch_bounds__(64) void k_sdf_scale_factors(SdfProgram prog, const float4 *__restrict__ positions, uint32_t n,
+                                                          float *__restrict__ scale_factors) {
+    SDF_STACK_DECL;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    scale_factors[i] = sdf_scale_factor(prog, positions[i], sdf_stack);
 }
 
 // The buffer SplatPropertyManager.updateFromCurvature binds as "curvatureData" is vec4(normal.xyz, scaleFactor)
 // (src/SplatPropertyManager.ts:70-72) while the samplers above produce vec4(distance, gradient) and one f32 per point
 // (SURVEY I4): this joins the two — normal = normalize(gradient), or (0, 1, 0) where the gradient vanishes.
-__global__ __launch_bounds__(64) void k_sdf_curvature(const float4 *__restrict__ gradients, const float *__restrict__ scale_factors,
-                                                      uint32_t n, float4 *__restrict__ curvature) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n) return;
-    const float4 g = gradients[i];
+__device__ __forceinline__ float4 sdf_curvature_of(float4 g, float scale_factor) {
     const float len = sdf_len3(g.y, g.z, g.w);
     float x = 0.0f, y = 1.0f, z = 0.0f;
     if (len > 0.0001f) {
@@ -201,7 +209,14 @@ __global__ __launch_bounds__(64) void k_sdf_curvature(const float4 *__restrict__
         y = g.z / len;
         z = g.w / len;
     }
-    curvature[i] = make_float4(x, y, z, scale_factors[i]);
+    return make_float4(x, y, z, scale_factor);
+}
+
+__global__ __launch_bounds__(64) void k_sdf_curvature(const float4 *__restrict__ gradients, const float *__restrict__ scale_factors,
+                                                      uint32_t n, float4 *__restrict__ curvature) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    curvature[i] = sdf_curvature_of(gradients[i], scale_factors[i]);
 }
 
 // stack discipline of a postfix program, checked on the host before anything is launched
@@ -237,9 +252,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(256) void k_sdf_seed_positions(SeedBox box, uint32_t n, uint64_t seed, float4 *__restrict__ positions) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ float4 sdf_seed_point(const SeedBox &box, uint64_t seed, uint32_t i) {
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull + 2ull * i;
     const uint64_t a = splitmix64(base), b = splitmix64(base + 1ull);
     const float k24 = 1.0f / 16777216.0f; // 24 bits per uniform: exact in binary32, [0, 1)
@@ -251,13 +264,50 @@ __global__ __launch_bounds__(256) void k_sdf_seed_positions(SeedBox box, uint32_
     const float c0 = ax, c1 = c0 + ax, c2 = c1 + ay, c3 = c2 + ay, c4 = c3 + az, c5 = c4 + az;
     const float t = u0 * c5;
     const uint32_t face = t < c0 ? 0u : t < c1 ? 1u : t < c2 ? 2u : t < c3 ? 3u : t < c4 ? 4u : 5u;
-    float p[3] = {box.mn[0] + u1 * d[0], box.mn[1] + u2 * d[1], box.mn[2] + u3 * d[2]};
-    const uint32_t axis = face >> 1;
-    const float pinned = (face & 1u) ? box.mx[axis] : box.mn[axis];
-    if (axis == 0) p[0] = pinned;
-    else if (axis == 1) p[1] = pinned;
-    else p[2] = pinned;
-    positions[i] = make_float4(p[0], p[1], p[2], 0.0f);
+    float x = box.mn[0] + u1 * d[0], y = box.mn[1] + u2 * d[1], z = box.mn[2] + u3 * d[2];
+    // (selects, not arrays indexed by the face: those end up in scratch)
+    if (face == 0) x = box.mn[0];
+    else if (face == 1) x = box.mx[0];
+    else if (face == 2) y = box.mn[1];
+    else if (face == 3) y = box.mx[1];
+    else if (face == 4) z = box.mn[2];
+    else z = box.mx[2];
+    return make_float4(x, y, z, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_sdf_seed_positions(SeedBox box, uint32_t n, uint64_t seed, float4 *__restrict__ positions) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) positions[i] = sdf_seed_point(box, seed, i);
+}
+
+// The producer half of the reference's frame in ONE launch (src/main.ts:146-180): a point's fresh position (seeded here, or
+// read), `steps` rounds of {evaluate the scene at it, step onto the surface}, the curvature scale factor at where it ends
+// up, vec4(normal of the LAST evaluation, scale) and the splat's property record — the same device functions, in the same
+// order, as the stage kernels above (and k_update_props), so every output has the bits theirs have.  A point never looks
+// at another, so nothing is lost by not materialising the rounds; what is gained is thirteen launches of ~6 us each on
+// 10^5 points, which is what the stage-by-stage form of this producer costs (0.086 ms of a 0.30 ms frame at the
+// reference's working point).
+__global__ __launch_bounds__(64) void k_sdf_generate(SdfProgram prog, SeedBox box, uint32_t seeded, uint64_t seed,
+                                                     const float4 *__restrict__ positions_in, uint32_t n, uint32_t steps,
+                                                     float4 *__restrict__ positions_out, float4 *__restrict__ gradients_out,
+                                                     float4 *__restrict__ curvature_out, float4 *__restrict__ props_out) {
+    SDF_STACK_DECL;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = seeded ? sdf_seed_point(box, seed, i) : positions_in[i];
+    float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < steps; ++k) {
+        g = scene_sdf(prog, p.x, p.y, p.z, sdf_stack);
+        p = sdf_step_position(p, g);
+    }
+    const float4 c = sdf_curvature_of(g, sdf_scale_factor(prog, p, sdf_stack));
+    positions_out[i] = p;
+    if (gradients_out) gradients_out[i] = g;
+    curvature_out[i] = c;
+    if (props_out) { // SplatPropertyManager.updateFromCurvature (src/SplatPropertyManager.ts:82-107), as k_update_props
+        props_out[(size_t)i * 2] = make_float4(p.x, p.y, p.z, 0.04f);                                                   // :94
+        props_out[(size_t)i * 2 + 1] = make_float4(fabsf(c.x) * 0.8f + 0.2f, fabsf(c.y) * 0.8f + 0.2f, fabsf(c.z) * 0.8f + 0.2f, 1.0f); // :97-101
+    }
 }
 
 extern "C" {
@@ -324,6 +374,33 @@ int splat_sdf_seed_positions(splat_ctx *ctx, const float *aabb_min3, const float
     }
     hipLaunchKernelGGL(k_sdf_seed_positions, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, box, n, seed, (float4 *)positions);
     LAUNCH_CHECK(ctx, "k_sdf_seed_positions");
+    return SPLAT_OK;
+}
+
+int splat_sdf_generate(splat_ctx *ctx, const splat_sdf_instr *program, uint32_t n_instr, const float *aabb_min3, const float *aabb_max3,
+                       uint64_t seed, const void *positions_in, uint32_t n, uint32_t steps, void *positions_out, void *gradients_out,
+                       void *curvature_out, void *props_out) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    const bool seeded = aabb_min3 != nullptr;
+    ARG_CHECK(ctx, seeded == (aabb_max3 != nullptr) && (n == 0 || seeded || positions_in));
+    ARG_CHECK(ctx, n == 0 || (positions_out && curvature_out));
+    ARG_CHECK(ctx, steps >= 1); // (the normal is that of the last evaluation: there has to be one)
+    ARG_CHECK(ctx, (((uintptr_t)positions_in | (uintptr_t)positions_out | (uintptr_t)gradients_out | (uintptr_t)curvature_out |
+                     (uintptr_t)props_out) & 15) == 0);
+    SdfProgram prog;
+    int rc = sdf_load(ctx, program, n_instr, prog);
+    if (rc != SPLAT_OK) return rc;
+    if (n == 0) return SPLAT_OK;
+    SeedBox box = {};
+    if (seeded)
+        for (int a = 0; a < 3; ++a) {
+            box.mn[a] = aabb_min3[a];
+            box.mx[a] = aabb_max3[a];
+        }
+    hipLaunchKernelGGL(k_sdf_generate, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, prog, box, seeded ? 1u : 0u, seed,
+                       (const float4 *)positions_in, n, steps, (float4 *)positions_out, (float4 *)gradients_out, (float4 *)curvature_out,
+                       (float4 *)props_out);
+    LAUNCH_CHECK(ctx, "k_sdf_generate");
     return SPLAT_OK;
 }
 

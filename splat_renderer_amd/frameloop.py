@@ -153,10 +153,14 @@ class SdfSplatSource:
         self.positionUpdater = PositionUpdater(device, None, n)
         self.properties = SplatPropertyManager(device, n)
 
-    def step(self, reinitialize=True):
+    def step(self, reinitialize=True, fused=True):
+        """One frame's splats.  fused=True (default): splat_sdf_generate, the whole producer in one launch; False: the
+        reference's thirteen stage calls through the classes above.  Same bits either way, in the same buffers."""
         pm, gs, cs = self.pointManager, self.gradientSampler, self.curvatureSampler
         gs.updateSceneParameters()  # :119-120 (the caller may have animated the primitives)
         cs.updateSceneParameters()
+        if fused:
+            return self._step_fused(reinitialize)
         if reinitialize:
             pm.reinitialize()       # :147
         for _ in range(self.ITERATIONS):  # :149-172
@@ -169,6 +173,28 @@ class SdfSplatSource:
         curvature = cs.getCurvatureBuffer(gs.getGradientBuffer())
         self.properties.updateFromCurvature(None, pm.getCurrentPositionBuffer(), curvature)
         return self.properties.getPropertyBuffer(), curvature
+
+    def _step_fused(self, reinitialize):
+        import ctypes as C
+        from . import sdf
+        from ._lib import check
+        pm, gs, cs, d = self.pointManager, self.gradientSampler, self.curvatureSampler, self.device
+        if cs.curvatureBuffer is None:
+            cs.curvatureBuffer = d.createBuffer(self.numPoints * 16)
+        fp = C.POINTER(C.c_float)
+        mn = mx = None
+        seed = 0
+        if reinitialize and pm.scene is not None and pm.seeding == "device":  # the fresh cloud is drawn inside the launch
+            lo, hi = sdf.seeding_box(pm.scene)
+            mn, mx, seed = lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), int(pm._seed) & 0xFFFFFFFFFFFFFFFF
+            pm._seed += 1
+        elif reinitialize:
+            pm.reinitialize()
+        check(d.lib.splat_sdf_generate(d.ctx, C.cast(gs._program, C.c_void_p), gs._count, mn, mx, seed, pm.getCurrentPositionBuffer().ptr,
+                                       self.numPoints, self.ITERATIONS, pm.getNextPositionBuffer().ptr, gs.getGradientBuffer().ptr,
+                                       cs.curvatureBuffer.ptr, self.properties.getPropertyBuffer().ptr), d.ctx)
+        pm.swap()  # (five swaps in the staged form: the same buffer ends up current)
+        return self.properties.getPropertyBuffer(), cs.curvatureBuffer
 
     def destroy(self):
         for o in (self.pointManager, self.gradientSampler, self.curvatureSampler, self.properties):

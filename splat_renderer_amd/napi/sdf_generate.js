@@ -42,4 +42,11 @@ out.set(pm.getCurrentPositionBuffer().read(new Float32Array(n * 4)), 0);
 out.set(gs.getGradientBuffer().read(new Float32Array(n * 4)), n * 4);
 out.set(cs.getCurvatureBuffer(gs.getGradientBuffer()).read(new Float32Array(n * 4)), n * 8);
 fs.writeFileSync(outPath, Buffer.from(out.buffer));
-console.log(JSON.stringify({ n, hash: scene.getStructureHash(), seededCount }));
+// the same producer in one launch (native.sdf_generate) from the same starting cloud: the same bits
+const start = device.createBuffer(n * 16); start.write(new Float32Array(b.buffer, b.byteOffset, n * 4));
+const fp = device.createBuffer(n * 16), fg = device.createBuffer(n * 16), fc = device.createBuffer(n * 16), fprops = device.createBuffer(n * 32);
+sr.native.sdf_generate(device.ctx, scene.program(), null, null, 0, start.ptr, n, 5, fp.ptr, fg.ptr, fc.ptr, fprops.ptr);
+const same = (x, y) => { const a = new Uint32Array(x.buffer, x.byteOffset, x.length), c = new Uint32Array(y.buffer, y.byteOffset, y.length); for (let i = 0; i < a.length; i++) if (a[i] !== c[i]) return false; return true; };
+const fusedEqual = same(fp.read(new Float32Array(n * 4)), out.subarray(0, n * 4)) && same(fg.read(new Float32Array(n * 4)), out.subarray(n * 4, n * 8)) &&
+  same(fc.read(new Float32Array(n * 4)), out.subarray(n * 8, n * 12));
+console.log(JSON.stringify({ n, hash: scene.getStructureHash(), seededCount, fusedEqual }));

@@ -335,6 +335,17 @@ FN(sdf_seed_positions) { /* (ctx, Float32Array(3) boxMin, Float32Array(3) boxMax
     if (b0 < 12 || b1 < 12) { napi_throw_range_error(env, NULL, "sdf_seed_positions: the box corners are three floats each"); return NULL; }
     return check(env, x, splat_sdf_seed_positions(x, mn, mx, n, (uint64_t)seed, pos), mk_undefined(env));
 }
+FN(sdf_generate) { /* (ctx, program, boxMin | null, boxMax | null, seed, positionsIn | null, n, steps, positionsOut, gradientsOut | null, curvatureOut, propsOut | null) */
+    ARGS(12); splat_ctx *x = arg_external(&c, 0); splat_sdf_instr prog[SPLAT_SDF_MAX_INSTR]; uint32_t cnt = 0;
+    if (!sdf_program(&c, 1, prog, &cnt)) return NULL;
+    napi_valuetype t; napi_typeof(env, c.argv[2], &t);
+    float *mn = NULL, *mx = NULL; size_t b0 = 12, b1 = 12;
+    if (t != napi_null && t != napi_undefined) { mn = arg_hostbuf(&c, 2, &b0); mx = arg_hostbuf(&c, 3, &b1); }
+    double seed = arg_number(&c, 4); void *pin = arg_dptr(&c, 5); uint32_t n = (uint32_t)arg_number(&c, 6), steps = (uint32_t)arg_number(&c, 7);
+    void *pout = arg_dptr(&c, 8), *gout = arg_dptr(&c, 9), *cout = arg_dptr(&c, 10), *props = arg_dptr(&c, 11); BAIL;
+    if (b0 < 12 || b1 < 12) { napi_throw_range_error(env, NULL, "sdf_generate: the box corners are three floats each"); return NULL; }
+    return check(env, x, splat_sdf_generate(x, prog, cnt, mn, mx, (uint64_t)seed, pin, n, steps, pout, gout, cout, props), mk_undefined(env));
+}
 
 /* ---- multi-GPU band path (include/splat.h: "multi-GPU band path", "the multi-GPU frame's one exchange") ---- */
 FN(project_slice_compact) { /* (ctx, Float32Array(22), posRadius, strideVec4, first, count, records16) */
@@ -389,7 +400,7 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
         EXPORT(project_slice_compact), EXPORT(band_frame), EXPORT(band_settle), EXPORT(comm_unique_id), EXPORT(comm_init), EXPORT(comm_destroy),
-        EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature), EXPORT(sdf_seed_positions),
+        EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature), EXPORT(sdf_seed_positions), EXPORT(sdf_generate),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

@@ -144,6 +144,28 @@ def test_point_manager_seeds_on_the_scene_box(device, seeding):
     pm.destroy()
 
 
+@pytest.mark.parametrize("seeding", ["device", "host"])
+def test_fused_generator_equals_the_staged_calls(device, seeding):
+    """splat_sdf_generate (the producer half of main.ts's frame in one launch) against the thirteen stage calls through the
+    reference's classes: positions, the gradient of the last evaluation, vec4(normal, scale) and the property records, bit for
+    bit, over three frames (fresh clouds, then one frame that keeps its points) with the scene animated in between."""
+    scene_a, scene_b = main_ts_scene(), main_ts_scene()
+    a = sr.SdfSplatSource(device, scene_a, seed=3, seeding=seeding)
+    b = sr.SdfSplatSource(device, scene_b, seed=3, seeding=seeding)
+    n = a.numPoints
+    for frame, reinit in enumerate((True, True, False)):
+        for sc in (scene_a, scene_b):
+            sc.get("sphere1").position[0] = np.float32(0.2 * frame)
+        pa, ca = a.step(reinitialize=reinit, fused=True)
+        pb, cb = b.step(reinitialize=reinit, fused=False)
+        for name, x, y, width in (("props", pa, pb, 8), ("curvature", ca, cb, 4),
+                                  ("positions", a.pointManager.getCurrentPositionBuffer(), b.pointManager.getCurrentPositionBuffer(), 4),
+                                  ("gradients", a.gradientSampler.getGradientBuffer(), b.gradientSampler.getGradientBuffer(), 4)):
+            assert np.array_equal(bits(x.read(np.float32)).reshape(n, width), bits(y.read(np.float32)).reshape(n, width)), (frame, name)
+    a.destroy()
+    b.destroy()
+
+
 def test_frame_from_generated_splats(device):
     """The reference's whole frame (src/main.ts:110-193) with the tile-raster path as its renderer: seeded points on the
     scene's box, five projection steps, curvature, SplatPropertyManager.updateFromCurvature, Renderer.render — against the

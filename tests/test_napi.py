@@ -178,6 +178,7 @@ def test_js_sdf_generation_matches_oracle(tmp_path):
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["hash"] == scene.getStructureHash()
+    assert info["fusedEqual"] is True  # native.sdf_generate from JS: the staged calls' bits
     # new PointManager(device, scene, seed) in JS: the reference's point count, clouds drawn on the device = the oracle's
     ns = sdf.point_count(scene)
     assert info["seededCount"] == ns
