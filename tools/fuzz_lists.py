@@ -33,8 +33,9 @@ for case in range(cases):
     if total > 30_000_000:
         continue
     pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
-    r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
-    tag = (case, n, w, h, rs, total)
+    order = "sortFirst" if case % 3 == 2 else "tileFirst"  # (the staged API's order of work: a third of the cases)
+    r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder=order)
+    tag = (case, n, w, h, rs, total, order)
     for rep in range(2):
         r.render(u, pbuf, nbuf, None, w, h)
         assert r.finish() == total, tag
