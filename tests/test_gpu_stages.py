@@ -831,6 +831,34 @@ def test_tile_first_sixteen_bit_tile_ids(device):
         o.destroy()
 
 
+def test_tile_first_with_ballot_ranking(monkeypatch):
+    """SPLAT_RANK=ballot: the escape from the measured lane order of returning LDS atomics (splat.h).  A context created
+    under it never asks the hardware and ranks with ballots in every kernel of the frame's binner — first-pass scatter,
+    second-pass downsweep, per-tile sort, both size classes and the global-memory passes: same lists, same image."""
+    monkeypatch.setenv("SPLAT_RANK", "ballot")
+    dev = sr.Device(0)  # (the ranking is resolved once per context, at its first sort)
+    try:
+        for n, w, h, seed, rs in [(3000, 128, 96, 41, 1.0), (20000, 640, 360, 42, 1.0), (20000, 64, 64, 43, 6.0), (30000, 48, 32, 44, 8.0)]:
+            props, normals, u = make_case(n, w, h, seed, rs)
+            ref = oracle_pipeline(props, normals, u, w, h)
+            pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
+            r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
+            for rep in range(2):  # first and sync-free
+                r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+                total = r.finish()
+                assert total == ref["indices"].shape[0], (n, w, h)
+                assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
+                assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), (n, w, h, rep)
+            got = r.readPixelsFloat()
+            r2 = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="sortFirst")
+            r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+            assert np.array_equal(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32))
+            for o in (r, r2, pbuf, nbuf):
+                o.destroy()
+    finally:
+        dev.destroy()
+
+
 def test_tile_first_sync_free_repeat_and_overflow(device):
     n, w, h = 20000, 320, 200
     small, normals, u = make_case(n, w, h, 61, 0.5)
