@@ -38,6 +38,10 @@ extern "C" {
 #define SPLAT_ERR_STATE (-5)    /* getter called before the verb that produces its result */
 #define SPLAT_ERR_NO_DEVICE (-6)
 #define SPLAT_ERR_COMM (-7)     /* RCCL call failed */
+#define SPLAT_ERR_RETRY (-8)    /* the previous frame's tile lists failed the per-tile sort's order check (see
+                                 * splat_rank_status): the context has switched to ballot ranking; render that frame again.
+                                 * Returned where SPLAT_ERR_CAPACITY is for an overflowed sync-free frame, and handled the
+                                 * same way by a caller: call the frame function again with the same arguments. */
 
 typedef struct splat_ctx splat_ctx;
 typedef struct splat_sorter splat_sorter;
@@ -142,12 +146,30 @@ int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches);
  * MI355X; ranks keys with returning LDS atomics when the lane-order probe above passes, else with
  * ballots), 1 = onesweep with decoupled look-back (the reference's structure), 2 = as 0 but always
  * ballot ranking, -1 = library default.
- * NOTE on mode 0 and on the frame path's binning kernels: ranking with returning LDS atomics is stable only if the
- * lanes of one instruction that collide on an address complete in ascending lane order.  That is what gfx950 does
- * (splat_probe_lds_atomic_order: 0 mismatches in 8.4 M colliding instructions) but it is not an ISA guarantee: the
- * library probes once per context and uses the ballot ranking if the probe ever fails, and the environment variable
- * SPLAT_RANK=ballot forces the ballot ranking for every kernel of the process without asking the hardware. */
+ * NOTE on ranking (mode 0, and the frame path's binning kernels).  Ranking a wave's keys with returning LDS atomics is
+ * stable only if the lanes of one instruction that collide on an address complete in ascending lane order.  That is what
+ * gfx950 does (splat_probe_lds_atomic_order: 0 mismatches in 8.4 M colliding instructions) but it is not an ISA guarantee,
+ * and index lists are bit-exact work, so nothing rests on it unverified:
+ *   - default: atomics are used ONLY by the tile-first frame path (splat_render_frame*, splat_band_frame), whose per-tile
+ *     sort checks every tile's final list for strictly increasing (depth key, splat index) order — the contract itself,
+ *     hence a complete check of every ranking pass that produced the list.  A frame that fails is reported like an
+ *     overflowed sync-free frame (SPLAT_ERR_RETRY at the next call), the context ranks with ballots from then on, and the
+ *     caller renders the frame again.  Every other sort (splat_sort_run, splat_bin_run, the sort-first frame order), whose
+ *     result nothing checks, ranks with ballots: lane order by construction (8 ballots + mbcnt per key).
+ *   - SPLAT_RANK=atomic: atomics wherever the start-up probe passes (the unchecked sorts too).
+ *   - SPLAT_RANK=ballot: ballots everywhere.
+ * The price of the guaranteed ranking on the frame path, measured on one MI355X (profiles/r03_a_rank_ab.txt): C0 0.048 ->
+ * 0.054 ms, C1 0.177 -> 0.210, C2 0.359 -> 0.425, C3 0.878 -> 0.986 (+12..19 %); the price of the check: see DESIGN.md. */
 int splat_sort_set_mode(splat_sorter *s, int mode);
+/* Ranking status of this context: *policy = 0 checked default / 1 SPLAT_RANK=atomic / 2 ballots (SPLAT_RANK=ballot, or
+ * after a failed order check); *atomics_ordered = the start-up probe's verdict (1 = in lane order, 0 = not or not asked);
+ * *order_faults = frames of this context whose tile lists failed the order check (each was reported with
+ * SPLAT_ERR_RETRY).  Runs the probe if it has not run yet (synchronises then). */
+int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_t *order_faults);
+/* TEST HOOK: the next per-tile sort of this context swaps the first two entries of tile `tile`'s finished list just
+ * before its order check, as an out-of-lane-order ranking would have left them: the check must raise the frame's flag,
+ * the next call return SPLAT_ERR_RETRY, and the frame rendered again be right.  One shot. */
+int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile);
 /* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
  * (the result is then invalid).  Synchronises. */
 int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag);

@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip.so")
 
 OK = 0
-ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -6: "NO_DEVICE", -7: "COMM"}
+ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -6: "NO_DEVICE", -7: "COMM", -8: "RETRY"}
+# "the previous frame must be rendered again" (its sync-free pair limit overflowed / its lists failed the order check)
+RENDER_AGAIN = (-4, -8)
 
 STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2, 3, 4
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
@@ -79,6 +81,8 @@ SIGNATURES = {
     "splat_sort_sorted_keys": (_vp, [_vp]),
     "splat_probe_lds_atomic_order": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "splat_sort_set_mode": (_i, [_vp, _i]),
+    "splat_rank_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32)]),
+    "splat_debug_inject_order_fault": (_i, [_vp, _u32]),
     "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),
     "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_bin_create": (_i, [_vp, _u32, _pvp]),

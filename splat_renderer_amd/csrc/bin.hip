@@ -401,25 +401,29 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         // first pass of the tile-id sort, fused with the expansion (tile_first.hip); later kernels take
         // their pair count from d_total[2], which k_tf_scatter sets (0 if the pairs do not fit)
         const uint32_t tf_hi_bits = tf_bits - tf_lo_bits;
-        uint32_t *report = async ? b->pinned_dev : nullptr;
-        const uint32_t seq = async ? ++b->seq : 0u;
+        // Every tile-first frame is reported — {pair total, flags, sequence number} into host-mapped words — by its LAST
+        // kernel, the composite (report_for_composite): the flags then include the per-tile sort's order check, which is
+        // what allows these kernels to rank with returning LDS atomics (common.h: rank_atomic_ok).  The report is examined
+        // at the next call (binner_settle).
         rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
                                b->d_total + 1, b->tf_hi, b->wide_a, b->tf_block, tf_lo_bits, tf_hi_bits > 0, &b->tf_runs, b->offsets, tiles,
-                               report, seq);
+                               nullptr, 0u);
         if (rc != SPLAT_OK) return rc;
         // second pass (high digit) into wide_b, and the tile offsets out of its histogram; a screen of at most 256
         // tiles is sorted by the first pass alone (which then writes the offsets too)
         const bool primary = tf_hi_bits == 0;
         rc = tf_second_pass_launch(ctx, b->tf_hi, b->wide_a, b->wide_b, &b->tf_runs, total32, tiles, tf_lo_bits, tf_hi_bits, b->tf2_hist,
-                                   b->offsets, b->d_total, report, seq);
+                                   b->offsets, b->d_total, nullptr, 0u);
         if (rc != SPLAT_OK) return rc;
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
-        // (its first launch also writes the tile counts)
+        // (its first launch also writes the tile counts); every list's order is checked there
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
-                              b->counts);
+                              b->counts, b->d_total + 1);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
-        if (async) b->pending = true; // k_tf_offsets reported {total, overflow, seq} into b->pinned; examined at the next call
+        b->report_for_composite = b->pinned_dev;
+        b->report_seq = ++b->seq;
+        b->pending = true;
     } else if (total32 > 0) {
         hipLaunchKernelGGL(k_bin_expand, dim3(blocks), dim3(BIN_THREADS), 0, ctx->stream, (const uint32_t *)sorted, n_sorted,
                            b->ranges, b->blocksums, ntx, b->pair_limit, b->d_total + 1, b->pairs.keys, b->pairs.payload);
@@ -482,11 +486,21 @@ int binner_settle(splat_binner *b) {
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const uint32_t total = ((volatile uint32_t *)b->pinned)[0], overflow = ((volatile uint32_t *)b->pinned)[1];
+    const uint32_t total = ((volatile uint32_t *)b->pinned)[0], flags = ((volatile uint32_t *)b->pinned)[1];
     b->last_total = total;
     b->have_last = true;
     b->total = total;
-    if (overflow || total > b->pair_limit) {
+    if (flags & FRAME_FLAG_ORDER) {
+        // a tile's list failed k_tile_sort's order check: some pass ranked equal digits out of lane order.  That frame's
+        // lists (and its image) are wrong; from here on this context ranks with ballots, which assume nothing.
+        b->ran = false;
+        ctx->order_faults++;
+        ctx->rank_policy = RANK_BALLOT;
+        return ctx_fail(ctx, SPLAT_ERR_RETRY,
+                        "the previous frame's tile lists failed the order check (ranking with returning LDS atomics was not in lane "
+                        "order): the context now ranks with ballots; render that frame again");
+    }
+    if ((flags & FRAME_FLAG_OVERFLOW) || total > b->pair_limit) {
         // that frame's lists (and anything composited from them) are incomplete: make room, tell the caller
         uint64_t want = (uint64_t)total + total / 2 + 8192;
         if (want > 0x3ffff000ull) want = 0x3ffff000ull;

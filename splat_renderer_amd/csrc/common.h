@@ -24,6 +24,15 @@ struct splat_ctx {
     std::string err;
     bool timing = false;
     int lds_atomic_ordered = -1; // -1 unknown, else the result of radix_probe_lds_atomic_order on this device
+    // Which kernels may rank with returning LDS atomics (stable only if colliding lanes complete in lane order: measured
+    // on gfx950, not an ISA promise).  RANK_CHECKED (default): only where a COMPLETE check of the result follows in the
+    // same frame — the tile-first frame path, whose per-tile sort verifies every list's strict (depth key, index) order
+    // and whose host side renders a frame that failed again with ballots (rank_atomic_ok) — and ballots everywhere else;
+    // RANK_ATOMIC (SPLAT_RANK=atomic): wherever the probe allows; RANK_BALLOT (SPLAT_RANK=ballot, or after a failed
+    // check): nowhere.
+    int rank_policy = 0;
+    uint32_t order_faults = 0;      // frames whose lists failed the order check (each was reported and rendered again)
+    uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars
@@ -78,7 +87,16 @@ int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, u
                      bool iota_payload = false, uint32_t first_bits = 8);
 
 int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host);
-int ctx_resolve_rank_mode(splat_ctx *ctx); // sets ctx->lds_atomic_ordered (probe, or SPLAT_RANK=ballot)
+int ctx_resolve_rank_mode(splat_ctx *ctx); // sets ctx->lds_atomic_ordered (probe) and ctx->rank_policy (SPLAT_RANK)
+constexpr int RANK_CHECKED = 0, RANK_ATOMIC = 1, RANK_BALLOT = 2;
+// may this launch rank with returning LDS atomics?  checked: its result is verified completely later in the frame
+static inline bool rank_atomic_ok(const splat_ctx *ctx, bool checked) {
+    if (ctx->lds_atomic_ordered != 1 || ctx->rank_policy == RANK_BALLOT) return false;
+    return ctx->rank_policy == RANK_ATOMIC || checked;
+}
+// frame flags word (binner d_total[1]): bit 0 = the pairs outgrew the sync-free limit, bit 1 = a tile's list failed the
+// order check of k_tile_sort
+constexpr uint32_t FRAME_FLAG_OVERFLOW = 1u, FRAME_FLAG_ORDER = 2u;
 int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);
 
 struct splat_sorter {
@@ -152,7 +170,11 @@ struct splat_binner {
     uint32_t pair_limit = 0;   // pairs this frame's grids / stores are bounded by
     uint32_t *pinned = nullptr; // 4 u32, host-pinned, mapped into the device's address space as pinned_dev
     uint32_t *pinned_dev = nullptr;
-    uint32_t seq = 0;          // sequence number of the last sync-free frame; its report carries it
+    uint32_t seq = 0;          // sequence number of the last reported frame; its report carries it
+    // tile-first frames: the report {pair total, flags, seq} is sent by the frame's LAST kernel, the composite (its flags
+    // include the per-tile sort's order check); the frame function hands these to the composite launch and clears them
+    uint32_t *report_for_composite = nullptr;
+    uint32_t report_seq = 0;
     hipEvent_t readback_done = nullptr;
 };
 
@@ -210,8 +232,14 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
                           uint32_t *report, uint32_t seq);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts);
-int binner_settle(splat_binner *b); // resolves a pending async readback; SPLAT_ERR_CAPACITY if that frame overflowed
+                     uint32_t *counts, uint32_t *frame_flags); // frame_flags: FRAME_FLAG_ORDER is raised if a list fails the order check
+int binner_settle(splat_binner *b); // resolves a pending report; SPLAT_ERR_CAPACITY if that frame overflowed, SPLAT_ERR_RETRY if its lists failed the order check
+// composite.hip: splat_composite with the frame's report attached (report != NULL: the launch's first workgroup stores
+// {frame_total[0], frame_total[1], seq} into the host-mapped report words; see tile_report)
+int composite_launch(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity, uint32_t color_stride_vec4, const void *normals,
+                     uint32_t normal_stride_vec4, const void *projected, const void *tile_indices, const void *tile_counts,
+                     const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8, void *out_rgba32f, void *consumed_dptr,
+                     const uint32_t *frame_total, uint32_t *report, uint32_t report_seq);
 // project.hip internal: the projector with the optional per-index tile range output
 int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius, uint32_t pr_stride_vec4, uint32_t n,
                    uint32_t index_base, void *projected, void *keys, void *payload, uint32_t n_padded, uint32_t *range32,

@@ -28,6 +28,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 typedef float v2f __attribute__((ext_vector_type(2))); // maps onto the packed FP32 instructions (v_pk_*_f32)
 
 constexpr int CT = 16;        // tile edge (pixels)
@@ -47,6 +49,11 @@ struct CompositeParams {
     uint32_t *out_rgba8;
     float4 *out_rgba32f;
     unsigned long long *consumed; // per tile {entries staged, entries consumed}, accumulated (or NULL)
+    // the frame's report (tile-first frames; NULL otherwise): this launch is the frame's last kernel, so its first
+    // workgroup tells the host {pair total, flags incl. the per-tile sort's order check, sequence number}
+    const uint32_t *frame_total;
+    uint32_t *report;
+    uint32_t report_seq;
 };
 
 __device__ __forceinline__ uint32_t unorm8(float v) {
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     __shared__ uint32_t s_wave_consumed[4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (p.report && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) tile_report(p.frame_total, p.report, p.report_seq);
     const uint32_t tx = blockIdx.x, ty = blockIdx.y + p.tile_row0;
     const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
     const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
@@ -390,6 +398,214 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
     }
 }
 
+// =====================================================================================================================
+// k_composite_px — the lane-efficient composite (round 3; the default for the isotropic footprint, nearest on top).
+//
+// What k_composite spends its time on is lanes that get g = 0: one entry is evaluated by a whole 8x8-pixel wave although
+// its box covers a quarter of it (18.5 live covered pixels per consumed entry at C2, 1.14 wave visits of 64 lanes).
+// Here every lane walks ITS OWN entries, and the Gaussian is not evaluated per pixel at all:
+//   * one WAVE per 16x16 tile (four tiles per workgroup, no workgroup barrier anywhere), lane = a 2x2-pixel block;
+//   * the list is consumed in chunks of 32 entries.  Per chunk the wave stages, in its own 5 KB of LDS,
+//       - the entry's Gaussian as two tables: gx[16] over the tile's pixel columns and gy[16] over its rows —
+//         exp(-(dx^2+dy^2) k^2) = exp(-(dx k)^2) exp(-(dy k)^2), so 32 exponentials per entry serve all 256 pixels —
+//         with the reference's box test (ComputeShaderRenderer.ts:118-121, exact: span_mask16) folded in as zeros,
+//       - its lit colour;
+//   * per lane a 32-bit queue: bit j = entry j's box touches this lane's 2x2 block (eight ballots transpose the
+//     entries' column / row masks into per-column / per-row entry masks; a lane ANDs its column's with its row's);
+//   * a trip = every lane with a non-empty queue takes its next entry: two 8-byte table reads (its two columns, its two
+//     rows), one 16-byte colour read, then four pixels in packed arithmetic: g = gx*gy, w = T*g, C += c*w, T -= w.
+//     Order per pixel is the list's order; pixels of different lanes work on different entries in the same instruction.
+//   * the stop rule is per pixel (exactly :187-190): a pixel whose T reaches T_STOP takes its background term at once
+//     and continues with T = 0 (it adds exact zeros from then on); a lane whose four pixels have stopped empties its
+//     queue; the wave leaves when no pixel is left.
+// Trips per consumed entry at C2: 0.30 (a wave instruction of up to 256 pixel-entries each) against 1.14 visits of a
+// 64-pixel wave.  Reference semantics: /root/reference/src/ComputeShaderRenderer.ts:150-198.
+// =====================================================================================================================
+constexpr int PXC = 32;     // entries per chunk = bits of a lane's queue
+constexpr int PX_ROW = 36;  // float2 slots per table row: 32 entries + 4 — rows 4 slots apart (mod 32) so that the eight
+                            // rows of one entry fall into eight different bank pairs of a ds_read_b64
+struct PxShared {
+    float2 tx[8][PX_ROW]; // tx[c][j] = {gx_j(2c), gx_j(2c+1)}: entry j's factor at the tile's pixel columns 2c, 2c+1
+    float2 ty[8][PX_ROW]; // ty[r][j] = {gy_j(2r), gy_j(2r+1)}
+    float4 col[PXC];      // lit colour of entry j
+};
+static_assert(sizeof(PxShared) == 5120, "four waves x 5 KB: eight workgroups fill a CU's 160 KB");
+
+template <bool EARLY_OUT, bool LIT32>
+__global__ __launch_bounds__(256) void k_composite_px(CompositeParams p, uint32_t band_tiles) {
+    __shared__ PxShared s_all[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t t_local = blockIdx.x * 4u + w;
+    if (p.report && blockIdx.x == 0 && tid == 0) tile_report(p.frame_total, p.report, p.report_seq);
+    if (t_local >= band_tiles) return; // (whole waves: nothing in this kernel waits for another wave)
+    PxShared &sh = s_all[w];
+    const uint32_t tx = t_local % p.ntx, ty = t_local / p.ntx + p.tile_row0;
+    const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
+    const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
+    const uint32_t bx = lane & 7, by = lane >> 3; // this lane's 2x2 block: pixel columns 2bx, 2bx+1, rows 2by, 2by+1 of the tile
+    const uint32_t px0 = tx * CT + 2 * bx, py0 = ty * CT + 2 * by;
+    const bool okx0 = px0 < p.width, okx1 = px0 + 1 < p.width, oky0 = py0 < p.height, oky1 = py0 + 1 < p.height;
+    const float tile_x0 = (float)(tx * CT), tile_y0 = (float)(ty * CT);
+    const float tile_cx = tile_x0 + 0.5f, tile_cy = tile_y0 + 0.5f; // :169 pixel centres
+
+    // pixel (row k, column i) of the block: component i of the k-th pair.  T = transmittance while the pixel accumulates,
+    // 0 once it has stopped (its background term is then already in C) and for pixels outside the image
+    v2f cr[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, cg[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, cb[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    v2f T[2] = {{(okx0 && oky0) ? 1.0f : 0.0f, (okx1 && oky0) ? 1.0f : 0.0f}, {(okx0 && oky1) ? 1.0f : 0.0f, (okx1 && oky1) ? 1.0f : 0.0f}};
+    // wave-uniform masks of the lanes whose pixel (k, i) still accumulates
+    unsigned long long al00 = uniform64(__ballot(okx0 && oky0)), al01 = uniform64(__ballot(okx1 && oky0));
+    unsigned long long al10 = uniform64(__ballot(okx0 && oky1)), al11 = uniform64(__ballot(okx1 && oky1));
+    uint32_t stop_pos = 0; // the largest list position (+1) at which one of this lane's pixels stopped
+    uint32_t staged = 0;
+
+    const uint32_t e = lane & 31, h = lane >> 5; // table building: lane (e, h) computes entry e's x (h = 0) or y (h = 1) table
+    constexpr uint32_t NONE = 0xffffffffu;
+    // entries are fetched a chunk ahead of their use and their indices two chunks ahead (the gather depends on the index)
+    uint32_t idx_cur = e < count ? p.indices[off + e] : NONE;
+    uint32_t idx_nxt = PXC + e < count ? p.indices[off + PXC + e] : NONE;
+    float4 c_b = make_float4(0, 0, 0, 0), c_b2 = c_b, c_c = c_b, c_n = c_b;
+    float c_r = 0.0f;
+    if (idx_cur != NONE) fetch_entry<SPLAT_COMPOSITE_FRONT_TO_BACK, EARLY_OUT, false, LIT32>(p, idx_cur, c_b, c_b2, c_c, c_n, c_r);
+
+    for (uint32_t cb0 = 0; cb0 < count; cb0 += PXC) {
+        if (EARLY_OUT && (al00 | al01 | al10 | al11) == 0) break; // every pixel of the tile has stopped
+        staged = min(cb0 + 2 * PXC, count); // entries gathered so far: this chunk and the one fetched ahead
+        // ---- next chunk's gathers and the index load behind them go out before this chunk is touched
+        float4 n_b = make_float4(0, 0, 0, 0), n_b2 = n_b, n_c = n_b, n_n = n_b;
+        float n_r = 0.0f;
+        if (idx_nxt != NONE) fetch_entry<SPLAT_COMPOSITE_FRONT_TO_BACK, EARLY_OUT, false, LIT32>(p, idx_nxt, n_b, n_b2, n_c, n_n, n_r);
+        const uint32_t idx_nn = cb0 + 2 * PXC + e < count ? p.indices[off + cb0 + 2 * PXC + e] : NONE;
+
+        // ---- stage: both halves of the wave hold entry e; half h builds the table of its axis
+        float k = 0.0f, ck = 0.0f;
+        uint32_t m16 = 0; // this axis's mask of covered pixel columns / rows (zero unless the entry draws something in this tile)
+        if (idx_cur != NONE && !(c_r < 0.5f)) { // :127-129 "too small"
+            const float4 b = c_b;
+            const uint32_t xm = span_mask16(b.x, b.z, tile_cx), ym = span_mask16(b.y, b.w, tile_cy);
+            if (xm != 0 && ym != 0) {
+                // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r (:133-140),
+                // in tile-local coordinates (as k_composite)
+                k = 1.6986436005760381f / c_r;
+                const float lx = (b.x + b.z) * 0.5f - tile_x0, ly = (b.y + b.w) * 0.5f - tile_y0; // :124, then exact
+                ck = (h ? ly : lx) * k;
+                m16 = h ? ym : xm;
+            }
+        }
+        if (h == 0) {
+            const float4 c = (LIT32 || p.prelit) ? c_c : lit_color(c_c, c_n);
+            sh.col[e] = make_float4(c.x, c.y, c.z, 1.0f); // (.w = 1: read back as the factor of T's update, which makes the read one ds_read_b128)
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const v2f pc = {(float)(2 * c2) + 0.5f, (float)(2 * c2) + 1.5f};
+            const v2f t = pc * (v2f){k, k} - (v2f){ck, ck};
+            const v2f q = t * t;
+            // (the box test as a bit mask on the value: v_bfe_i32 spreads the coverage bit over the word)
+            const uint32_t g0 = __float_as_uint(__builtin_amdgcn_exp2f(-q.x)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2, 1);
+            const uint32_t g1 = __float_as_uint(__builtin_amdgcn_exp2f(-q.y)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2 + 1, 1);
+            (h ? sh.ty : sh.tx)[c2][e] = make_float2(__uint_as_float(g0), __uint_as_float(g1));
+        }
+        // ---- queues: bit j of X[c] = entry j's box meets pixel columns 2c, 2c+1; of Y[r] likewise for rows.  One ballot
+        // gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 test the y mask) together.
+        const uint32_t mm = m16 | (m16 >> 1);
+        uint32_t qx = 0, qy = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const unsigned long long bal = __ballot((mm >> (2 * c2)) & 1u);
+            qx = __builtin_amdgcn_inverse_ballot_w64(0x0101010101010101ull << c2) ? (uint32_t)bal : qx;          // lanes with bx == c2
+            qy = __builtin_amdgcn_inverse_ballot_w64(0xffull << (8 * c2)) ? (uint32_t)(bal >> 32) : qy;           // lanes with by == c2
+        }
+        uint32_t mine = qx & qy;
+        if (EARLY_OUT && !__builtin_amdgcn_inverse_ballot_w64(al00 | al01 | al10 | al11)) mine = 0; // this lane's block has stopped
+        // the wave's own LDS stores are read back by other lanes: DS operations of one wave execute in order; the compiler
+        // must not move the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- trips
+        for (;;) {
+            const bool act = mine != 0;
+            if (!__builtin_amdgcn_readfirstlane((int)(__ballot(act) != 0))) break;
+            uint32_t j = 0;
+            if (act) {
+                j = (uint32_t)__builtin_ctz(mine);
+                mine &= mine - 1;
+                const float2 gx = sh.tx[bx][j], gy = sh.ty[by][j];
+                const float4 c = sh.col[j];
+                const v2f gxx = {gx.x, gx.y};
+                const v2f g0 = gxx * (v2f){gy.x, gy.x}, g1 = gxx * (v2f){gy.y, gy.y}; // rows 2by, 2by+1
+                const v2f w0 = T[0] * g0, w1 = T[1] * g1;                                // SURVEY §8a contract 3: nearest on top
+                cr[0] += (v2f){c.x, c.x} * w0; cr[1] += (v2f){c.x, c.x} * w1;
+                cg[0] += (v2f){c.y, c.y} * w0; cg[1] += (v2f){c.y, c.y} * w1;
+                cb[0] += (v2f){c.z, c.z} * w0; cb[1] += (v2f){c.z, c.z} * w1;
+                // T (1 - g) with the product in hand; c.w is 1.0 (exact: the same bits as T - w) — its use keeps the colour
+                // read a single 16-byte ds_read_b128 (4 LDS cycles; the compiler would shrink it to a ds_read_b96: 8)
+                T[0] -= (v2f){c.w, c.w} * w0; T[1] -= (v2f){c.w, c.w} * w1;
+            }
+            if (EARLY_OUT) {
+                // pixels that have just reached alpha >= 0.99 (:187-190): T <= T_STOP on a pixel that was accumulating (a stopped
+                // pixel carries T = 0 and is masked by its `al` bit)
+                // (an accumulating pixel has T > T_STOP until the trip that stops it, so no test of `act` is needed)
+                const unsigned long long f00 = uniform64(__ballot(T[0].x <= T_STOP) & al00);
+                const unsigned long long f01 = uniform64(__ballot(T[0].y <= T_STOP) & al01);
+                const unsigned long long f10 = uniform64(__ballot(T[1].x <= T_STOP) & al10);
+                const unsigned long long f11 = uniform64(__ballot(T[1].y <= T_STOP) & al11);
+                if ((f00 | f01 | f10 | f11) != 0) {
+                    // the background term of :193-195 now, T = 0 from here on
+                    if (__builtin_amdgcn_inverse_ballot_w64(f00)) { cr[0].x += 0.05f * T[0].x; cg[0].x += 0.05f * T[0].x; cb[0].x += 0.1f * T[0].x; T[0].x = 0.0f; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(f01)) { cr[0].y += 0.05f * T[0].y; cg[0].y += 0.05f * T[0].y; cb[0].y += 0.1f * T[0].y; T[0].y = 0.0f; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(f10)) { cr[1].x += 0.05f * T[1].x; cg[1].x += 0.05f * T[1].x; cb[1].x += 0.1f * T[1].x; T[1].x = 0.0f; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(f11)) { cr[1].y += 0.05f * T[1].y; cg[1].y += 0.05f * T[1].y; cb[1].y += 0.1f * T[1].y; T[1].y = 0.0f; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(f00 | f01 | f10 | f11)) stop_pos = max(stop_pos, cb0 + j + 1);
+                    al00 &= ~f00; al01 &= ~f01; al10 &= ~f10; al11 &= ~f11;
+                    if (!__builtin_amdgcn_inverse_ballot_w64(al00 | al01 | al10 | al11)) mine = 0;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next chunk's table stores stay behind this chunk's reads
+        __builtin_amdgcn_wave_barrier();
+        idx_cur = idx_nxt; idx_nxt = idx_nn;
+        c_b = n_b; c_b2 = n_b2; c_c = n_c; c_n = n_n; c_r = n_r;
+    }
+
+    if (p.consumed) { // (uniform branch; timed / diagnostic runs only)
+        // entries this tile needed: the position at which its last pixel stopped, or the whole list if one never did
+        // (SURVEY §8d's P_used per tile = count with early-out off)
+        uint32_t used = stop_pos;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) used = max(used, (uint32_t)__shfl_xor((int)used, d));
+        if (!EARLY_OUT || (al00 | al01 | al10 | al11) != 0) used = count;
+        if (lane == 0 && staged) {
+            p.consumed[(size_t)tile_idx * 2] += (unsigned long long)staged;
+            p.consumed[(size_t)tile_idx * 2 + 1] += (unsigned long long)used;
+        }
+    }
+
+    // :193-197 (a stopped pixel has T = 0 here: its background term went in when it stopped)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t py = py0 + r;
+        if (py >= p.height || !okx0) continue;
+        const float r0 = cr[r].x + 0.05f * T[r].x, g0 = cg[r].x + 0.05f * T[r].x, b0 = cb[r].x + 0.1f * T[r].x;
+        const float r1 = cr[r].y + 0.05f * T[r].y, g1 = cg[r].y + 0.05f * T[r].y, b1 = cb[r].y + 0.1f * T[r].y;
+        const size_t o = (size_t)py * p.width + px0;
+        const uint32_t q0 = unorm8(r0) | (unorm8(g0) << 8) | (unorm8(b0) << 16) | (255u << 24);
+        const uint32_t q1 = unorm8(r1) | (unorm8(g1) << 8) | (unorm8(b1) << 16) | (255u << 24);
+        if (p.out_rgba8) {
+            if (okx1 && (o & 1) == 0) *reinterpret_cast<uint2 *>(p.out_rgba8 + o) = make_uint2(q0, q1);
+            else {
+                p.out_rgba8[o] = q0;
+                if (okx1) p.out_rgba8[o + 1] = q1;
+            }
+        }
+        if (p.out_rgba32f) {
+            p.out_rgba32f[o] = make_float4(r0, g0, b0, 1.0f);
+            if (okx1) p.out_rgba32f[o + 1] = make_float4(r1, g1, b1, 1.0f);
+        }
+    }
+}
+
 extern "C" int splat_lit_colors(splat_ctx *ctx, const void *color_opacity, uint32_t color_stride_vec4, const void *normals,
                                 uint32_t normal_stride_vec4, uint32_t n, void *lit) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
@@ -403,11 +619,45 @@ extern "C" int splat_lit_colors(splat_ctx *ctx, const void *color_opacity, uint3
     return SPLAT_OK;
 }
 
+__global__ void k_frame_report(const uint32_t *frame_total, uint32_t *report, uint32_t seq) { tile_report(frame_total, report, seq); }
+
 extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity,
                                uint32_t color_stride_vec4, const void *normals, uint32_t normal_stride_vec4,
                                const void *projected, const void *tile_indices, const void *tile_counts,
                                const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8, void *out_rgba32f,
                                void *consumed_dptr) {
+    return composite_launch(ctx, cfg, color_opacity, color_stride_vec4, normals, normal_stride_vec4, projected, tile_indices, tile_counts,
+                            tile_offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr, nullptr, nullptr, 0u);
+}
+
+static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity, uint32_t color_stride_vec4,
+                                    const void *normals, uint32_t normal_stride_vec4, const void *projected, const void *tile_indices,
+                                    const void *tile_counts, const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8,
+                                    void *out_rgba32f, void *consumed_dptr, const uint32_t *frame_total, uint32_t *report,
+                                    uint32_t report_seq, bool *launched);
+
+// The composite with the frame's report attached.  Whatever happens to the launch, a report that was promised is sent
+// (the host waits for it at its next call).
+int composite_launch(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity, uint32_t color_stride_vec4, const void *normals,
+                     uint32_t normal_stride_vec4, const void *projected, const void *tile_indices, const void *tile_counts,
+                     const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8, void *out_rgba32f, void *consumed_dptr,
+                     const uint32_t *frame_total, uint32_t *report, uint32_t report_seq) {
+    bool launched = false;
+    const int rc = composite_launch_checked(ctx, cfg, color_opacity, color_stride_vec4, normals, normal_stride_vec4, projected, tile_indices,
+                                            tile_counts, tile_offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr, frame_total, report,
+                                            report_seq, &launched);
+    if (ctx && report && !launched) { // an empty band of tile rows, or a rejected argument: the report goes out on its own
+        hipLaunchKernelGGL(k_frame_report, dim3(1), dim3(1), 0, ctx->stream, frame_total, report, report_seq);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+
+static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *cfg, const void *color_opacity, uint32_t color_stride_vec4,
+                                    const void *normals, uint32_t normal_stride_vec4, const void *projected, const void *tile_indices,
+                                    const void *tile_counts, const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8,
+                                    void *out_rgba32f, void *consumed_dptr, const uint32_t *frame_total, uint32_t *report,
+                                    uint32_t report_seq, bool *launched) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, cfg != nullptr);
     ARG_CHECK(ctx, cfg->tile_size == CT); // the kernel's quadrant mapping is built for 16x16 tiles
@@ -450,6 +700,10 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
     p.out_rgba8 = (uint32_t *)out_rgba8;
     p.out_rgba32f = (float4 *)out_rgba32f;
     p.consumed = (unsigned long long *)consumed_dptr;
+    p.frame_total = frame_total;
+    p.report = report;
+    p.report_seq = report_seq;
+    *launched = true;
     dim3 grid(ntx, r1 - r0), block(256);
     const bool eo = cfg->early_out != 0;
     // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
@@ -460,6 +714,34 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
         if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO, DISC, LIT>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
         else hipLaunchKernelGGL((k_composite<MODE, EO, DISC, LIT>), grid, block, 0, ctx->stream, p);                     \
     } while (0)
+    // Which kernel composites the isotropic footprint nearest-on-top (the frame's default): k_composite_px — one wave per
+    // tile, every lane walking its own entries — unless SPLAT_COMPOSITE=quadrant asks for round 2's k_composite (one
+    // 8x8-pixel wave per quadrant visiting every entry of the tile), which also serves the oriented disc (its footprint is
+    // not separable) and the reference-literal blend.
+    static int s_px = -1;
+    if (s_px < 0) {
+        const char *e = getenv("SPLAT_COMPOSITE");
+        s_px = (e && (e[0] == 'p' || e[0] == 'P')) ? 1 : 0; // (opt-in until it measures faster: SPLAT_COMPOSITE=pixel)
+    }
+    if (s_px && !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
+        const uint32_t band_tiles = ntx * (r1 - r0);
+        const dim3 pgrid(div_up(band_tiles, 4));
+#define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT)                                                                                   \
+    do {                                                                                                                     \
+        if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT>), pgrid, block, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
+        else hipLaunchKernelGGL((k_composite_px<EO, LIT>), pgrid, block, 0, ctx->stream, p, band_tiles);                     \
+    } while (0)
+        if (lit32) {
+            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, true);
+            else    SPLAT_COMPOSITE_PX_LAUNCH(false, true);
+        } else {
+            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, false);
+            else    SPLAT_COMPOSITE_PX_LAUNCH(false, false);
+        }
+#undef SPLAT_COMPOSITE_PX_LAUNCH
+        LAUNCH_CHECK(ctx, "k_composite_px");
+        return SPLAT_OK;
+    }
     if (p.disc) {
         if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, true, false);
         else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, true, false);

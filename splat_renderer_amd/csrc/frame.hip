@@ -305,8 +305,11 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         splat_composite_cfg c2 = *cfg;
         c2.tile_row0 = row0;
         c2.tile_row1 = row1;
-        return splat_composite(ctx, &c2, band_color, band_color_stride, normals, 1, records, binner->pairs.payload, binner->counts,
-                               binner->offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr);
+        uint32_t *report = binner->report_for_composite; // (the frame's last kernel reports it: common.h)
+        binner->report_for_composite = nullptr;
+        return composite_launch(ctx, &c2, band_color, band_color_stride, normals, 1, records, binner->pairs.payload, binner->counts,
+                                binner->offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr, binner->d_total, report,
+                                binner->report_seq);
     }
     sorter->kept_blocks = 0;
     // keep -> sort -> bin with the kept count living on the device: no host round trip in here
@@ -505,8 +508,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     }
     // (n == 0: every list is empty and no record is read; the composite only wants a non-null pointer)
     const void *records = disc ? (n ? (const void *)binner->discs : (projected ? projected : (const void *)counts)) : projected;
-    return splat_composite(ctx, cfg, color, color_stride, normals, 1, records, indices, counts, offsets, width, height, out_rgba8,
-                           out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr);
+    uint32_t *report = binner->report_for_composite; // (tile-first frames: the frame's last kernel reports it: common.h)
+    binner->report_for_composite = nullptr;
+    return composite_launch(ctx, cfg, color, color_stride, normals, 1, records, indices, counts, offsets, width, height, out_rgba8,
+                            out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr, binner->d_total, report, binner->report_seq);
 }
 
 extern "C" {

@@ -486,7 +486,7 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
     }
-    const bool rank_atomic = ctx->lds_atomic_ordered == 1 && !force_ballot_rank;
+    const bool rank_atomic = rank_atomic_ok(ctx, false) && !force_ballot_rank; // (nothing checks a global sort's result)
     const uint32_t parts = div_up(n, RS_PART_KEYS);
     // Between passes the pairs travel INTERLEAVED: (key, payload) as one uint2 per element, laid over
     // the destination's key+payload storage (the two arrays of a ping-pong side are one allocation:
@@ -641,16 +641,22 @@ int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host) {
 
 // Which ranking the sort kernels of this context use.  Returning LDS atomics give a stable rank only if the lanes of
 // one instruction that collide on an address complete in ascending lane order — observed on gfx950, not an ISA
-// promise — so it is probed once per context (radix_probe_lds_atomic_order) and the ballot ranking, which assumes
-// nothing, is used if the probe ever fails.  SPLAT_RANK=ballot in the environment forces the ballot ranking without
-// asking the hardware.
+// promise.  So (the guaranteed ranking measured 12-19 % of a frame, profiles/r03_a_rank_ab.txt):
+//   * default: atomics ONLY in the tile-first frame path, where k_tile_sort checks every tile's final list for strict
+//     (depth key, index) order — a complete check of every pass before it — and a frame that fails is reported, the
+//     context falls back to ballots for good and the frame is rendered again (binner_settle); every other sort (the staged
+//     RadixSorter / GPUTileBinner, the sort-first frame order) ranks with ballots, which assume nothing;
+//   * SPLAT_RANK=atomic: atomics everywhere the start-up probe (radix_probe_lds_atomic_order) allows;
+//   * SPLAT_RANK=ballot: ballots everywhere.
 int ctx_resolve_rank_mode(splat_ctx *ctx) {
     if (ctx->lds_atomic_ordered >= 0) return SPLAT_OK;
     const char *e = getenv("SPLAT_RANK");
     if (e && (e[0] == 'b' || e[0] == 'B')) {
+        ctx->rank_policy = RANK_BALLOT;
         ctx->lds_atomic_ordered = 0;
         return SPLAT_OK;
     }
+    ctx->rank_policy = (e && (e[0] == 'a' || e[0] == 'A')) ? RANK_ATOMIC : RANK_CHECKED;
     uint64_t bad = 1;
     int prc = radix_probe_lds_atomic_order(ctx, &bad);
     if (prc != SPLAT_OK) return prc;
@@ -780,6 +786,23 @@ int splat_sort_set_mode(splat_sorter *s, int mode) {
     if (mode < -1 || mode > 2)
         return ctx_fail(s->ctx, SPLAT_ERR_INVALID, "sort mode must be -1 (default), 0 (rowscan), 1 (onesweep) or 2 (rowscan, ballot ranking)");
     s->mode = mode;
+    return SPLAT_OK;
+}
+
+int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_t *order_faults) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    int rc = ctx_resolve_rank_mode(ctx);
+    if (rc != SPLAT_OK) return rc;
+    if (policy) *policy = ctx->rank_policy;
+    if (atomics_ordered) *atomics_ordered = ctx->lds_atomic_ordered;
+    if (order_faults) *order_faults = ctx->order_faults;
+    return SPLAT_OK;
+}
+
+int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, tile != 0xffffffffu);
+    ctx->inject_order_fault = tile + 1u;
     return SPLAT_OK;
 }
 

@@ -324,7 +324,9 @@ template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS>
 __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
                                                                                     uint32_t n_above, uint2 *vals, uint2 *scratch,
                                                                                     uint32_t *__restrict__ out_idx,
-                                                                                    uint32_t *__restrict__ counts) {
+                                                                                    uint32_t *__restrict__ counts,
+                                                                                    uint32_t *__restrict__ frame_flags,
+                                                                                    uint32_t inject_tile) {
     static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
     constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_LDS_ELEMS ? TS_MAX_ITEMS * TS_THREADS : TS_LDS_ELEMS;
     __shared__ TileSortShared sh;
@@ -446,7 +448,28 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
             }
             __syncthreads();
         }
-        for (uint32_t p = tid; p < n; p += TS_THREADS) out_idx[base + p] = s_el[p].y;
+        if (t == inject_tile && tid == 0 && n >= 2) { // test hook (splat_debug_inject_order_fault): the check below must see this
+            const uint2 a = s_el[0];
+            s_el[0] = s_el[1];
+            s_el[1] = a;
+        }
+        if (t == inject_tile) __syncthreads();
+        // THE ORDER CHECK.  The tile's list must be in strictly increasing (depth key, splat index) order — that IS the
+        // contract (TileBinner.binSorted applied to the stable depth order), so verifying it here verifies every pass
+        // that led to it, in this kernel and in the two passes of the tile-id sort before it, whichever way they ranked:
+        // an unstable rank anywhere leaves equal digits out of their earlier order, i.e. keys or tied indices out of
+        // order in the final list.  One LDS read per element (its successor); a violation raises the frame's flag, and
+        // the host renders the frame again with ballot ranking (binner_settle).
+        bool bad = false;
+        for (uint32_t p = tid; p < n; p += TS_THREADS) {
+            const uint2 a = s_el[p];
+            out_idx[base + p] = a.y;
+            if (p + 1 < n) {
+                const uint2 b = s_el[p + 1];
+                bad |= a.x > b.x || (a.x == b.x && a.y >= b.y);
+            }
+        }
+        if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
         return;
     }
 
@@ -494,38 +517,48 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
         __threadfence_block(); // the next pass reads what other waves of this workgroup just stored
         __syncthreads();
     }
-    for (uint32_t p = tid; p < n; p += TS_THREADS) out_idx[base + p] = src[p].y;
+    bool bad = false; // the order check, as above
+    for (uint32_t p = tid; p < n; p += TS_THREADS) {
+        uint2 a = src[p];
+        if (t == inject_tile && p < 2) a = src[p ^ 1u];
+        out_idx[base + p] = a.y;
+        if (p + 1 < n) {
+            uint2 b = src[p + 1];
+            if (t == inject_tile && p == 0) b = src[0];
+            bad |= a.x > b.x || (a.x == b.x && a.y >= b.y);
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
 }
 
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts) {
+                     uint32_t *counts, uint32_t *frame_flags) {
     {
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
     }
     const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
+    const bool ra = rank_atomic_ok(ctx, true); // (every list is checked below: atomics are allowed here by default)
+    const uint32_t inject = ctx->inject_order_fault ? ctx->inject_order_fault - 1u : 0xffffffffu; // one-shot test hook
+    ctx->inject_order_fault = 0;
     // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
     // a tenth of a C0 frame).
     const bool one_class = tiles <= 3u * 256u;
+#define SPLAT_TILE_SORT(RA, ITEMS, LAST, ABOVE, COUNTS)                                                                                      \
+    hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, scratch, \
+                       out_idx, COUNTS, frame_flags, inject)
     if (one_class) {
-        if (ctx->lds_atomic_ordered == 1)
-            hipLaunchKernelGGL((k_tile_sort<true, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
-                               scratch, out_idx, counts);
-        else
-            hipLaunchKernelGGL((k_tile_sort<false, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
-                               scratch, out_idx, counts);
-    } else if (ctx->lds_atomic_ordered == 1) {
-        hipLaunchKernelGGL((k_tile_sort<true, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
-                           scratch, out_idx, counts);
-        hipLaunchKernelGGL((k_tile_sort<true, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
-                           vals, scratch, out_idx, nullptr);
+        if (ra) SPLAT_TILE_SORT(true, TS_LONG_ITEMS, true, 0u, counts);
+        else SPLAT_TILE_SORT(false, TS_LONG_ITEMS, true, 0u, counts);
+    } else if (ra) {
+        SPLAT_TILE_SORT(true, TS_SHORT_ITEMS, false, 0u, counts);
+        SPLAT_TILE_SORT(true, TS_LONG_ITEMS, true, short_cap, nullptr);
     } else {
-        hipLaunchKernelGGL((k_tile_sort<false, TS_SHORT_ITEMS, false>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, 0u, vals,
-                           scratch, out_idx, counts);
-        hipLaunchKernelGGL((k_tile_sort<false, TS_LONG_ITEMS, true>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, short_cap,
-                           vals, scratch, out_idx, nullptr);
+        SPLAT_TILE_SORT(false, TS_SHORT_ITEMS, false, 0u, counts);
+        SPLAT_TILE_SORT(false, TS_LONG_ITEMS, true, short_cap, nullptr);
     }
+#undef SPLAT_TILE_SORT
     LAUNCH_CHECK(ctx, "k_tile_sort");
     return SPLAT_OK;
 }
@@ -730,7 +763,7 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
         LAUNCH_CHECK(ctx, "k_tf_upsweep2");
         int rc = radix_rowscan_launch(ctx, hist, num_parts, hmask + 1u);
         if (rc != SPLAT_OK) return rc;
-        if (ctx->lds_atomic_ordered == 1)
+        if (rank_atomic_ok(ctx, true)) // (checked: k_tile_sort verifies every list this pass contributes to)
             hipLaunchKernelGGL(k_tf_downsweep2<true>, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask,
                                num_parts, hist, totals);
         else
@@ -757,7 +790,7 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
     }
-    const bool ra = ctx->lds_atomic_ordered == 1;
+    const bool ra = rank_atomic_ok(ctx, true); // (checked: k_tile_sort verifies every list this pass contributes to)
 #define SPLAT_TF_SCATTER(RA, PER)                                                                                                 \
     hipLaunchKernelGGL((k_tf_scatter<RA, PER>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
                        hist, totals, d_total, pair_limit, overflow, out_hi, out_val, lo_bits, second_pass ? TF_RUN_ALIGN - 1u : 0u, *runs,         \

@@ -182,7 +182,7 @@ class HipStages:
                 self.width, self.height, out_image.data_ptr(), None,
                 self.consumed.data_ptr() if self.consumed is not None else None)
         rc = self.lib.splat_band_frame(*args)
-        if rc == -4:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
+        if rc in _lib.RENDER_AGAIN:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
             self.overflows += 1
             rc = self.lib.splat_band_frame(*args)
         check(rc, self.ctx)
@@ -190,7 +190,7 @@ class HipStages:
             t, k = C.c_uint64(), C.c_uint32()
             for _ in range(4):  # kept-count overflow, then pair overflow, at worst
                 rc = self.lib.splat_band_settle(self.ctx, self.sorter, self.binner, C.byref(k), C.byref(t))
-                if rc != -4:
+                if rc not in _lib.RENDER_AGAIN:
                     break
                 self.overflows += 1
                 check(self.lib.splat_band_frame(*args), self.ctx)
@@ -217,14 +217,14 @@ class HipStages:
         else:
             fn, args = self.lib.splat_render_frame, head + (props_ptr,) + tail
         rc = fn(*args)
-        if rc == -4:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
+        if rc in _lib.RENDER_AGAIN:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
             self.overflows += 1
             rc = fn(*args)
         check(rc, self.ctx)
         if settle:
             t = C.c_uint64()
             rc = self.lib.splat_bin_total(self.binner, C.byref(t))
-            if rc == -4:
+            if rc in _lib.RENDER_AGAIN:
                 self.overflows += 1
                 check(fn(*args), self.ctx)
                 rc = self.lib.splat_bin_total(self.binner, C.byref(t))

@@ -131,6 +131,19 @@ class Device:
         check(self.lib.splat_stage_time_ms(self.ctx, stage, C.byref(ms)), self.ctx)
         return float(ms.value)
 
+    def rankStatus(self):
+        """How this context ranks equal digits in its sort kernels (include/splat.h, NOTE on ranking): dict(policy =
+        'checked' | 'atomic' | 'ballot', atomicsOrdered = the start-up probe's verdict, orderFaults = frames whose tile
+        lists failed the per-tile sort's order check and were rendered again)."""
+        pol, ordered, faults = C.c_int(), C.c_int(), C.c_uint32()
+        check(self.lib.splat_rank_status(self.ctx, C.byref(pol), C.byref(ordered), C.byref(faults)), self.ctx)
+        return {"policy": ("checked", "atomic", "ballot")[pol.value], "atomicsOrdered": bool(ordered.value == 1),
+                "orderFaults": int(faults.value)}
+
+    def injectOrderFault(self, tile):
+        """TEST HOOK (splat_debug_inject_order_fault): the next per-tile sort leaves tile `tile`'s first two entries swapped."""
+        check(self.lib.splat_debug_inject_order_fault(self.ctx, int(tile)), self.ctx)
+
     def destroy(self):
         if self.ctx:
             self.lib.splat_ctx_destroy(self.ctx)
@@ -736,7 +749,7 @@ class Renderer:
             fn, args = d.lib.splat_render_frame, head + (propertyBuffer.ptr,) + tail
         self._last = (fn, args, u, cfg)  # keeps u/cfg alive; finish() may have to render this frame again
         rc = fn(*args)
-        if rc == -4:  # SPLAT_ERR_CAPACITY: the PREVIOUS (sync-free) frame outgrew its pair limit; room was made
+        if rc in _lib.RENDER_AGAIN:  # SPLAT_ERR_CAPACITY: the PREVIOUS (sync-free) frame outgrew its pair limit; room was made
             self.previousFrameOverflowed = True
             rc = fn(*args)
         check(rc, d.ctx)
@@ -750,7 +763,7 @@ class Renderer:
         d = self.device
         t = C.c_uint64()
         rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
-        if rc == -4 and self._last is not None:
+        if rc in _lib.RENDER_AGAIN and self._last is not None:
             self.previousFrameOverflowed = True
             check(self._last[0](*self._last[1]), d.ctx)
             rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))

@@ -126,6 +126,11 @@ static napi_value check(napi_env env, splat_ctx *ctx, int rc, napi_value ok) {
     return NULL;
 }
 
+/* A frame function that returns SPLAT_ERR_CAPACITY / SPLAT_ERR_RETRY is reporting the PREVIOUS (sync-free) frame — it
+ * outgrew its pair limit, or its lists failed the order check; room has been made / the ranking switched — and has not
+ * rendered this one: call it again (include/splat.h).  The Python facades do the same (host.py Renderer.render). */
+#define AGAIN(rc) ((rc) == SPLAT_ERR_CAPACITY || (rc) == SPLAT_ERR_RETRY)
+
 #define FN(name) static napi_value name(napi_env env, napi_callback_info info)
 #define ARGS(n) call_t c; if (!get_args(env, info, &c, n)) return NULL
 #define BAIL if (c.failed) return NULL
@@ -284,7 +289,9 @@ FN(render_frame) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), props, nor
     void *props = arg_dptr(&c, 5), *nrm = arg_dptr(&c, 6); uint32_t n = (uint32_t)arg_number(&c, 7), w = (uint32_t)arg_number(&c, 8), h = (uint32_t)arg_number(&c, 9);
     void *proj = arg_dptr(&c, 10), *o8 = arg_dptr(&c, 11), *of = arg_dptr(&c, 12); BAIL;
     if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
-    return check(env, x, splat_render_frame(x, s, b, &cfg, u, props, nrm, n, w, h, proj, o8, of), mk_undefined(env));
+    int rc = splat_render_frame(x, s, b, &cfg, u, props, nrm, n, w, h, proj, o8, of);
+    if (AGAIN(rc)) rc = splat_render_frame(x, s, b, &cfg, u, props, nrm, n, w, h, proj, o8, of);
+    return check(env, x, rc, mk_undefined(env));
 }
 
 FN(render_frame_planes) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), posRadius, colorOpacity, normals, n, W, H, projected, out8|null, outF|null) */
@@ -294,7 +301,9 @@ FN(render_frame_planes) { /* (ctx, sorter, binner, cfg[5], Float32Array(22), pos
     uint32_t n = (uint32_t)arg_number(&c, 8), w = (uint32_t)arg_number(&c, 9), h = (uint32_t)arg_number(&c, 10);
     void *proj = arg_dptr(&c, 11), *o8 = arg_dptr(&c, 12), *of = arg_dptr(&c, 13); BAIL;
     if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
-    return check(env, x, splat_render_frame_planes(x, s, b, &cfg, u, pr, co, nrm, n, w, h, proj, o8, of), mk_undefined(env));
+    int rc = splat_render_frame_planes(x, s, b, &cfg, u, pr, co, nrm, n, w, h, proj, o8, of);
+    if (AGAIN(rc)) rc = splat_render_frame_planes(x, s, b, &cfg, u, pr, co, nrm, n, w, h, proj, o8, of);
+    return check(env, x, rc, mk_undefined(env));
 }
 
 /* ---- SDF splat generation (include/splat.h: "SDF splat generation") ---- */
@@ -361,7 +370,9 @@ FN(band_frame) { /* (ctx, sorter, binner, cfg[8], props, normals|null, records, 
     void *props = arg_dptr(&c, 4), *nrm = arg_dptr(&c, 5), *rec = arg_dptr(&c, 6);
     uint32_t n = (uint32_t)arg_number(&c, 7), w = (uint32_t)arg_number(&c, 8), h = (uint32_t)arg_number(&c, 9);
     void *o8 = arg_dptr(&c, 10), *of = arg_dptr(&c, 11); BAIL;
-    return check(env, x, splat_band_frame(x, s, b, &cfg, props, nrm, rec, n, w, h, o8, of, NULL), mk_undefined(env));
+    int rc = splat_band_frame(x, s, b, &cfg, props, nrm, rec, n, w, h, o8, of, NULL);
+    if (AGAIN(rc)) rc = splat_band_frame(x, s, b, &cfg, props, nrm, rec, n, w, h, o8, of, NULL);
+    return check(env, x, rc, mk_undefined(env));
 }
 FN(band_settle) { /* (ctx, sorter, binner) -> pairs of the last band frame (waits for it; throws if it overflowed: render it again) */
     ARGS(3); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); splat_binner *b = arg_external(&c, 2); BAIL;

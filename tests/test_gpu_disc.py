@@ -12,7 +12,7 @@ import pytest
 import splat_renderer_amd as sr
 from oracle import oracle as O
 from splat_renderer_amd import _lib
-from tests.helpers import make_case
+from tests.helpers import assert_same, make_case
 
 pytestmark = pytest.mark.gpu
 
@@ -80,18 +80,18 @@ def test_disc_projector_bit_exact(device, n, w, h, seed, rs):
     with pytest.raises(sr.SplatError):
         proj.project(None, u, pm.getPropertyBuffer())  # the disc projector reads the normals
     proj.project(None, u, pm.getPropertyBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), sorter.paddedSize, normalsBuffer=nbuf)
-    assert np.array_equal(bits(proj.getDiscBuffer().read(np.float32)).reshape(n, 8), bits(ref["discs"]))
-    assert np.array_equal(bits(proj.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]))
-    assert np.array_equal(sorter.getKeysBuffer().read(np.uint32), ref["keys"])
-    assert np.array_equal(sorter.getPayloadBuffer().read(np.uint32), ref["payload"])
+    assert_same(bits(proj.getDiscBuffer().read(np.float32)).reshape(n, 8), bits(ref["discs"]), "disc L83")
+    assert_same(bits(proj.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]), "disc L84")
+    assert_same(sorter.getKeysBuffer().read(np.uint32), ref["keys"], "disc L85")
+    assert_same(sorter.getPayloadBuffer().read(np.uint32), ref["payload"], "disc L86")
     # from a position plane (stride 1) through the C ABI directly: same bits
     planes = pm.getPropertyPlanes()
     out_p, out_d = device.createBuffer(n * 32), device.createBuffer(n * 32)
     uu = np.ascontiguousarray(u, np.float32)
     _lib.check(device.lib.splat_project_disc(device.ctx, uu.ctypes.data_as(C.POINTER(C.c_float)), planes.posRadius.ptr, 1, nbuf.ptr, 1, n,
                                              out_p.ptr, out_d.ptr, None, None, 0), device.ctx)
-    assert np.array_equal(bits(out_d.read(np.float32)).reshape(n, 8), bits(ref["discs"]))
-    assert np.array_equal(bits(out_p.read(np.float32)).reshape(n, 8), bits(ref["proj"]))
+    assert_same(bits(out_d.read(np.float32)).reshape(n, 8), bits(ref["discs"]), "disc L93")
+    assert_same(bits(out_p.read(np.float32)).reshape(n, 8), bits(ref["proj"]), "disc L94")
     with pytest.raises(sr.SplatError):
         sr.SplatProjector(device, 4).getDiscBuffer()
     for o in (pm, nbuf, proj, sorter, out_p, out_d):
@@ -113,10 +113,10 @@ def test_disc_staged_pipeline_vs_oracle(device, n, w, h, seed, rs, early_out):
     sorter.sort()
     binner.binSplats(None, proj.getProjectedBuffer(), sorter.getSortedIndicesBuffer(), n, w, h)
     total = ref["indices"].shape[0]
-    assert np.array_equal(sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n])
+    assert_same(sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n], "disc L116")
     assert binner.getTotalIndices() == total
-    assert np.array_equal(binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert_same(binner.getTileCountsBuffer().read(np.uint32), ref["counts"], "disc L118")
+    assert_same(binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "disc L119")
     # TileRenderer with its own (the reference's) footprint
     tr = sr.TileRenderer(device, None, "rgba8unorm", earlyOut=early_out, footprint="disc")
     tr.bindTileData(proj.getDiscBuffer(), binner.getTileCountsBuffer(), binner.getTileOffsetsBuffer())
@@ -174,9 +174,9 @@ def test_disc_whole_frame(device, order, layout):
         r.render(u, src, nbuf, None, w, h, wantFloat=True)
     total = r.finish()
     assert total == ref["indices"].shape[0]
-    assert np.array_equal(bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]))
-    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert_same(bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]), "disc L177")
+    assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], "disc L178")
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "disc L179")
     check_image(r.readPixelsFloat(), ref)
     if layout == "lit":
         with pytest.raises(sr.SplatError):  # the disc projector needs the normals even when the colours are pre-lit
@@ -186,8 +186,8 @@ def test_disc_whole_frame(device, order, layout):
     r2.projector.getProjectedBuffer().zero()
     r2.render(u, src, nbuf, None, w, h, wantFloat=True)
     assert r2.finish() == total
-    assert np.array_equal(r2.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
-    assert np.array_equal(r2.readPixelsFloat().view(np.uint32), r.readPixelsFloat().view(np.uint32))
+    assert_same(r2.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "disc L189")
+    assert_same(r2.readPixelsFloat().view(np.uint32), r.readPixelsFloat().view(np.uint32), "disc L190")
     assert not r2.projector.getProjectedBuffer().read(np.uint32).any()
     r2.destroy()
     with pytest.raises(sr.SplatError):
@@ -273,7 +273,7 @@ def test_disc_virtual_ranks_band_frame_matches_single_gpu(device, world):
         stages.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard, nt.data_ptr())
     gathered = torch.cat([br.shard for br in renderers], dim=0).contiguous()
     rec = gathered.cpu().numpy()[:n]
-    assert np.array_equal(bits(rec[:, :8]), bits(ref["discs"]))
+    assert_same(bits(rec[:, :8]), bits(ref["discs"]), "disc L276")
     assert np.array_equal(bits(rec[:, 8]), bits(ref["proj"][:, 4])) and not rec[:, 9:].any()
     got = np.zeros_like(want)
     for br in renderers:
@@ -281,7 +281,7 @@ def test_disc_virtual_ranks_band_frame_matches_single_gpu(device, world):
         torch.cuda.synchronize()
         r0, r1 = br.pixel_rows()
         got[r0:r1] = br.image.cpu().numpy()[r0:r1]
-    assert np.array_equal(got, want)
+    assert_same(got, want, "disc L284")
     # and a sort-first band frame says what it cannot do instead of rendering something else
     lib = device.lib
     _lib.check(lib.splat_bin_set_frame_order(stages.binner, 0), stages.ctx)  # SPLAT_FRAME_ORDER_SORT_FIRST
@@ -322,7 +322,7 @@ def test_disc_frame_pipeline_two_frames_in_flight(device):
             pipe.exchange(k + 1, cams[k + 1], pt.data_ptr(), nt.data_ptr())
         got.append(pipe.band(k, pt.data_ptr(), nt.data_ptr(), settle=True).cpu().numpy().copy())
     for k in range(4):
-        assert np.array_equal(got[k], want[k])
+        assert_same(got[k], want[k], "disc L325")
     assert not np.array_equal(want[0], want[1])
     pipe.destroy()
     stages.destroy()
@@ -343,14 +343,14 @@ def test_disc_full_size_C2_properties(device):
     b.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
     total = a.finish()
     assert total == b.finish()
-    assert np.array_equal(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(proj_ref))
+    assert_same(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(proj_ref), "disc L346")
     counts = a.binner.getTileCountsBuffer().read(np.uint32)
     offsets = a.binner.getTileOffsetsBuffer().read(np.uint32)
     idx = a.binner.getTileIndicesBuffer().read(np.uint32, total)
-    assert np.array_equal(offsets, b.binner.getTileOffsetsBuffer().read(np.uint32))
-    assert np.array_equal(idx, b.binner.getTileIndicesBuffer().read(np.uint32, total))
+    assert_same(offsets, b.binner.getTileOffsetsBuffer().read(np.uint32), "disc L350")
+    assert_same(idx, b.binner.getTileIndicesBuffer().read(np.uint32, total), "disc L351")
     img = a.readPixelsFloat()
-    assert np.array_equal(img.view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    assert_same(img.view(np.uint32), b.readPixelsFloat().view(np.uint32), "disc L353")
     assert int(counts.sum(dtype=np.uint64)) == total
     # depth order inside every list, ties by ascending index
     depth = proj_ref[idx, 4]
@@ -418,7 +418,7 @@ def test_exchange_free_bands_stitch_to_the_single_gpu_frame(device, footprint, p
     stages = dist.HipStages(torch, 0, n, w, h, footprint=footprint)
     if prelit:
         stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
-        assert np.array_equal(stages.pos_plane.cpu().numpy(), props[:, :4])
+        assert_same(stages.pos_plane.cpu().numpy(), props[:, :4], "disc L421")
     got = np.zeros_like(want)
     for rank in range(world):
         lr = dist.LocalBandRenderer(stages, n, w, h, rank, world)
@@ -428,7 +428,7 @@ def test_exchange_free_bands_stitch_to_the_single_gpu_frame(device, footprint, p
         torch.cuda.synchronize()
         r0, r1 = lr.pixel_rows()
         got[r0:r1] = lr.image.cpu().numpy()[r0:r1]
-    assert np.array_equal(got, want)
+    assert_same(got, want, "disc L431")
     stages.destroy()
     for o in (full, pbuf, nbuf):
         o.destroy()
@@ -458,7 +458,7 @@ def test_full_size_C2_eight_exchange_free_bands_stitch_bit_identically(device, f
         assert np.array_equal(c[r0:r1], counts_full.reshape(nty, -1)[r0:r1])  # the band's lists are the full frame's
         pairs += int(c[r0:r1].sum(dtype=np.uint64))
     assert pairs == total
-    assert np.array_equal(got, want)
+    assert_same(got, want, "disc L461")
     for o in (r, pbuf, nbuf):
         o.destroy()
 
@@ -506,10 +506,10 @@ def test_disc_random_scenes(device):
         tag = (case, n, w, h, rs, cam)
         total = ref["indices"].shape[0]
         assert r.finish() == total, tag
-        assert np.array_equal(bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"])), tag
-        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"]), tag
+        assert_same(bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), bits(ref["proj"]), ("disc L509", tag))
+        assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], ("disc L510", tag))
         if total:
-            assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), tag
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("disc L512", tag))
         got = r.readPixelsFloat()
         d = np.abs(got - ref["img"]).max(axis=2)
         off = ref["rim"] == 0

@@ -4,6 +4,7 @@ Bit-exact: ProjectedSplat records, keys, payload, sort order, scan, tile counts/
 Tolerance (stated below): composited pixels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -11,7 +12,7 @@ import pytest
 import splat_renderer_amd as sr
 from oracle import oracle as O
 from splat_renderer_amd import _lib
-from tests.helpers import make_case, oracle_pipeline
+from tests.helpers import assert_same, make_case, oracle_pipeline
 
 pytestmark = pytest.mark.gpu
 
@@ -83,15 +84,15 @@ def test_project_and_keys_bit_exact(device, n, w, h, seed):
     proj.project(enc, u, pm.getPropertyBuffer())
     ext.extract(enc, proj.getProjectedBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), n, sorter.paddedSize)
     got = proj.getProjectedBuffer().read(np.float32).reshape(n, 8)
-    assert np.array_equal(bits(got), bits(ref["proj"]))
+    assert_same(bits(got), bits(ref["proj"]), "L86")
     assert sorter.paddedSize == sr.scene.padded_size(n)
-    assert np.array_equal(sorter.getKeysBuffer().read(np.uint32), ref["keys"])
-    assert np.array_equal(sorter.getPayloadBuffer().read(np.uint32), ref["payload"])
+    assert_same(sorter.getKeysBuffer().read(np.uint32), ref["keys"], "L88")
+    assert_same(sorter.getPayloadBuffer().read(np.uint32), ref["payload"], "L89")
     # fused form writes the same keys
     sorter.getKeysBuffer().zero()
     proj.project(enc, u, pm.getPropertyBuffer(), sorter.getKeysBuffer(), sorter.getPayloadBuffer(), sorter.paddedSize)
-    assert np.array_equal(sorter.getKeysBuffer().read(np.uint32), ref["keys"])
-    assert np.array_equal(bits(proj.getProjectedBuffer().read(np.float32)), bits(ref["proj"]).reshape(-1))
+    assert_same(sorter.getKeysBuffer().read(np.uint32), ref["keys"], "L93")
+    assert_same(bits(proj.getProjectedBuffer().read(np.float32)), bits(ref["proj"]).reshape(-1), "L94")
     for o in (pm, proj, sorter):
         o.destroy()
 
@@ -119,8 +120,8 @@ def test_radix_sort_stable(device, n, kind, mode):
     s.sort(n)
     assert s.lookbackTimeouts() == 0
     order = np.argsort(keys, kind="stable").astype(np.uint32)
-    assert np.array_equal(s.getSortedIndicesBuffer().read(np.uint32, n), order)
-    assert np.array_equal(s.getSortedKeysBuffer().read(np.uint32, n), keys[order])
+    assert_same(s.getSortedIndicesBuffer().read(np.uint32, n), order, "L122")
+    assert_same(s.getSortedKeysBuffer().read(np.uint32, n), keys[order], "L123")
     s.destroy()
 
 
@@ -137,8 +138,8 @@ def test_radix_sort_bit_ranges(device, bits_range):
     s.sort(n, b0, b1)
     sub = (keys >> np.uint32(b0)) & np.uint32((1 << (b1 - b0)) - 1)
     order = np.argsort(sub, kind="stable")
-    assert np.array_equal(s.getSortedIndicesBuffer().read(np.uint32, n), payload[order])
-    assert np.array_equal(s.getSortedKeysBuffer().read(np.uint32, n), keys[order])
+    assert_same(s.getSortedIndicesBuffer().read(np.uint32, n), payload[order], "L140")
+    assert_same(s.getSortedKeysBuffer().read(np.uint32, n), keys[order], "L141")
     s.destroy()
 
 
@@ -170,12 +171,12 @@ def test_scan_exclusive(device, n):
     tot = device.createBuffer(16)
     scanner.scan(None, src, dst, n, tot)
     want = np.concatenate([[0], np.cumsum(a, dtype=np.uint64)[:-1]]).astype(np.uint32)
-    assert np.array_equal(dst.read(np.uint32, n), want)
+    assert_same(dst.read(np.uint32, n), want, "L173")
     assert int(tot.read(np.uint32, 1)[0]) == int(a.sum(dtype=np.uint64) & 0xFFFFFFFF)
     if n == 5:
         assert dst.read(np.uint32, 5).tolist() == [0, 1, 3, 6, 10]  # GPU_PIPELINE_PLAN.md:632-635
     scanner.scan(None, src, src, n)  # in place
-    assert np.array_equal(src.read(np.uint32, n), want)
+    assert_same(src.read(np.uint32, n), want, "L178")
     for b in (src, dst, tot):
         b.destroy()
 
@@ -212,12 +213,12 @@ def test_sort_and_bin_bit_exact(device, n, w, h, seed, rs):
     props, normals, u = make_case(n, w, h, seed, rs)
     ref = oracle_pipeline(props, normals, u, w, h)
     g = run_gpu_pipeline(device, props, normals, u, n, w, h)
-    assert np.array_equal(g["sorter"].getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n])
+    assert_same(g["sorter"].getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n], "L215")
     b = g["binner"]
     assert b.getTotalIndices() == ref["indices"].shape[0]
-    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
-    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    assert_same(b.getTileCountsBuffer().read(np.uint32), ref["counts"], "L218")
+    assert_same(b.getTileOffsetsBuffer().read(np.uint32), ref["offsets"], "L219")
+    assert_same(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"], "L220")
     destroy_all(g)
 
 
@@ -247,9 +248,9 @@ def test_bin_offscreen_and_padding(device):
     sbuf = device.createBufferFrom(sorted_idx)
     b = sr.GPUTileBinner(device, 16)
     b.binSplats(None, pbuf, sbuf, n, w, h, numSorted=sorted_idx.shape[0])
-    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), counts)
-    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), offsets)
-    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, idx.shape[0]), idx)
+    assert_same(b.getTileCountsBuffer().read(np.uint32), counts, "L250")
+    assert_same(b.getTileOffsetsBuffer().read(np.uint32), offsets, "L251")
+    assert_same(b.getTileIndicesBuffer().read(np.uint32, idx.shape[0]), idx, "L252")
     b.destroy()
     pbuf.destroy()
     sbuf.destroy()
@@ -298,11 +299,17 @@ def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
         cons = r.consumedBuffer.read(np.uint64).reshape(nty * ntx, 2)
         tile_stop, tile_near = tile_max(stop, 16), tile_max(near, 16) > 0
         ok = ~tile_near.reshape(-1)
-        assert np.array_equal(cons[ok, 1], tile_stop.reshape(-1)[ok].astype(np.uint64))
-        batches = np.minimum(ref["counts"].astype(np.uint64), (cons[:, 1] + np.uint64(255)) // np.uint64(256) * np.uint64(256))
-        assert np.array_equal(cons[:, 0], batches)
+        assert_same(cons[ok, 1], tile_stop.reshape(-1)[ok].astype(np.uint64), "L301")
+        # entries gathered: k_composite_px (nearest-on-top, the default) works in chunks of 32 and fetches one chunk ahead;
+        # k_composite (reference-literal blend, SPLAT_COMPOSITE=quadrant) stages batches of 256
+        counts64 = ref["counts"].astype(np.uint64)
+        if mode == sr.MODE_FRONT_TO_BACK and os.environ.get("SPLAT_COMPOSITE", "q")[:1].lower() == "p":
+            staged_want = np.minimum(counts64, (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32) + np.uint64(32))
+        else:
+            staged_want = np.minimum(counts64, (cons[:, 1] + np.uint64(255)) // np.uint64(256) * np.uint64(256))
+        assert_same(cons[:, 0], staged_want, "entries staged per tile")
         if not early_out:
-            assert np.array_equal(cons[:, 1], ref["counts"].astype(np.uint64))
+            assert_same(cons[:, 1], ref["counts"].astype(np.uint64), "L305")
         if fmt == _lib.RECORDS_LIT32:
             records.destroy()
         r.destroy()
@@ -348,7 +355,7 @@ def test_band_rendering_stitches_bit_identically(device, bands):
         r.render(u, pbuf, nbuf, None, w, h, tileRows=(r0, r1), wantFloat=True)
         img = r.readPixelsFloat()
         stitched[r0 * 16:min(r1 * 16, h)] = img[r0 * 16:min(r1 * 16, h)]
-    assert np.array_equal(stitched.view(np.uint32), want.view(np.uint32))
+    assert_same(stitched.view(np.uint32), want.view(np.uint32), "L351")
     full.destroy()
     r.destroy()
     pbuf.destroy()
@@ -367,7 +374,7 @@ def test_update_props(device):
     pb, cb = device.createBufferFrom(pos), device.createBufferFrom(cur)
     pm.updateFromCurvature(None, pb, cb)
     got = pm.getPropertyBuffer().read(np.float32).reshape(n, 8)
-    assert np.array_equal(bits(got), bits(want))
+    assert_same(bits(got), bits(want), "L370")
     for o in (pm, pb, cb):
         o.destroy()
 
@@ -386,12 +393,12 @@ def test_full_frame_C0(device, order, records):
     r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order, records=records)
     r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
     if order == "sortFirst":  # (the tile-first order never sorts the splats globally)
-        assert np.array_equal(r.sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"])
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32), ref["indices"])
+        assert_same(r.sorter.getSortedIndicesBuffer().read(np.uint32, n), ref["order"], "L389")
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32), ref["indices"], "L390")
     check_image_against_oracle(r.readPixelsFloat(), r.readPixels(), want, want8, near)
     # what the frame's projector left behind: the reference's ProjectedSplat records, or the lit composite records
     rec = bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8)
-    assert np.array_equal(rec, bits(lit_records(u, props, normals) if records == "lit" else ref["proj"]))
+    assert_same(rec, bits(lit_records(u, props, normals) if records == "lit" else ref["proj"]), "L394")
     r.destroy()
     pbuf.destroy()
     nbuf.destroy()
@@ -422,9 +429,9 @@ def test_lit_composite_records_give_the_same_frame_bit_for_bit(device, order):
                 b.render(u, pbuf, None if layout == "prelit" else nbuf, None, w, h, wantFloat=True)
             assert b.finish() == total, layout
             assert b.recordFormat == _lib.RECORDS_LIT32
-            assert np.array_equal(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), want_rec), layout
-            assert np.array_equal(b.binner.getTileIndicesBuffer().read(np.uint32, total), lists), layout
-            assert np.array_equal(b.readPixelsFloat().view(np.uint32), img), layout
+            assert_same(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), want_rec, ("L425", layout))
+            assert_same(b.binner.getTileIndicesBuffer().read(np.uint32, total), lists, ("L426", layout))
+            assert_same(b.readPixelsFloat().view(np.uint32), img, ("L427", layout))
             b.destroy()
         a.destroy()
     # a band of tile rows (the exchange-free multi-GPU cut): records of splats that can reach the band, same pixels
@@ -432,7 +439,7 @@ def test_lit_composite_records_give_the_same_frame_bit_for_bit(device, order):
     full.render(u, pm.getPropertyBuffer(), nbuf, None, w, h)
     band = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
     band.render(u, pm.getPropertyBuffer(), nbuf, None, w, h, tileRows=(5, 11))
-    assert np.array_equal(band.readPixels()[80:176], full.readPixels()[80:176])
+    assert_same(band.readPixels()[80:176], full.readPixels()[80:176], "L435")
     for o in (full, band, pm, nbuf):
         o.destroy()
 
@@ -468,7 +475,7 @@ def test_virtual_ranks_band_frame_matches_single_gpu(device, world):
         r0, r1 = br.pixel_rows()
         got[r0:r1] = br.image.cpu().numpy()[r0:r1]
         kept.append(stages.kept)
-    assert np.array_equal(got, want)
+    assert_same(got, want, "L471")
     assert all(0 < k < n for k in kept) and sum(kept) >= n * 0.9  # bands keep a subset; overlaps allowed
     stages.destroy()
     full.destroy()
@@ -483,12 +490,12 @@ def test_golden_fixtures(device, name):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     n, w, h, _ = (int(x) for x in g["dims"])
     gpu = run_gpu_pipeline(device, g["props"], g["normals"], g["uniforms"], n, w, h)
-    assert np.array_equal(bits(gpu["proj"].getProjectedBuffer().read(np.float32)), bits(g["projected"]).reshape(-1))
-    assert np.array_equal(gpu["sorter"].getSortedIndicesBuffer().read(np.uint32, n), g["order"][:n])
+    assert_same(bits(gpu["proj"].getProjectedBuffer().read(np.float32)), bits(g["projected"]).reshape(-1), "L486")
+    assert_same(gpu["sorter"].getSortedIndicesBuffer().read(np.uint32, n), g["order"][:n], "L487")
     b = gpu["binner"]
-    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), g["counts"])
-    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), g["offsets"])
-    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"])
+    assert_same(b.getTileCountsBuffer().read(np.uint32), g["counts"], "L489")
+    assert_same(b.getTileOffsetsBuffer().read(np.uint32), g["offsets"], "L490")
+    assert_same(b.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"], "L491")
     for mode, key in ((sr.MODE_FRONT_TO_BACK, "image_front_to_back"), (sr.MODE_REFERENCE_LITERAL, "image_literal")):
         r = sr.ComputeShaderRenderer(device, None, "rgba8unorm", mode=mode, earlyOut=True)
         r.render(g["uniforms"], gpu["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), gpu["nbuf"],
@@ -512,11 +519,17 @@ def test_tile_lists_equal_the_reference_own_code(device, name):
     w, h, tile = (int(x) for x in g["dims"])
     n = g["projected"].shape[0]
     pbuf, sbuf = device.createBufferFrom(g["projected"]), device.createBufferFrom(g["sorted"])
+    # (what a mismatch report needs to tell a tie-order swap — the ranking — from anything else: the depth keys, the
+    # offsets that name the tile, and which ranking / block size this process used)
+    keys = O.extract_keys(g["projected"])[0]
+    info = {"SPLAT_RANK": os.environ.get("SPLAT_RANK", "(library default)"), "n": n, "tiles": int(g["counts"].shape[0]),
+            "first_pass_block": 256 if n <= 131072 else 1024}
     b = sr.GPUTileBinner(device, tile)
     b.binSplats(None, pbuf, sbuf, n, w, h, numSorted=g["sorted"].shape[0])
-    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), g["counts"])
-    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), g["offsets"])
-    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"])
+    assert_same(b.getTileCountsBuffer().read(np.uint32), g["counts"], (name, "staged binner", "counts"), extra=info)
+    assert_same(b.getTileOffsetsBuffer().read(np.uint32), g["offsets"], (name, "staged binner", "offsets"), extra=info)
+    assert_same(b.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"], (name, "staged binner", "lists"),
+                offsets=g["offsets"], keys=keys, extra=info)
     for o in (b, pbuf, sbuf):
         o.destroy()
     if name == "edges":
@@ -526,9 +539,12 @@ def test_tile_lists_equal_the_reference_own_code(device, name):
     for order in ("tileFirst", "sortFirst"):
         r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
         r.render(f["uniforms"], props, nbuf, None, w, h)
-        assert r.finish() == g["indices"].shape[0]
-        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), g["counts"]), order
-        assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"]), order
+        total = r.finish()
+        assert total == g["indices"].shape[0], (name, order, total)
+        assert_same(r.binner.getTileCountsBuffer().read(np.uint32), g["counts"], (name, "frame", order, "counts"), extra=info)
+        assert_same(r.binner.getTileOffsetsBuffer().read(np.uint32), g["offsets"], (name, "frame", order, "offsets"), extra=info)
+        assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"], (name, "frame", order, "lists"),
+                    offsets=g["offsets"], keys=keys, extra=info)
         r.destroy()
     props.destroy()
     nbuf.destroy()
@@ -544,7 +560,7 @@ def test_scan_equals_the_reference_own_code(device):
         a = g[f"in{k}"]
         ib, ob = device.createBufferFrom(a), device.createBuffer(max(a.nbytes, 16))
         sc.scan(None, ib, ob, a.shape[0])
-        assert np.array_equal(ob.read(np.uint32, a.shape[0]), g[f"out{k}"]), k
+        assert_same(ob.read(np.uint32, a.shape[0]), g[f"out{k}"], ("L547", k))
         ib.destroy()
         ob.destroy()
         k += 1
@@ -560,9 +576,9 @@ def test_bin_other_tile_sizes(device, tile):
     ref = oracle_pipeline(props, normals, u, w, h, tile=tile)
     g = run_gpu_pipeline(device, props, normals, u, n, w, h, tile=tile)
     b = g["binner"]
-    assert np.array_equal(b.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(b.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
-    assert np.array_equal(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    assert_same(b.getTileCountsBuffer().read(np.uint32), ref["counts"], "L563")
+    assert_same(b.getTileOffsetsBuffer().read(np.uint32), ref["offsets"], "L564")
+    assert_same(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"], "L565")
     destroy_all(g)
 
 
@@ -578,7 +594,7 @@ def test_full_size_C2_properties(device):
     r.render(u, pbuf, nbuf, None, w, h)
     order = r.sorter.getSortedIndicesBuffer().read(np.uint32, n)
     keys = r.sorter.getSortedKeysBuffer().read(np.uint32, n)
-    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+    assert_same(np.sort(order), np.arange(n, dtype=np.uint32), "L581")
     dk = np.diff(keys.astype(np.int64))
     assert (dk >= 0).all()
     ties = dk == 0
@@ -589,7 +605,7 @@ def test_full_size_C2_properties(device):
     offsets = r.binner.getTileOffsetsBuffer().read(np.uint32)
     total = r.binner.getTotalIndices()
     assert int(counts.sum(dtype=np.uint64)) == total
-    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32))
+    assert_same(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32), "L592")
     idx = r.binner.getTileIndicesBuffer().read(np.uint32, total)
     rank = np.empty(n, np.uint32)
     rank[order] = np.arange(n, dtype=np.uint32)
@@ -633,11 +649,11 @@ def test_sync_free_frames_repeat_bit_exactly(device):
     for _ in range(4):
         r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
     assert not r.previousFrameOverflowed
-    assert np.array_equal(r.readPixelsFloat().view(np.uint32), first.view(np.uint32))
+    assert_same(r.readPixelsFloat().view(np.uint32), first.view(np.uint32), "L636")
     assert r.binner.getTotalIndices() == ref["indices"].shape[0]
-    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], "L638")
+    assert_same(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"], "L639")
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"], "L640")
     r.destroy()
     pbuf.destroy()
     nbuf.destroy()
@@ -663,7 +679,7 @@ def test_sync_free_overflow_is_detected_and_recovered(device):
     got = r.readPixelsFloat()                              # finish(): detects, re-renders
     assert r.previousFrameOverflowed
     assert r.binner.getTotalIndices() == ref["indices"].shape[0]
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"])
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"], "L666")
     err = np.abs(got - want)
     assert err.max() <= TOL_EARLY_OUT_BOUND and (err.max(axis=2) > TOL_NO_EARLY_OUT).mean() <= FRAC_ABOVE_TIGHT
     # and the low-level contract: the raw ABI call after an overflowed frame returns CAPACITY once
@@ -747,9 +763,9 @@ def test_tile_first_lists_and_image_match_sort_first(device, n, w, h, seed, rs):
     r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h)
     total = ref["indices"].shape[0]
     assert r.binner.getTotalIndices() == total
-    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], "L750")
+    assert_same(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"], "L751")
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "L752")
     got = r.readPixelsFloat()
     r2 = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
     r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
@@ -772,7 +788,7 @@ def test_tile_first_depth_ties_resolve_by_index(device, kind):
     r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h, want_float=False)
     total = ref["indices"].shape[0]
     assert r.binner.getTotalIndices() == total
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "L775")
     for o in (r, pbuf, nbuf):
         o.destroy()
 
@@ -804,7 +820,7 @@ def test_tile_first_wide_depth_range_inside_a_tile(device, n, rs, cls):
     r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h, want_float=False)
     total = idx.shape[0]
     assert r.binner.getTotalIndices() == total
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), idx)
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), idx, "L807")
     for o in (r, pbuf, nbuf):
         o.destroy()
 
@@ -821,12 +837,12 @@ def test_tile_first_sixteen_bit_tile_ids(device):
     r, pbuf, nbuf = _tile_first_frame(device, props, normals, u, n, w, h, want_float=False)
     total = ref["indices"].shape[0]
     assert r.binner.getTotalIndices() == total
-    assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
-    assert np.array_equal(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"])
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], "L824")
+    assert_same(r.binner.getTileOffsetsBuffer().read(np.uint32), ref["offsets"], "L825")
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "L826")
     r.render(u, pbuf, nbuf, None, w, h)  # and again, sync-free
     r.finish()
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "L829")
     for o in (r, pbuf, nbuf):
         o.destroy()
 
@@ -847,16 +863,98 @@ def test_tile_first_with_ballot_ranking(monkeypatch):
                 r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
                 total = r.finish()
                 assert total == ref["indices"].shape[0], (n, w, h)
-                assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"])
-                assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), (n, w, h, rep)
+                assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], "L850")
+                assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("L851", n, w, h, rep), offsets=ref["offsets"])
             got = r.readPixelsFloat()
             r2 = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="sortFirst")
             r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-            assert np.array_equal(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32))
+            assert_same(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32), "L855")
             for o in (r, r2, pbuf, nbuf):
                 o.destroy()
     finally:
         dev.destroy()
+
+
+def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
+    """The default ranking of the tile-first frame rests on nothing unverified (include/splat.h, NOTE on ranking): the
+    per-tile sort checks every finished list for strictly increasing (depth key, splat index) order.  Here a list is
+    deliberately left as an out-of-lane-order rank would leave it (first two entries swapped, test hook): the frame's
+    report must carry the flag, the facade must get SPLAT_ERR_RETRY and render the frame again, the context must rank
+    with ballots from then on, and the lists and the image that come back must be the oracle's.  First (host-synchronised)
+    frame, sync-free frame, both size classes and a list long enough for the global-memory passes."""
+    cases = [(3000, 128, 96, 71, 1.0, False), (20000, 640, 360, 72, 1.0, True), (30000, 48, 32, 73, 8.0, True), (6000, 16, 16, 74, 30.0, False)]
+    for n, w, h, seed, rs, sync_free in cases:
+        dev = sr.Device(0)  # (a failed check switches its context to ballots for good: one context per case)
+        try:
+            assert dev.rankStatus() == {"policy": "checked", "atomicsOrdered": True, "orderFaults": 0}
+            props, normals, u = make_case(n, w, h, seed, rs)
+            ref = oracle_pipeline(props, normals, u, w, h)
+            victim = int(np.argmax(ref["counts"]))  # the longest list (>= 2 entries)
+            assert ref["counts"][victim] >= 2
+            pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
+            r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
+            if sync_free:  # a good first frame, then the fault hits a frame whose report is only read at the next call
+                r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+                good = r.readPixelsFloat().copy()
+            dev.injectOrderFault(victim)
+            r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+            total = r.finish()  # learns of the failed check, renders the frame again (with ballots)
+            assert r.previousFrameOverflowed  # (the facade's "a frame had to be rendered again" flag)
+            st = dev.rankStatus()
+            assert st["policy"] == "ballot" and st["orderFaults"] == 1, st
+            assert total == ref["indices"].shape[0]
+            assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], ("order check", n, w, h, "counts"))
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("order check", n, w, h, "lists"),
+                        offsets=ref["offsets"], keys=ref["keys"])
+            img = r.readPixelsFloat()
+            if sync_free:
+                assert_same(img.view(np.uint32), good.view(np.uint32), ("order check", n, w, h, "image"))
+            # and it stays right, without further faults, on the ballot ranking
+            r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+            assert r.finish() == total and dev.rankStatus()["orderFaults"] == 1
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("order check", n, w, h, "lists after"),
+                        offsets=ref["offsets"], keys=ref["keys"])
+            for o in (r, pbuf, nbuf):
+                o.destroy()
+        finally:
+            dev.destroy()
+
+
+def test_ranking_policies(monkeypatch):
+    """SPLAT_RANK unset: 'checked' (atomics only on the checked frame path); =atomic: atomics wherever the probe passes —
+    the staged RadixSorter / GPUTileBinner too; =ballot: nowhere.  Every policy gives the oracle's order and lists."""
+    n, w, h = 20000, 320, 200
+    props, normals, u = make_case(n, w, h, 91, 1.0)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    for env, policy in ((None, "checked"), ("atomic", "atomic"), ("ballot", "ballot")):
+        if env is None:
+            monkeypatch.delenv("SPLAT_RANK", raising=False)
+        else:
+            monkeypatch.setenv("SPLAT_RANK", env)
+        dev = sr.Device(0)
+        try:
+            st = dev.rankStatus()
+            assert st["policy"] == policy and st["atomicsOrdered"] == (policy != "ballot"), st
+            gpu = run_gpu_pipeline(dev, props, normals, u, n, w, h)  # staged API: projector, sorter, binner
+            assert_same(gpu["sorter"].getSortedIndicesBuffer().read(np.uint32, n), ref["order"][:n], ("policy", policy, "order"))
+            b = gpu["binner"]
+            assert_same(b.getTileIndicesBuffer().read(np.uint32, ref["indices"].shape[0]), ref["indices"], ("policy", policy, "staged lists"),
+                        offsets=ref["offsets"], keys=ref["keys"])
+            destroy_all(gpu)
+            pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
+            for order in ("tileFirst", "sortFirst"):
+                r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder=order)
+                for rep in range(2):
+                    r.render(u, pbuf, nbuf, None, w, h)
+                    total = r.finish()
+                    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("policy", policy, order, rep),
+                                offsets=ref["offsets"], keys=ref["keys"])
+                r.destroy()
+            assert dev.rankStatus()["orderFaults"] == 0
+            pbuf.destroy()
+            nbuf.destroy()
+        finally:
+            dev.destroy()
 
 
 def test_tile_first_sync_free_repeat_and_overflow(device):
@@ -872,13 +970,13 @@ def test_tile_first_sync_free_repeat_and_overflow(device):
     for _ in range(3):
         r.render(u, sbuf, nbuf, None, w, h, wantFloat=True)  # sync-free
     assert not r.previousFrameOverflowed
-    assert np.array_equal(r.readPixelsFloat().view(np.uint32), first.view(np.uint32))
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref_s["indices"].shape[0]), ref_s["indices"])
+    assert_same(r.readPixelsFloat().view(np.uint32), first.view(np.uint32), "L875")
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, ref_s["indices"].shape[0]), ref_s["indices"], "L876")
     r.render(u, bbuf, nbuf, None, w, h, wantFloat=True)      # outgrows the sync-free limit
     r.readPixelsFloat()                                       # finish(): detects, renders again
     assert r.previousFrameOverflowed
     assert r.binner.getTotalIndices() == ref_b["indices"].shape[0]
-    assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, ref_b["indices"].shape[0]), ref_b["indices"])
+    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, ref_b["indices"].shape[0]), ref_b["indices"], "L881")
     for o in (r, sbuf, bbuf, nbuf):
         o.destroy()
 
@@ -913,7 +1011,7 @@ def test_full_size_frame_lists_and_pixels(device, name):
     offsets = r.binner.getTileOffsetsBuffer().read(np.uint32)
     idx = r.binner.getTileIndicesBuffer().read(np.uint32, total)
     assert int(counts.sum(dtype=np.uint64)) == total
-    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32))
+    assert_same(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32), "L916")
     # the frame's records against the oracle's projector (every splat)
     proj = O.project(u, props)
     rec = r.projector.getProjectedBuffer().read(np.float32).reshape(n, 8)
@@ -934,13 +1032,13 @@ def test_full_size_frame_lists_and_pixels(device, name):
         members = np.nonzero(on & (tx0 <= tx) & (tx <= tx1) & (ty0 <= ty) & (ty <= ty1))[0]
         members = members[np.lexsort((members, keys[members]))]
         got = idx[offsets[t]:offsets[t] + counts[t]]
-        assert np.array_equal(got, members.astype(np.uint32)), f"tile {t} ({tx},{ty}): list differs from binSorted"
+        assert_same(got, members.astype(np.uint32), ("L937", f"tile {t} ({tx},{ty}): list differs from binSorted"))
     # the sort-first order (global depth sort, then bin) gives the same lists over the whole frame
     a = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
     a.render(u, pbuf, nbuf, None, w, h)
     assert a.finish() == total
-    assert np.array_equal(a.binner.getTileIndicesBuffer().read(np.uint32, total), idx)
-    assert np.array_equal(a.readPixels(), r.readPixels())
+    assert_same(a.binner.getTileIndicesBuffer().read(np.uint32, total), idx, "L942")
+    assert_same(a.readPixels(), r.readPixels(), "L943")
     a.destroy()
     # pixel parity on two bands of 32 rows
     img, img8 = r.readPixelsFloat(), r.readPixels()
@@ -966,12 +1064,12 @@ def test_tile_first_full_size_C2(device):
     b.render(u, pbuf, nbuf, None, w, h)
     total = a.binner.getTotalIndices()
     assert total == b.binner.getTotalIndices() == 11280103
-    assert np.array_equal(a.binner.getTileOffsetsBuffer().read(np.uint32), b.binner.getTileOffsetsBuffer().read(np.uint32))
-    assert np.array_equal(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total))
-    assert np.array_equal(a.readPixels(), b.readPixels())
+    assert_same(a.binner.getTileOffsetsBuffer().read(np.uint32), b.binner.getTileOffsetsBuffer().read(np.uint32), "L969")
+    assert_same(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total), "L970")
+    assert_same(a.readPixels(), b.readPixels(), "L971")
     for _ in range(3):  # sync-free frames
         b.render(u, pbuf, nbuf, None, w, h)
-    assert np.array_equal(a.readPixels(), b.readPixels())
+    assert_same(a.readPixels(), b.readPixels(), "L974")
     for o in (a, b, pbuf, nbuf):
         o.destroy()
 
@@ -994,14 +1092,14 @@ def test_frame_with_nothing_on_screen_then_something(device, order):
     r.render(u, abuf, nbuf, None, w, h, wantFloat=True)            # first frame: empty
     assert r.binner.getTotalIndices() == 0
     assert not r.binner.getTileCountsBuffer().read(np.uint32).any()
-    assert np.array_equal(r.readPixelsFloat(), want_away)
+    assert_same(r.readPixelsFloat(), want_away, "L997")
     for buf, rr in ((pbuf, ref), (pbuf, ref), (abuf, ref_away), (pbuf, ref)):
         r.render(u, buf, nbuf, None, w, h, wantFloat=True)
         total = rr["indices"].shape[0]
         assert r.finish() == total
-        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), rr["counts"])
+        assert_same(r.binner.getTileCountsBuffer().read(np.uint32), rr["counts"], "L1002")
         if total:
-            assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), rr["indices"])
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), rr["indices"], "L1004")
     for o in (r, pbuf, abuf, nbuf):
         o.destroy()
 
@@ -1013,7 +1111,7 @@ def test_compact_exchange_records_rebuild_projected_records_bit_exactly(device):
     props, normals, u = make_case(n, w, h, 9, 1.0)
     want16 = O.project_compact(u, props)
     want32 = O.project(u, props)
-    assert np.array_equal(O.expand_compact(want16).view(np.uint32), want32.view(np.uint32))
+    assert_same(O.expand_compact(want16).view(np.uint32), want32.view(np.uint32), "L1016")
     lib, ctx = device.lib, device.ctx
     pbuf = device.createBufferFrom(props)
     first, count = 777, 15000
@@ -1022,10 +1120,10 @@ def test_compact_exchange_records_rebuild_projected_records_bit_exactly(device):
     uf = np.ascontiguousarray(u, np.float32)
     _lib.check(lib.splat_project_slice_compact(ctx, uf.ctypes.data_as(C.POINTER(C.c_float)), pbuf.ptr, 2, first, count, rec16.ptr), ctx)
     got16 = rec16.read(np.float32).reshape(count, 4)
-    assert np.array_equal(got16.view(np.uint32), want16[first:first + count].view(np.uint32))
+    assert_same(got16.view(np.uint32), want16[first:first + count].view(np.uint32), "L1025")
     _lib.check(lib.splat_expand_compact(ctx, rec16.ptr, count, first, rec32.ptr), ctx)
     got32 = rec32.read(np.float32).reshape(count, 8)
-    assert np.array_equal(got32.view(np.uint32), want32[first:first + count].view(np.uint32))
+    assert_same(got32.view(np.uint32), want32[first:first + count].view(np.uint32), "L1028")
     for o in (pbuf, rec16, rec32):
         o.destroy()
 
@@ -1055,11 +1153,11 @@ def test_band_frame_from_compact_records_matches_frame_from_projected_records(de
         binner._tiles = -(-w // 16) * -(-h // 16)
         total = ref["indices"].shape[0]
         assert binner.getTotalIndices() == total
-        assert np.array_equal(binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"])
+        assert_same(binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "L1058")
         images.append(out.read(np.float32).reshape(h, w, 4).copy())
         for o in (sorter, binner, out):
             o.destroy()
-    assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+    assert_same(images[0].view(np.uint32), images[1].view(np.uint32), "L1062")
     for o in (pbuf, nbuf, rec16, rec32):
         o.destroy()
 
@@ -1083,8 +1181,8 @@ def test_switching_frame_order_between_frames_on_one_renderer(device):
         r.render(u, pbuf, nbuf, None, w, h)
         total = ref["indices"].shape[0]
         assert r.finish() == total, (order, w, h)
-        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"]), (order, w, h)
-        assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), (order, w, h)
+        assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], ("L1086", order, w, h))
+        assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("L1087", order, w, h), offsets=ref["offsets"])
     for o in (r, pbuf, nbuf):
         o.destroy()
 
@@ -1105,14 +1203,14 @@ def test_tile_first_random_scenes(device):
         total = ref["indices"].shape[0]
         tag = (case, n, w, h, rs)
         assert r.binner.getTotalIndices() == total, tag
-        assert np.array_equal(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"]), tag
+        assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], ("L1108", tag))
         if total:
-            assert np.array_equal(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), tag
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("L1110", tag))
         if case % 3 == 0:
             got = r.readPixelsFloat()
             r2 = sr.Renderer(device, None, "rgba8unorm", n, frameOrder="sortFirst")
             r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-            assert np.array_equal(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32)), tag
+            assert_same(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32), ("L1115", tag))
             r2.destroy()
         for o in (r, pbuf, nbuf):
             o.destroy()
@@ -1131,15 +1229,15 @@ def test_property_planes_give_the_same_frame_as_interleaved_records(device):
     b = sr.Renderer(device, None, "rgba8unorm", n, records="projected")
     a.render(u, pm.getPropertyBuffer(), nbuf, None, w, h, wantFloat=True)
     planes = pm.getPropertyPlanes()
-    assert np.array_equal(planes.posRadius.read(np.float32).reshape(n, 4), props[:, :4])
-    assert np.array_equal(planes.colorOpacity.read(np.float32).reshape(n, 4), props[:, 4:])
+    assert_same(planes.posRadius.read(np.float32).reshape(n, 4), props[:, :4], "L1134")
+    assert_same(planes.colorOpacity.read(np.float32).reshape(n, 4), props[:, 4:], "L1135")
     for _ in range(3):  # also as sync-free frames
         b.render(u, planes, nbuf, None, w, h, wantFloat=True)
     total = a.finish()
     assert b.finish() == total
-    assert np.array_equal(a.projector.getProjectedBuffer().read(np.uint32), b.projector.getProjectedBuffer().read(np.uint32))
-    assert np.array_equal(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total))
-    assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    assert_same(a.projector.getProjectedBuffer().read(np.uint32), b.projector.getProjectedBuffer().read(np.uint32), "L1140")
+    assert_same(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total), "L1141")
+    assert_same(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32), "L1142")
     # K12 into planes == K12 into interleaved records
     rng = np.random.default_rng(5)
     pos = rng.standard_normal((n, 4)).astype(np.float32)
@@ -1147,11 +1245,11 @@ def test_property_planes_give_the_same_frame_as_interleaved_records(device):
     posb, curb = device.createBufferFrom(pos), device.createBufferFrom(cur)
     pm.updateFromCurvature(None, posb, curb)
     want = pm.getPropertyBuffer().read(np.float32).reshape(n, 8).copy()
-    assert np.array_equal(want, O.update_props(pos, cur))
+    assert_same(want, O.update_props(pos, cur), "L1150")
     pm.setFromArrays(props)  # scramble, then update the planes only
     planes = pm.updatePlanesFromCurvature(None, posb, curb)
-    assert np.array_equal(planes.posRadius.read(np.float32).reshape(n, 4), want[:, :4])
-    assert np.array_equal(planes.colorOpacity.read(np.float32).reshape(n, 4), want[:, 4:])
+    assert_same(planes.posRadius.read(np.float32).reshape(n, 4), want[:, :4], "L1153")
+    assert_same(planes.colorOpacity.read(np.float32).reshape(n, 4), want[:, 4:], "L1154")
     for o in (a, b, pm, nbuf, posb, curb):
         o.destroy()
 
@@ -1181,7 +1279,7 @@ def test_frame_pipeline_keeps_frames_apart(device):
             pipe.exchange(k + 1, cams[k + 1], pt.data_ptr())
         img = pipe.band(k, pt.data_ptr(), nt.data_ptr(), settle=True)
         torch.cuda.synchronize()
-        assert np.array_equal(img.cpu().numpy(), want[k]), k
+        assert_same(img.cpu().numpy(), want[k], ("L1184", k))
     pipe.destroy()
     stages.destroy()
 
@@ -1246,7 +1344,7 @@ def test_prelit_colour_plane_gives_the_same_image_bit_for_bit(device):
         b = sr.Renderer(device, None, "rgba8unorm", n, mode=mode)
         a.render(u, pm.getPropertyPlanes(), nbuf, None, w, h, wantFloat=True)
         b.render(u, pm.getLitPlanes(nbuf), None, None, w, h, wantFloat=True)  # no normals needed
-        assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+        assert_same(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32), "L1249")
         a.destroy()
         b.destroy()
     # new normals in a new buffer, then new properties: the cached plane follows
@@ -1256,13 +1354,13 @@ def test_prelit_colour_plane_gives_the_same_image_bit_for_bit(device):
     b = sr.Renderer(device, None, "rgba8unorm", n)
     a.render(u, pm.getPropertyBuffer(), nbuf2, None, w, h, wantFloat=True)
     b.render(u, pm.getLitPlanes(nbuf2), None, None, w, h, wantFloat=True)
-    assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    assert_same(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32), "L1259")
     props2 = props.copy()
     props2[:, 4:7] = props[::-1, 4:7]
     pm.setFromArrays(props2)
     a.render(u, pm.getPropertyBuffer(), nbuf2, None, w, h, wantFloat=True)
     b.render(u, pm.getLitPlanes(nbuf2), None, None, w, h, wantFloat=True)
-    assert np.array_equal(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32))
+    assert_same(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32), "L1265")
     for o in (a, b, pm, nbuf, nbuf2):
         o.destroy()
 
@@ -1286,11 +1384,11 @@ def test_abi_communicator_one_rank_self_test(device):
     out.zero()
     device.setTiming(True)
     _lib.check(lib.splat_allgather_records(ctx, comm, shard.ptr, out.ptr, rec.nbytes), ctx)
-    assert np.array_equal(out.read(np.float32).reshape(rec.shape), rec)
+    assert_same(out.read(np.float32).reshape(rec.shape), rec, "L1289")
     assert device.stageTimeMs(_lib.STAGE_EXCHANGE) >= 0.0
     device.setTiming(False)
     _lib.check(lib.splat_allgather_records(ctx, comm, shard.ptr, shard.ptr, rec.nbytes), ctx)  # in place
-    assert np.array_equal(shard.read(np.float32).reshape(rec.shape), rec)
+    assert_same(shard.read(np.float32).reshape(rec.shape), rec, "L1293")
     assert lib.splat_allgather_records(ctx, None, shard.ptr, out.ptr, rec.nbytes) == -1
     lib.splat_comm_destroy(comm)
     shard.destroy()
@@ -1347,7 +1445,7 @@ def test_frame_loop_dolly_in_and_out_sync_free(device):
             loop.renderer.previousFrameOverflowed = False
             ref = oracle_pipeline(props, normals, u, w, h)
             assert total == ref["indices"].shape[0], k
-            assert np.array_equal(loop.renderer.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"]), k
+            assert_same(loop.renderer.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("L1350", k))
             totals.append(total)
             if k == 27:
                 _, want8, _, _, near = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"],
@@ -1384,14 +1482,15 @@ def test_headless_frame_loop_orbits_the_camera(device, tmp_path):
     assert len({s[1].tobytes() for s in shots}) == len(shots)  # the camera really moved
     for k, (u, got8, total, idx) in enumerate(shots):
         ref = oracle_pipeline(props, normals, u, w, h)
-        assert total == ref["indices"].shape[0] and np.array_equal(idx, ref["indices"]), k
+        assert total == ref["indices"].shape[0], k
+        assert_same(idx, ref["indices"], ("L1387", k), offsets=ref["offsets"])
         _, want8, _, _, near = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
                                            ref["offsets"], w, h, want_stops=True)
         d8 = np.abs(got8.astype(int) - want8.astype(int)).max(axis=2)
         assert d8[near == 0].max() <= 1 and d8.max() <= 3, k
         path = tmp_path / f"frame_{k}.png"
         sr.write_png(path, got8)
-        assert np.array_equal(sr.read_png(path), got8)
+        assert_same(sr.read_png(path), got8, "L1394")
     # the same frames without reading anything back in between (all sync-free): same last image
     cam2 = sr.Camera()
     loop2 = sr.FrameLoop(device, n, w, h, camera=cam2)
@@ -1400,7 +1499,7 @@ def test_headless_frame_loop_orbits_the_camera(device, tmp_path):
         loop2.render(pbuf, nbuf)
         if k < 3:
             [lambda: cam2.rotate(2 * np.pi / 4, 0.0), lambda: cam2.pan(0.2, -0.1), lambda: ctl2.onWheel(sr.MouseEvent(deltaY=400.0))][k]()
-    assert np.array_equal(loop2.readPixels(), shots[3][1])
+    assert_same(loop2.readPixels(), shots[3][1], "L1403")
     for o in (loop, loop2, pbuf, nbuf):
         o.destroy()
 
@@ -1430,7 +1529,7 @@ def test_pipelined_renderer_keeps_frames_identical(device):
             got.append((k, pr.readPixels().copy()))
     pr.finish()
     for k, img in got:
-        assert np.array_equal(img, want[k]), k
+        assert_same(img, want[k], ("L1433", k))
     assert len({w_.tobytes() for w_ in want}) == len(want)
     for o in (pr, one, pbuf, nbuf):
         o.destroy()
