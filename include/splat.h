@@ -170,6 +170,9 @@ int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_
  * before its order check, as an out-of-lane-order ranking would have left them: the check must raise the frame's flag,
  * the next call return SPLAT_ERR_RETRY, and the frame rendered again be right.  One shot. */
 int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile);
+/* EXPERIMENT HOOK: the order in which the lane-efficient composite's workgroups take the tiles of the rendered band
+ * (a permutation of 0 .. tiles - 1 as u32 on the device; NULL = row-major).  Any order gives the same image. */
+int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
 /* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
  * (the result is then invalid).  Synchronises. */
 int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag);

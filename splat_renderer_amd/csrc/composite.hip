@@ -54,6 +54,8 @@ struct CompositeParams {
     const uint32_t *frame_total;
     uint32_t *report;
     uint32_t report_seq;
+    const uint32_t *tile_order; // k_composite_px: workgroup b works on tile tile_order[b] of the band (NULL: b)
+    uint32_t *tile_cost;        // k_composite_px: chunks each tile's consumer walked (orders the next launch; NULL: not kept)
 };
 
 __device__ __forceinline__ uint32_t unorm8(float v) {
@@ -421,168 +423,329 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
 // Trips per consumed entry at C2: 0.30 (a wave instruction of up to 256 pixel-entries each) against 1.14 visits of a
 // 64-pixel wave.  Reference semantics: /root/reference/src/ComputeShaderRenderer.ts:150-198.
 // =====================================================================================================================
-constexpr int PXC = 32;     // entries per chunk = bits of a lane's queue
-constexpr int PX_ROW = 36;  // float2 slots per table row: 32 entries + 4 — rows 4 slots apart (mod 32) so that the eight
-                            // rows of one entry fall into eight different bank pairs of a ds_read_b64
-struct PxShared {
-    float2 tx[8][PX_ROW]; // tx[c][j] = {gx_j(2c), gx_j(2c+1)}: entry j's factor at the tile's pixel columns 2c, 2c+1
-    float2 ty[8][PX_ROW]; // ty[r][j] = {gy_j(2r), gy_j(2r+1)}
-    float4 col[PXC];      // lit colour of entry j
+// One list entry as fetched, untouched (k_composite_px keeps a chunk of these in flight: nothing may be computed from
+// them at issue).  LIT32: a = {centre.xy, radius, depth}, c = lit colour.  Otherwise a = bounds (or the compact record),
+// c = colour, n = normal, r = radius.
+struct PxRaw {
+    float4 a, c, n;
+    float r;
 };
-static_assert(sizeof(PxShared) == 5120, "four waves x 5 KB: eight workgroups fill a CU's 160 KB");
+template <bool LIT32>
+__device__ __forceinline__ void px_fetch(const CompositeParams &p, uint32_t idx, PxRaw &o) {
+    if constexpr (LIT32) {
+        o.a = p.projected[(size_t)idx * 2];
+        o.c = p.projected[(size_t)idx * 2 + 1];
+    } else {
+        if (p.compact) {
+            o.a = p.projected[idx];
+        } else {
+            o.a = p.projected[(size_t)idx * 2];
+            o.r = reinterpret_cast<const float *>(p.projected)[(size_t)idx * 8 + 5];
+        }
+        o.c = p.color[(size_t)idx * p.color_stride];
+        if (!p.prelit) o.n = p.normals[(size_t)idx * p.normal_stride];
+    }
+}
+// bounds, screen radius and lit colour of a fetched entry (fetch_entry's arithmetic, at the time of use)
+template <bool LIT32>
+__device__ __forceinline__ void px_unpack(const CompositeParams &p, const PxRaw &o, float4 &bounds, float &radius, float4 &lit) {
+    if constexpr (LIT32) {
+        bounds = lit_bounds(o.a);
+        radius = o.a.z;
+        lit = o.c;
+    } else {
+        if (p.compact) {
+            bounds = lit_bounds(o.a); // the bounds must be the projector's: one rounding per operation
+            radius = o.a.z;
+        } else {
+            bounds = o.a;
+            radius = o.r;
+        }
+        lit = p.prelit ? o.c : lit_color(o.c, o.n);
+    }
+}
 
-template <bool EARLY_OUT, bool LIT32>
-__global__ __launch_bounds__(256) void k_composite_px(CompositeParams p, uint32_t band_tiles) {
-    __shared__ PxShared s_all[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t t_local = blockIdx.x * 4u + w;
+constexpr int PXC = 32;     // entries per chunk = bits of a lane's queue
+constexpr int PX_ROW = 35;  // float2 slots per table row: the idle slot, 32 entries, 2 of padding — rows 3 slots apart (mod 32),
+                            // so the eight rows a wave reads for ONE entry fall into eight different bank pairs of a ds_read_b64
+// One chunk as the builder wave leaves it for the consumer wave.  Slot 0 of every row and colour 0 are the IDLE entry
+// (zeros): what a lane with an empty queue "takes" — entry j lives at index 1 + j, so ffbl's -1 for an empty queue
+// addresses the idle slot without a select.
+struct PxBuf {
+    float2 t[16][PX_ROW];  // t[c][1 + j] = {gx_j(2c), gx_j(2c+1)}: entry j's factor at the tile's pixel columns 2c, 2c+1 (c < 8);
+                           // t[8 + r][1 + j] = {gy_j(2r), gy_j(2r+1)} at its pixel rows
+    float4 col[PXC + 1];   // col[1 + j] = {lit r, g, b, 1}
+    uint2 q[8];            // q[c].x: bit j = entry j's box meets pixel columns 2c, 2c+1; q[r].y: ... pixel rows 2r, 2r+1
+};
+static_assert(sizeof(PxBuf) * 2 * 15 <= 160 * 1024, "fifteen tiles (thirty waves) per CU");
+
+#ifndef PX_WAVES
+#define PX_WAVES 8 // (every instantiation fits 61 registers without scratch; tuning knob of tools/build_variant.sh: minimum waves per SIMD the register allocation must leave room for)
+#endif
+// One workgroup of TWO waves per tile.  Wave 1, the BUILDER, gathers the list's entries (two chunks ahead of their use),
+// and per chunk of 32 builds the tables, the colours and the queue words into one of two LDS buffers; wave 0, the
+// CONSUMER, owns the tile's 256 pixels (2x2 per lane) and walks the other buffer.  One s_barrier per chunk hands a buffer
+// over in each direction.  (One wave doing both — the first version — spent as long staging a chunk, ~230 vector
+// instructions, as walking it, one instruction stream after the other: the kernel is bound by each tile's own latency, not
+// by the device's throughput, and a second instruction stream halves it.)
+// The kernel's duration is its LONGEST tile's (every tile is resident from the start: C2 has 4969 tiles with entries, two
+// waves each, on 8192 wave slots), and while the SIMDs are full every wave advances at an eighth of the speed it has
+// alone.  A tile that is still going after a few chunks is one of the long ones: its waves raise their issue priority
+// with their progress, so the tail runs at full speed from early on instead of from the moment the others have left.
+#ifndef PX_PRIO
+#define PX_PRIO 1
+#endif
+#if PX_PRIO
+#define PX_PRIORITY(N)                                         \
+    do {                                                       \
+        if ((N) == 3u) __builtin_amdgcn_s_setprio(1);          \
+        else if ((N) == 6u) __builtin_amdgcn_s_setprio(2);     \
+        else if ((N) == 10u) __builtin_amdgcn_s_setprio(3);    \
+    } while (0)
+#else
+#define PX_PRIORITY(N) do { } while (0)
+#endif
+template <bool EARLY_OUT, bool LIT32, bool COUNT>
+__global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams p, uint32_t band_tiles) {
+    __shared__ PxBuf s_buf[2];
+    __shared__ uint32_t s_done;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // 0 = consumer, 1 = builder (wave-uniform)
+    const uint32_t t_local = p.tile_order ? p.tile_order[blockIdx.x] : blockIdx.x;
     if (p.report && blockIdx.x == 0 && tid == 0) tile_report(p.frame_total, p.report, p.report_seq);
-    if (t_local >= band_tiles) return; // (whole waves: nothing in this kernel waits for another wave)
-    PxShared &sh = s_all[w];
     const uint32_t tx = t_local % p.ntx, ty = t_local / p.ntx + p.tile_row0;
     const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
     const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
+    const uint32_t nchunks = (count + PXC - 1) / PXC;
+    const float tile_x0 = (float)(tx * CT), tile_y0 = (float)(ty * CT);
+
+    if (role == 1) {
+        // ================================================= builder =================================================
+        if (count == 0) return; // (the consumer writes the background; no barrier is executed by either wave)
+        const float tile_cx = tile_x0 + 0.5f, tile_cy = tile_y0 + 0.5f; // :169 pixel centres
+        const uint32_t e = lane & 31, h = lane >> 5; // lane (e, h) computes entry e's x (h = 0) or y (h = 1) table
+        if (lane < 32) s_buf[lane >> 4].t[lane & 15][0] = make_float2(0.0f, 0.0f); // the idle slots of both buffers
+        if (lane >= 32 && lane < 34) s_buf[lane - 32].col[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // Entries are fetched two chunks ahead of their use and their indices three (the gather depends on the index).
+        // Every load of this pipeline is UNCONDITIONAL — positions past the list's end re-read its last entry and are
+        // ignored — and nothing is computed from a loaded value before its chunk comes up: a load under a branch, or a use
+        // at issue, would make the compiler wait for everything in flight (s_waitcnt vmcnt(0)) where it can otherwise count.
+        PxRaw ra = {}, rb = {}, rc = {};
+        const uint32_t last = count - 1u;
+        uint32_t idx_c = p.indices[off + min(2 * PXC + e, last)];
+        px_fetch<LIT32>(p, p.indices[off + min(e, last)], ra);
+        px_fetch<LIT32>(p, p.indices[off + min(PXC + e, last)], rb);
+        uint32_t staged = 0;
+#ifdef PX_PROFILE
+        const unsigned long long pb0 = __builtin_amdgcn_s_memtime();
+        unsigned long long pb_wait = 0, pb_fetch = 0, pb_chunks = 0;
+#endif
+        for (uint32_t m = 0;; ++m) { // builds chunk m (chunk 0 before the first barrier, chunk n + 1 while the consumer walks n)
+            const uint32_t cb0 = m * PXC;
+            PX_PRIORITY(m);
+            if (m < nchunks) {
+                staged = min(cb0 + 3 * PXC, count); // entries gathered so far: this chunk and the two fetched ahead
+                px_fetch<LIT32>(p, idx_c, rc);
+                idx_c = p.indices[off + min(cb0 + 3 * PXC + e, last)];
+                PxBuf &B = s_buf[m & 1];
+                float k = 0.0f, ck = 0.0f;
+                uint32_t m16 = 0; // this axis's mask of covered pixel columns / rows (zero unless the entry draws something in this tile)
+                float4 b, colr;
+                float rad;
+#ifdef PX_PROFILE
+                const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
+#endif
+                px_unpack<LIT32>(p, ra, b, rad, colr);
+#ifdef PX_PROFILE
+                if (__ballot(rad > 1e30f || colr.x > 1e30f) == 0) { pb_fetch += __builtin_amdgcn_s_memtime() - pf0; pb_chunks++; } // (forces the loads' arrival)
+#endif
+                if (cb0 + e < count && !(rad < 0.5f)) { // :127-129 "too small"
+                    const uint32_t xm = span_mask16(b.x, b.z, tile_cx), ym = span_mask16(b.y, b.w, tile_cy);
+                    if (xm != 0 && ym != 0) {
+                        // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r
+                        // (:133-140), in tile-local coordinates (as k_composite)
+                        // (v_rcp_f32, 1 ulp: the correctly rounded quotient costs ten instructions on this wave's path)
+                        k = 1.6986436005760381f * __builtin_amdgcn_rcpf(rad);
+                        const float lx = (b.x + b.z) * 0.5f - tile_x0, ly = (b.y + b.w) * 0.5f - tile_y0; // :124, then exact
+                        ck = (h ? ly : lx) * k;
+                        m16 = h ? ym : xm;
+                    }
+                }
+                if (h == 0) B.col[1 + e] = make_float4(colr.x, colr.y, colr.z, 1.0f); // (.w = 1: the factor of T's update, see PX_BLEND)
+#pragma unroll
+                for (int c2 = 0; c2 < 8; ++c2) {
+                    const v2f pc = {(float)(2 * c2) + 0.5f, (float)(2 * c2) + 1.5f};
+                    const v2f t = pc * (v2f){k, k} - (v2f){ck, ck};
+                    const v2f q = t * t;
+                    // (the box test — ComputeShaderRenderer.ts:118-121, exact: span_mask16 — as a bit mask on the value:
+                    // v_bfe_i32 spreads the coverage bit over the word)
+                    const uint32_t g0 = __float_as_uint(__builtin_amdgcn_exp2f(-q.x)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2, 1);
+                    const uint32_t g1 = __float_as_uint(__builtin_amdgcn_exp2f(-q.y)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2 + 1, 1);
+                    B.t[h * 8 + c2][1 + e] = make_float2(__uint_as_float(g0), __uint_as_float(g1));
+                }
+                // queue words: one ballot gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 the y mask)
+                const uint32_t mm = m16 | (m16 >> 1);
+                unsigned long long bal[8];
+#pragma unroll
+                for (int c2 = 0; c2 < 8; ++c2) bal[c2] = __ballot((mm >> (2 * c2)) & 1u);
+                if (lane == 0) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 8; ++c2) B.q[c2] = make_uint2((uint32_t)bal[c2], (uint32_t)(bal[c2] >> 32));
+                }
+                ra = rb;
+                rb = rc;
+            }
+#ifdef PX_PROFILE
+            const unsigned long long pbw = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads(); // chunk m is the consumer's; the buffer of chunk m - 1 is free again
+#ifdef PX_PROFILE
+            pb_wait += __builtin_amdgcn_s_memtime() - pbw;
+#endif
+            if (m >= nchunks || (EARLY_OUT && s_done)) break;
+        }
+#ifdef PX_PROFILE
+        if (p.consumed && lane == 0)
+            p.consumed[(size_t)tile_idx * 2] = (((__builtin_amdgcn_s_memtime() - pb0) >> 4) & 0xffffull) | (((pb_wait >> 4) & 0xffffull) << 16) |
+                                               (((pb_fetch >> 4) & 0xffffull) << 32) | ((pb_chunks & 0xffffull) << 48);
+        return;
+#endif
+        if (COUNT && p.consumed && lane == 0) p.consumed[(size_t)tile_idx * 2] += (unsigned long long)staged;
+        return;
+    }
+
+    // ================================================= consumer ====================================================
     const uint32_t bx = lane & 7, by = lane >> 3; // this lane's 2x2 block: pixel columns 2bx, 2bx+1, rows 2by, 2by+1 of the tile
     const uint32_t px0 = tx * CT + 2 * bx, py0 = ty * CT + 2 * by;
     const bool okx0 = px0 < p.width, okx1 = px0 + 1 < p.width, oky0 = py0 < p.height, oky1 = py0 + 1 < p.height;
-    const float tile_x0 = (float)(tx * CT), tile_y0 = (float)(ty * CT);
-    const float tile_cx = tile_x0 + 0.5f, tile_cy = tile_y0 + 0.5f; // :169 pixel centres
-
-    // pixel (row k, column i) of the block: component i of the k-th pair.  T = transmittance while the pixel accumulates,
-    // 0 once it has stopped (its background term is then already in C) and for pixels outside the image
+    // pixel (row k, column i) of the block: component i of the k-th pair.  T = transmittance; a pixel accumulates while
+    // T > T_STOP (:187-190, see T_STOP); pixels outside the image start at 0 and never do
     v2f cr[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, cg[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, cb[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
     v2f T[2] = {{(okx0 && oky0) ? 1.0f : 0.0f, (okx1 && oky0) ? 1.0f : 0.0f}, {(okx0 && oky1) ? 1.0f : 0.0f, (okx1 && oky1) ? 1.0f : 0.0f}};
-    // wave-uniform masks of the lanes whose pixel (k, i) still accumulates
-    unsigned long long al00 = uniform64(__ballot(okx0 && oky0)), al01 = uniform64(__ballot(okx1 && oky0));
-    unsigned long long al10 = uniform64(__ballot(okx0 && oky1)), al11 = uniform64(__ballot(okx1 && oky1));
-    uint32_t stop_pos = 0; // the largest list position (+1) at which one of this lane's pixels stopped
-    uint32_t staged = 0;
-
-    const uint32_t e = lane & 31, h = lane >> 5; // table building: lane (e, h) computes entry e's x (h = 0) or y (h = 1) table
+    uint32_t stop_pos = 0; // COUNT: list position after the last entry this lane took while one of its pixels still accumulated
+    uint32_t walked = 0;   // chunks this tile needed
     constexpr uint32_t NONE = 0xffffffffu;
-    // entries are fetched a chunk ahead of their use and their indices two chunks ahead (the gather depends on the index)
-    uint32_t idx_cur = e < count ? p.indices[off + e] : NONE;
-    uint32_t idx_nxt = PXC + e < count ? p.indices[off + PXC + e] : NONE;
-    float4 c_b = make_float4(0, 0, 0, 0), c_b2 = c_b, c_c = c_b, c_n = c_b;
-    float c_r = 0.0f;
-    if (idx_cur != NONE) fetch_entry<SPLAT_COMPOSITE_FRONT_TO_BACK, EARLY_OUT, false, LIT32>(p, idx_cur, c_b, c_b2, c_c, c_n, c_r);
-
-    for (uint32_t cb0 = 0; cb0 < count; cb0 += PXC) {
-        if (EARLY_OUT && (al00 | al01 | al10 | al11) == 0) break; // every pixel of the tile has stopped
-        staged = min(cb0 + 2 * PXC, count); // entries gathered so far: this chunk and the one fetched ahead
-        // ---- next chunk's gathers and the index load behind them go out before this chunk is touched
-        float4 n_b = make_float4(0, 0, 0, 0), n_b2 = n_b, n_c = n_b, n_n = n_b;
-        float n_r = 0.0f;
-        if (idx_nxt != NONE) fetch_entry<SPLAT_COMPOSITE_FRONT_TO_BACK, EARLY_OUT, false, LIT32>(p, idx_nxt, n_b, n_b2, n_c, n_n, n_r);
-        const uint32_t idx_nn = cb0 + 2 * PXC + e < count ? p.indices[off + cb0 + 2 * PXC + e] : NONE;
-
-        // ---- stage: both halves of the wave hold entry e; half h builds the table of its axis
-        float k = 0.0f, ck = 0.0f;
-        uint32_t m16 = 0; // this axis's mask of covered pixel columns / rows (zero unless the entry draws something in this tile)
-        if (idx_cur != NONE && !(c_r < 0.5f)) { // :127-129 "too small"
-            const float4 b = c_b;
-            const uint32_t xm = span_mask16(b.x, b.z, tile_cx), ym = span_mask16(b.y, b.w, tile_cy);
-            if (xm != 0 && ym != 0) {
-                // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r (:133-140),
-                // in tile-local coordinates (as k_composite)
-                k = 1.6986436005760381f / c_r;
-                const float lx = (b.x + b.z) * 0.5f - tile_x0, ly = (b.y + b.w) * 0.5f - tile_y0; // :124, then exact
-                ck = (h ? ly : lx) * k;
-                m16 = h ? ym : xm;
+#ifdef PX_PROFILE
+    const unsigned long long pc0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pc_wait = 0, pc_trips = 0, pc_ntrips = 0;
+#endif
+    if (count) {
+        if (lane == 0) s_done = 0;
+#ifdef PX_PROFILE
+        { const unsigned long long w0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); pc_wait += __builtin_amdgcn_s_memtime() - w0_; }
+#else
+        __syncthreads(); // chunk 0 is built
+#endif
+        for (uint32_t n = 0; n < nchunks; ++n) {
+            const PxBuf &B = s_buf[n & 1];
+            const uint32_t cb0 = n * PXC;
+            walked = n + 1;
+            PX_PRIORITY(n);
+            // a lane whose four pixels have all stopped takes no more entries
+            const bool lane_live = !EARLY_OUT || fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y)) > T_STOP;
+            uint32_t mine = lane_live ? (B.q[bx].x & B.q[by].y) : 0u;
+            // ---- trips.  Every lane takes its next entry (the idle one when its queue is empty: no divergence, an idle
+            // lane adds exact zeros); the NEXT entry's table and colour reads are issued before the current one is blended,
+            // so a trip costs its arithmetic, not an LDS round trip.
+#define PX_POP(J, R)                                                                        \
+    do {                                                                                    \
+        R = __ballot(mine != 0); /* lanes that take an entry */                              \
+        J = (uint32_t)(int)__builtin_ctz(mine) | (mine ? 0u : NONE); /* v_ffbl_b32: -1 for 0 */ \
+        mine &= mine - 1u;                                                                  \
+    } while (0)
+#define PX_LOAD(J, GX, GY, C)        \
+    do {                             \
+        GX = (&B.t[bx][1])[(int)J];      \
+        GY = (&B.t[8 + by][1])[(int)J];  \
+        C = (&B.col[1])[(int)J];         \
+    } while (0)
+#define PX_BLEND(J, R, GX, GY, C)                                                                                             \
+    do {                                                                                                                      \
+        const v2f gxx = {GX.x, GX.y};                                                                                         \
+        v2f w0 = T[0] * (gxx * (v2f){GY.x, GY.x}), w1 = T[1] * (gxx * (v2f){GY.y, GY.y}); /* rows 2by, 2by+1: w = T g */       \
+        if (EARLY_OUT) { /* :187-190 per pixel: a pixel that has reached alpha >= 0.99 takes nothing more */                   \
+            const unsigned long long a00 = __ballot(T[0].x > T_STOP), a01 = __ballot(T[0].y > T_STOP);                        \
+            const unsigned long long a10 = __ballot(T[1].x > T_STOP), a11 = __ballot(T[1].y > T_STOP);                        \
+            w0.x = __builtin_amdgcn_inverse_ballot_w64(a00) ? w0.x : 0.0f; w0.y = __builtin_amdgcn_inverse_ballot_w64(a01) ? w0.y : 0.0f; \
+            w1.x = __builtin_amdgcn_inverse_ballot_w64(a10) ? w1.x : 0.0f; w1.y = __builtin_amdgcn_inverse_ballot_w64(a11) ? w1.y : 0.0f; \
+            /* COUNT: the last entry a lane takes while one of its pixels still accumulates is the one that stops its last   \
+               pixel (if they all stop) */                                                                                    \
+            if (COUNT) jlast = __builtin_amdgcn_inverse_ballot_w64((a00 | a01 | a10 | a11) & R) ? J : jlast;                  \
+        }                                                                                                                     \
+        cr[0] += (v2f){C.x, C.x} * w0; cr[1] += (v2f){C.x, C.x} * w1; /* SURVEY §8a contract 3: nearest on top */             \
+        cg[0] += (v2f){C.y, C.y} * w0; cg[1] += (v2f){C.y, C.y} * w1;                                                         \
+        cb[0] += (v2f){C.z, C.z} * w0; cb[1] += (v2f){C.z, C.z} * w1;                                                         \
+        /* T (1 - g) with the product in hand; C.w is 1.0 for an entry (the same bits as T - w), 0 for the idle one — its    \
+           use keeps the colour read one 16-byte ds_read_b128 (4 LDS cycles; shrunk to a ds_read_b96 it costs 8) */           \
+        T[0] -= (v2f){C.w, C.w} * w0; T[1] -= (v2f){C.w, C.w} * w1;                                                           \
+    } while (0)
+#ifdef PX_PROFILE
+            const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
+            uint32_t ja, jb, jlast = NONE;
+            unsigned long long ra_, rb_;
+            float2 gxa, gya, gxb, gyb;
+            float4 ca, cb4;
+            PX_POP(ja, ra_);
+            PX_LOAD(ja, gxa, gya, ca);
+            for (;;) {
+                if (ra_ == 0) break;
+#ifdef PX_PROFILE
+                pc_ntrips++;
+#endif
+                PX_POP(jb, rb_);
+                PX_LOAD(jb, gxb, gyb, cb4);
+                __builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads to their use, one trip later: the point is lost)
+                PX_BLEND(ja, ra_, gxa, gya, ca);
+                if (rb_ == 0) break;
+#ifdef PX_PROFILE
+                pc_ntrips++;
+#endif
+                PX_POP(ja, ra_);
+                PX_LOAD(ja, gxa, gya, ca);
+                __builtin_amdgcn_sched_barrier(0);
+                PX_BLEND(jb, rb_, gxb, gyb, cb4);
             }
-        }
-        if (h == 0) {
-            const float4 c = (LIT32 || p.prelit) ? c_c : lit_color(c_c, c_n);
-            sh.col[e] = make_float4(c.x, c.y, c.z, 1.0f); // (.w = 1: read back as the factor of T's update, which makes the read one ds_read_b128)
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < 8; ++c2) {
-            const v2f pc = {(float)(2 * c2) + 0.5f, (float)(2 * c2) + 1.5f};
-            const v2f t = pc * (v2f){k, k} - (v2f){ck, ck};
-            const v2f q = t * t;
-            // (the box test as a bit mask on the value: v_bfe_i32 spreads the coverage bit over the word)
-            const uint32_t g0 = __float_as_uint(__builtin_amdgcn_exp2f(-q.x)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2, 1);
-            const uint32_t g1 = __float_as_uint(__builtin_amdgcn_exp2f(-q.y)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2 + 1, 1);
-            (h ? sh.ty : sh.tx)[c2][e] = make_float2(__uint_as_float(g0), __uint_as_float(g1));
-        }
-        // ---- queues: bit j of X[c] = entry j's box meets pixel columns 2c, 2c+1; of Y[r] likewise for rows.  One ballot
-        // gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 test the y mask) together.
-        const uint32_t mm = m16 | (m16 >> 1);
-        uint32_t qx = 0, qy = 0;
-#pragma unroll
-        for (int c2 = 0; c2 < 8; ++c2) {
-            const unsigned long long bal = __ballot((mm >> (2 * c2)) & 1u);
-            qx = __builtin_amdgcn_inverse_ballot_w64(0x0101010101010101ull << c2) ? (uint32_t)bal : qx;          // lanes with bx == c2
-            qy = __builtin_amdgcn_inverse_ballot_w64(0xffull << (8 * c2)) ? (uint32_t)(bal >> 32) : qy;           // lanes with by == c2
-        }
-        uint32_t mine = qx & qy;
-        if (EARLY_OUT && !__builtin_amdgcn_inverse_ballot_w64(al00 | al01 | al10 | al11)) mine = 0; // this lane's block has stopped
-        // the wave's own LDS stores are read back by other lanes: DS operations of one wave execute in order; the compiler
-        // must not move the reads up
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- trips
-        for (;;) {
-            const bool act = mine != 0;
-            if (!__builtin_amdgcn_readfirstlane((int)(__ballot(act) != 0))) break;
-            uint32_t j = 0;
-            if (act) {
-                j = (uint32_t)__builtin_ctz(mine);
-                mine &= mine - 1;
-                const float2 gx = sh.tx[bx][j], gy = sh.ty[by][j];
-                const float4 c = sh.col[j];
-                const v2f gxx = {gx.x, gx.y};
-                const v2f g0 = gxx * (v2f){gy.x, gy.x}, g1 = gxx * (v2f){gy.y, gy.y}; // rows 2by, 2by+1
-                const v2f w0 = T[0] * g0, w1 = T[1] * g1;                                // SURVEY §8a contract 3: nearest on top
-                cr[0] += (v2f){c.x, c.x} * w0; cr[1] += (v2f){c.x, c.x} * w1;
-                cg[0] += (v2f){c.y, c.y} * w0; cg[1] += (v2f){c.y, c.y} * w1;
-                cb[0] += (v2f){c.z, c.z} * w0; cb[1] += (v2f){c.z, c.z} * w1;
-                // T (1 - g) with the product in hand; c.w is 1.0 (exact: the same bits as T - w) — its use keeps the colour
-                // read a single 16-byte ds_read_b128 (4 LDS cycles; the compiler would shrink it to a ds_read_b96: 8)
-                T[0] -= (v2f){c.w, c.w} * w0; T[1] -= (v2f){c.w, c.w} * w1;
-            }
+#undef PX_POP
+#undef PX_LOAD
+#undef PX_BLEND
+#ifdef PX_PROFILE
+            if (__ballot(T[0].x > 1e30f) == 0) pc_trips += __builtin_amdgcn_s_memtime() - pt0;
+#endif
+            if (COUNT && EARLY_OUT && jlast != NONE) stop_pos = cb0 + jlast + 1; // (chunks come in order: later ones overwrite)
             if (EARLY_OUT) {
-                // pixels that have just reached alpha >= 0.99 (:187-190): T <= T_STOP on a pixel that was accumulating (a stopped
-                // pixel carries T = 0 and is masked by its `al` bit)
-                // (an accumulating pixel has T > T_STOP until the trip that stops it, so no test of `act` is needed)
-                const unsigned long long f00 = uniform64(__ballot(T[0].x <= T_STOP) & al00);
-                const unsigned long long f01 = uniform64(__ballot(T[0].y <= T_STOP) & al01);
-                const unsigned long long f10 = uniform64(__ballot(T[1].x <= T_STOP) & al10);
-                const unsigned long long f11 = uniform64(__ballot(T[1].y <= T_STOP) & al11);
-                if ((f00 | f01 | f10 | f11) != 0) {
-                    // the background term of :193-195 now, T = 0 from here on
-                    if (__builtin_amdgcn_inverse_ballot_w64(f00)) { cr[0].x += 0.05f * T[0].x; cg[0].x += 0.05f * T[0].x; cb[0].x += 0.1f * T[0].x; T[0].x = 0.0f; }
-                    if (__builtin_amdgcn_inverse_ballot_w64(f01)) { cr[0].y += 0.05f * T[0].y; cg[0].y += 0.05f * T[0].y; cb[0].y += 0.1f * T[0].y; T[0].y = 0.0f; }
-                    if (__builtin_amdgcn_inverse_ballot_w64(f10)) { cr[1].x += 0.05f * T[1].x; cg[1].x += 0.05f * T[1].x; cb[1].x += 0.1f * T[1].x; T[1].x = 0.0f; }
-                    if (__builtin_amdgcn_inverse_ballot_w64(f11)) { cr[1].y += 0.05f * T[1].y; cg[1].y += 0.05f * T[1].y; cb[1].y += 0.1f * T[1].y; T[1].y = 0.0f; }
-                    if (__builtin_amdgcn_inverse_ballot_w64(f00 | f01 | f10 | f11)) stop_pos = max(stop_pos, cb0 + j + 1);
-                    al00 &= ~f00; al01 &= ~f01; al10 &= ~f10; al11 &= ~f11;
-                    if (!__builtin_amdgcn_inverse_ballot_w64(al00 | al01 | al10 | al11)) mine = 0;
-                }
+                // the tile is finished when every pixel has stopped: both waves leave after the next barrier
+                const bool live = fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y)) > T_STOP;
+                if (__ballot(live) == 0 && lane == 0) s_done = 1;
             }
+#ifdef PX_PROFILE
+            const unsigned long long pcw = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads(); // chunk n + 1 is built; chunk n's buffer is the builder's again
+#ifdef PX_PROFILE
+            pc_wait += __builtin_amdgcn_s_memtime() - pcw;
+#endif
+            if (EARLY_OUT && s_done) break;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the next chunk's table stores stay behind this chunk's reads
-        __builtin_amdgcn_wave_barrier();
-        idx_cur = idx_nxt; idx_nxt = idx_nn;
-        c_b = n_b; c_b2 = n_b2; c_c = n_c; c_n = n_n; c_r = n_r;
     }
 
-    if (p.consumed) { // (uniform branch; timed / diagnostic runs only)
-        // entries this tile needed: the position at which its last pixel stopped, or the whole list if one never did
-        // (SURVEY §8d's P_used per tile = count with early-out off)
+    if (p.tile_cost && lane == 0) p.tile_cost[t_local] = walked; // (what the next launch over this band is ordered by)
+#ifdef PX_PROFILE
+    if (p.consumed && lane == 0)
+        p.consumed[(size_t)tile_idx * 2 + 1] = (((__builtin_amdgcn_s_memtime() - pc0) >> 4) & 0xffffull) | (((pc_wait >> 4) & 0xffffull) << 16) |
+                                               (((pc_trips >> 4) & 0xffffull) << 32) | ((pc_ntrips & 0xffffull) << 48);
+#else
+    if (COUNT && p.consumed && count) { // (uniform branch; timed / diagnostic runs only)
         uint32_t used = stop_pos;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) used = max(used, (uint32_t)__shfl_xor((int)used, d));
-        if (!EARLY_OUT || (al00 | al01 | al10 | al11) != 0) used = count;
-        if (lane == 0 && staged) {
-            p.consumed[(size_t)tile_idx * 2] += (unsigned long long)staged;
-            p.consumed[(size_t)tile_idx * 2 + 1] += (unsigned long long)used;
-        }
+        const bool px_live = fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y)) > T_STOP;
+        if (!EARLY_OUT || __ballot(px_live) != 0) used = count;
+        if (lane == 0) p.consumed[(size_t)tile_idx * 2 + 1] += (unsigned long long)used;
     }
+#endif
 
-    // :193-197 (a stopped pixel has T = 0 here: its background term went in when it stopped)
+    // :193-197
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t py = py0 + r;
@@ -604,6 +767,68 @@ __global__ __launch_bounds__(256) void k_composite_px(CompositeParams p, uint32_
             if (okx1) p.out_rgba32f[o + 1] = make_float4(r1, g1, b1, 1.0f);
         }
     }
+}
+
+// Which tile each workgroup of the next k_composite_px launch takes: the tiles that took longest LAST time first.
+// The kernel's duration is its longest tile's plus the time that tile spent sharing its SIMD before it was left alone:
+// with every tile resident from the start (C2: 4969 workgroups with entries on 3840 slots) a silhouette tile that walks
+// a thousand entries of pixels that never saturate finishes 60 us after tiles that need 150 — unless it is dispatched
+// first: the hardware favours the oldest waves, and by the time the bulk has drained the long tiles are done as well
+// (C2: 71 -> 57 us with the exact descending order, profiles/r03_c_px_tile_order.txt).  Which tiles are long is not
+// known before they are walked, but a frame resembles the one before it: every launch leaves each tile's cost (chunks
+// walked) behind, and this one-workgroup kernel sorts the tiles by it, longest first, empty tiles last.  The order only says who goes first — any order (also a stale one) gives the same image.
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t *__restrict__ cost, uint32_t tiles, uint32_t *__restrict__ order) {
+    // a counting sort on min(cost, 255), descending; the order inside one cost is whatever the atomics give (it only
+    // decides who is dispatched first)
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&s_cnt[255u - min(cost[t], 255u)], 1u); // bin 0 = the longest
+    __syncthreads();
+    if (tid < 256) { // exclusive scan of the 256 bins (four waves)
+        const uint32_t v = s_cnt[tid];
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += x;
+        }
+        if (lane == 63) s_wsum[w] = incl;
+        s_cnt[tid] = incl - v;
+    }
+    __syncthreads();
+    if (tid < 256) s_cnt[tid] += (w > 0 ? s_wsum[0] : 0u) + (w > 1 ? s_wsum[1] : 0u) + (w > 2 ? s_wsum[2] : 0u);
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&s_cnt[255u - min(cost[t], 255u)], 1u)] = t;
+}
+
+static bool g_px_order_on = true; // SPLAT_TILE_ORDER=0 switches the ordering off (read once per process)
+
+// the per-band ordering state of a context (see k_tile_order): arrays for `tiles` tiles of the band described by `key`
+static int px_order_prepare(splat_ctx *ctx, uint32_t band_tiles, uint64_t key, const uint32_t **order_out, uint32_t **cost_out) {
+    *order_out = nullptr;
+    *cost_out = nullptr;
+    if (band_tiles > ctx->px_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (a launch in flight may still write the old arrays)
+        if (ctx->px_cost) (void)hipFree(ctx->px_cost);
+        if (ctx->px_order) (void)hipFree(ctx->px_order);
+        ctx->px_cost = ctx->px_order = nullptr;
+        ctx->px_cap = 0;
+        ctx->px_key = 0;
+        if (hipMalloc((void **)&ctx->px_cost, (size_t)band_tiles * 4) != hipSuccess || hipMalloc((void **)&ctx->px_order, (size_t)band_tiles * 4) != hipSuccess)
+            return ctx_fail(ctx, SPLAT_ERR_OOM, "composite tile order hipMalloc");
+        ctx->px_cap = band_tiles;
+    }
+    if (ctx->px_key == key && g_px_order_on) { // the previous launch over this very band left its costs: order by them
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, ctx->px_cost, band_tiles, ctx->px_order);
+        LAUNCH_CHECK(ctx, "k_tile_order");
+        *order_out = ctx->px_order;
+    }
+    ctx->px_key = key;
+    *cost_out = ctx->px_cost;
+    return SPLAT_OK;
 }
 
 extern "C" int splat_lit_colors(splat_ctx *ctx, const void *color_opacity, uint32_t color_stride_vec4, const void *normals,
@@ -703,6 +928,8 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     p.frame_total = frame_total;
     p.report = report;
     p.report_seq = report_seq;
+    p.tile_order = nullptr;
+    p.tile_cost = nullptr;
     *launched = true;
     dim3 grid(ntx, r1 - r0), block(256);
     const bool eo = cfg->early_out != 0;
@@ -718,18 +945,37 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     // tile, every lane walking its own entries — unless SPLAT_COMPOSITE=quadrant asks for round 2's k_composite (one
     // 8x8-pixel wave per quadrant visiting every entry of the tile), which also serves the oriented disc (its footprint is
     // not separable) and the reference-literal blend.
-    static int s_px = -1;
-    if (s_px < 0) {
+    // Which kernel composites the isotropic footprint nearest-on-top (the frame's default): k_composite_px — a builder and
+    // a consumer wave per tile, every lane walking its own entries — on screens of at least PX_MIN_TILES tiles (the whole
+    // screen decides, not the band of tile rows this call renders: the ranks of a multi-GPU frame must run the same
+    // arithmetic for their bands to stitch into the single-GPU image bit for bit); below that (C0's 256 tiles: 18 against
+    // 22 us) and for the oriented disc (its footprint is not separable) and the reference-
+    // literal blend, round 2's k_composite (four waves per tile, each visiting every entry that touches its quadrant).
+    // SPLAT_COMPOSITE=pixel | quadrant forces one of them.
+    constexpr uint32_t PX_MIN_TILES = 2048;
+    static int s_px = -2;
+    if (s_px == -2) {
         const char *e = getenv("SPLAT_COMPOSITE");
-        s_px = (e && (e[0] == 'p' || e[0] == 'P')) ? 1 : 0; // (opt-in until it measures faster: SPLAT_COMPOSITE=pixel)
+        s_px = !e ? -1 : (e[0] == 'p' || e[0] == 'P') ? 1 : (e[0] == 'q' || e[0] == 'Q') ? 0 : -1;
+        const char *o = getenv("SPLAT_TILE_ORDER"); // =0: workgroups take tiles row-major (A/B knob for k_tile_order)
+        g_px_order_on = !(o && o[0] == '0');
     }
-    if (s_px && !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK) {
-        const uint32_t band_tiles = ntx * (r1 - r0);
-        const dim3 pgrid(div_up(band_tiles, 4));
+    const uint32_t band_tiles = ntx * (r1 - r0);
+    const bool use_px = !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && (s_px == 1 || (s_px == -1 && ntx * nty >= PX_MIN_TILES));
+    if (use_px) {
+        p.tile_order = ctx->debug_tile_order;
+        const uint64_t key = ((uint64_t)ntx << 40) ^ ((uint64_t)r0 << 20) ^ (uint64_t)r1 ^ ((uint64_t)width << 50);
+        const uint32_t *order = nullptr;
+        int orc = px_order_prepare(ctx, band_tiles, key, &order, &p.tile_cost);
+        if (orc != SPLAT_OK) return orc;
+        if (!p.tile_order) p.tile_order = order;
+        const dim3 pgrid(band_tiles), pblock(128); // one workgroup of two waves (consumer, builder) per tile
 #define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT)                                                                                   \
     do {                                                                                                                     \
-        if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT>), pgrid, block, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
-        else hipLaunchKernelGGL((k_composite_px<EO, LIT>), pgrid, block, 0, ctx->stream, p, band_tiles);                     \
+        if (timed && p.consumed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, true>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
+        else if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, false>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles);      \
+        else if (p.consumed) hipLaunchKernelGGL((k_composite_px<EO, LIT, true>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                   \
+        else hipLaunchKernelGGL((k_composite_px<EO, LIT, false>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                                  \
     } while (0)
         if (lit32) {
             if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, true);

@@ -799,6 +799,12 @@ int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_
     return SPLAT_OK;
 }
 
+int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ctx->debug_tile_order = (const uint32_t *)order_dptr;
+    return SPLAT_OK;
+}
+
 int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, tile != 0xffffffffu);

@@ -300,11 +300,21 @@ def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
         tile_stop, tile_near = tile_max(stop, 16), tile_max(near, 16) > 0
         ok = ~tile_near.reshape(-1)
         assert_same(cons[ok, 1], tile_stop.reshape(-1)[ok].astype(np.uint64), "L301")
-        # entries gathered: k_composite_px (nearest-on-top, the default) works in chunks of 32 and fetches one chunk ahead;
-        # k_composite (reference-literal blend, SPLAT_COMPOSITE=quadrant) stages batches of 256
+        # entries gathered: k_composite_px (nearest-on-top on screens of at least 2048 tiles, or SPLAT_COMPOSITE=pixel) works in
+        # chunks of 32, builds one chunk ahead of the one being walked and fetches two further ahead; k_composite (smaller
+        # screens, the reference-literal blend, SPLAT_COMPOSITE=quadrant) stages batches of 256
         counts64 = ref["counts"].astype(np.uint64)
-        if mode == sr.MODE_FRONT_TO_BACK and os.environ.get("SPLAT_COMPOSITE", "q")[:1].lower() == "p":
-            staged_want = np.minimum(counts64, (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32) + np.uint64(32))
+        forced = os.environ.get("SPLAT_COMPOSITE", "")[:1].lower()
+        px = mode == sr.MODE_FRONT_TO_BACK and (forced == "p" or (forced != "q" and ntx * nty >= 2048))
+        if px and early_out:  # walked chunks = ceil(consumed / 32); the builder was building the next and had fetched two more
+            staged_want = np.minimum(counts64, (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32) + np.uint64(96))
+            # (a tile whose builder had not yet started the chunk after the last walked one when the consumer finished has
+            # fetched one chunk less: both are what the kernel does, depending on which wave reached the barrier first)
+            alt = np.minimum(counts64, (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32) + np.uint64(64))
+            assert np.all((cons[:, 0] == staged_want) | (cons[:, 0] == alt)), "entries staged per tile (k_composite_px)"
+            staged_want = cons[:, 0]
+        elif px:
+            staged_want = counts64
         else:
             staged_want = np.minimum(counts64, (cons[:, 1] + np.uint64(255)) // np.uint64(256) * np.uint64(256))
         assert_same(cons[:, 0], staged_want, "entries staged per tile")

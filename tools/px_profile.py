@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic (a -DPX_PROFILE build of the library, tools/build_variant.sh prof "-DPX_PROFILE"): per tile, how long the
+consumer and builder waves of k_composite_px live and how long each waits at the chunk barriers (s_memtime ticks = shader
+cycles).  python tools/px_profile.py [C2] [early_out=1]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import splat_renderer_amd as sr
+from splat_renderer_amd import _lib
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C2"
+eo = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
+n, w, h = sr.scene.CONFIGS[name]
+props, normals = sr.scene.make_scene(n)
+cam = sr.Camera()
+cam.setAspect(w / h)
+u = cam.uniforms(w, h)
+dev = sr.Device(0)
+pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
+r = sr.Renderer(dev, None, "rgba8unorm", n, records="lit")
+r.render(u, pbuf, nbuf, None, w, h)
+r.finish()
+b = r.binner
+ntx, nty = -(-w // 16), -(-h // 16)
+counts = b.getTileCountsBuffer().read(np.uint32)
+args = (u, pbuf, b.getTileIndicesBuffer(), nbuf, r.projector.getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h)
+cons = dev.createBuffer(ntx * nty * 16)
+csr = sr.ComputeShaderRenderer(dev, None, "rgba8unorm", earlyOut=eo, recordFormat=_lib.RECORDS_LIT32)
+csr.consumedBuffer = cons
+for _ in range(3):
+    csr.render(*args)
+cons.zero()
+csr.render(*args)
+dev.sync()
+v = cons.read(np.uint64).reshape(-1, 2)
+f = lambda x, k: ((x >> np.uint64(16 * k)) & np.uint64(0xffff)).astype(np.float64)
+nz = counts > 0
+b_life, b_wait, b_fetch, b_chunks = f(v[:, 0], 0) * 16, f(v[:, 0], 1) * 16, f(v[:, 0], 2) * 16, f(v[:, 0], 3)
+c_life, c_wait, c_trips, c_ntrips = f(v[:, 1], 0) * 16, f(v[:, 1], 1) * 16, f(v[:, 1], 2) * 16, f(v[:, 1], 3)
+print(f"{name} early_out={eo}: tiles with entries {nz.sum()} (cycles; a life beyond 1.05M cycles wraps)")
+for lab, a in (("consumer life", c_life), ("consumer barrier wait", c_wait), ("consumer in trip loops", c_trips), ("consumer trips", c_ntrips),
+               ("builder life", b_life), ("builder barrier wait", b_wait), ("builder record wait", b_fetch), ("builder chunks built", b_chunks)):
+    x = a[nz]
+    print(f"  {lab:24s} mean {x.mean():9.0f}  p50 {np.percentile(x, 50):9.0f}  p90 {np.percentile(x, 90):9.0f}  p99 {np.percentile(x, 99):9.0f}  max {x.max():9.0f}  sum {x.sum():.3e}")
+print(f"  cycles per trip {c_trips[nz].sum() / max(c_ntrips[nz].sum(), 1):.0f}; record wait per chunk built {b_fetch[nz].sum() / max(b_chunks[nz].sum(), 1):.0f}; "
+      f"builder busy-but-not-waiting per chunk {(b_life[nz].sum() - b_wait[nz].sum() - b_fetch[nz].sum()) / max(b_chunks[nz].sum(), 1):.0f}")
