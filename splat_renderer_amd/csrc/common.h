@@ -33,10 +33,10 @@ struct splat_ctx {
     int rank_policy = 0;
     uint32_t order_faults = 0;      // frames whose lists failed the order check (each was reported and rendered again)
     const uint32_t *debug_tile_order = nullptr; // experiment hook (splat_debug_set_tile_order)
-    // k_composite_px's dispatch order (composite.hip, k_tile_order): per tile of the band `px_key` describes, the cost its
-    // last launch left behind and the order the next one takes
-    uint32_t *px_cost = nullptr, *px_order = nullptr;
-    uint32_t px_cap = 0;
+    // k_composite_px's dispatch order (composite.hip, px_order_prepare): for the band `px_key` describes, two arrays of
+    // per-tile costs and two of tile orders (px_cap entries each), alternating between launches
+    uint32_t *px_mem = nullptr;
+    uint32_t px_cap = 0, px_parity = 0, px_streak = 0;
     uint64_t px_key = 0;
     uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on

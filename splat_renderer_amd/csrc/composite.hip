@@ -55,7 +55,9 @@ struct CompositeParams {
     uint32_t *report;
     uint32_t report_seq;
     const uint32_t *tile_order; // k_composite_px: workgroup b works on tile tile_order[b] of the band (NULL: b)
-    uint32_t *tile_cost;        // k_composite_px: chunks each tile's consumer walked (orders the next launch; NULL: not kept)
+    uint32_t *tile_cost;        // k_composite_px: chunks each tile's consumer walked (NULL: not kept)
+    const uint32_t *order_src;  // k_composite_px, workgroup 0: the costs the PREVIOUS launch over this band left (NULL: none) ...
+    uint32_t *order_dst;        // ... sorted into the order the NEXT launch takes its tiles in
 };
 
 __device__ __forceinline__ uint32_t unorm8(float v) {
@@ -479,6 +481,82 @@ struct PxBuf {
 };
 static_assert(sizeof(PxBuf) * 2 * 15 <= 160 * 1024, "fifteen tiles (thirty waves) per CU");
 
+// Which tile each workgroup of k_composite_px takes: the tiles that took longest first.
+// The kernel's duration is its longest tile's plus the time that tile spent sharing its SIMD before it was left alone:
+// with every tile resident from the start (C2: 4969 workgroups with entries on 3840 slots) a silhouette tile that walks
+// a thousand entries of pixels that never saturate finishes 60 us after tiles that need 150 — unless it is dispatched
+// first: the hardware favours the oldest waves, and by the time the bulk has drained the long tiles are done as well
+// (C2: 71 -> 57 us with the exact descending order, profiles/r03_c_px_tile_order_oracle_C2.txt).  Which tiles are long is
+// not known before they are walked, but a frame resembles the ones before it: every launch leaves each tile's cost
+// (chunks walked) behind, and ONE extra workgroup of the next launch — beside the tiles, costing the frame no launch —
+// sorts them into nine classes, longest first, empty tiles last, for the launch after.  The order only says who goes
+// first: any order (a stale one, one from another scene) gives the same image.
+constexpr uint32_t PX_CLASSES = 9;
+__device__ __forceinline__ uint32_t px_cost_class(uint32_t c) { // 0 = longest ... 8 = no entries
+    return 8u - ((c >= 1) + (c >= 3) + (c >= 5) + (c >= 7) + (c >= 9) + (c >= 12) + (c >= 16) + (c >= 24));
+}
+__device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost, uint32_t tiles, uint32_t *__restrict__ order, uint32_t *s_scratch) {
+    // 128 threads; thread i owns the tiles [i * per, (i + 1) * per) — consecutive, so the order inside a class is the
+    // row-major one — and reads their costs sixteen at a time (the arrays are padded to whole 16-byte reads:
+    // px_order_prepare).  Its nine counters live in LDS (s_cnt[class][thread]: the class of a tile is a run-time index).
+    // The workgroup shares its SIMDs with tile workgroups that would leave it an eighth of the issue slots: top priority.
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t per = (((tiles + 127u) / 128u) + 15u) & ~15u, t0 = tid * per;
+    uint32_t *s_cnt = s_scratch;                     // [PX_CLASSES][128]
+    uint32_t *s_tot = s_scratch + PX_CLASSES * 128;  // [2][PX_CLASSES]
+#pragma unroll
+    for (uint32_t q = 0; q < PX_CLASSES; ++q) s_cnt[q * 128 + tid] = 0;
+    for (uint32_t i = 0; i < per; i += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const uint4 *>(cost + t0 + i)[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = reinterpret_cast<const uint32_t *>(v)[j];
+            if (t0 + i + j < tiles) s_cnt[px_cost_class(c) * 128 + tid] += 1u; // (this thread's own words: no atomics)
+        }
+    }
+    // exclusive scan over the threads, per class; then the classes one after the other
+    uint32_t base[PX_CLASSES];
+#pragma unroll
+    for (uint32_t q = 0; q < PX_CLASSES; ++q) {
+        const uint32_t mine = s_cnt[q * 128 + tid];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += x;
+        }
+        if (lane == 63) s_tot[w * PX_CLASSES + q] = incl; // the wave's total
+        base[q] = incl - mine;
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PX_CLASSES; ++q) {
+        const uint32_t c0 = s_tot[q], c1 = s_tot[PX_CLASSES + q];
+        s_cnt[q * 128 + tid] = base[q] + run + (w ? c0 : 0u); // where this thread's next tile of class q goes
+        run += c0 + c1;
+    }
+    for (uint32_t i = 0; i < per; i += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const uint4 *>(cost + t0 + i)[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = reinterpret_cast<const uint32_t *>(v)[j];
+            const uint32_t t = t0 + i + j;
+            if (t < tiles) {
+                uint32_t *slot = &s_cnt[px_cost_class(c) * 128 + tid];
+                const uint32_t pos = *slot;
+                *slot = pos + 1u;
+                order[pos] = t;
+            }
+        }
+    }
+}
+
 #ifndef PX_WAVES
 #define PX_WAVES 8 // (every instantiation fits 61 registers without scratch; tuning knob of tools/build_variant.sh: minimum waves per SIMD the register allocation must leave room for)
 #endif
@@ -511,8 +589,12 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     __shared__ uint32_t s_done;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // 0 = consumer, 1 = builder (wave-uniform)
-    const uint32_t t_local = p.tile_order ? p.tile_order[blockIdx.x] : blockIdx.x;
-    if (p.report && blockIdx.x == 0 && tid == 0) tile_report(p.frame_total, p.report, p.report_seq);
+    if (blockIdx.x == 0) { // not a tile: the frame's report, and the next launch's tile order
+        if (p.report && tid == 0) tile_report(p.frame_total, p.report, p.report_seq);
+        if (p.order_dst) px_make_order(p.order_src, band_tiles, p.order_dst, reinterpret_cast<uint32_t *>(s_buf));
+        return;
+    }
+    const uint32_t t_local = p.tile_order ? p.tile_order[blockIdx.x - 1u] : blockIdx.x - 1u;
     const uint32_t tx = t_local % p.ntx, ty = t_local / p.ntx + p.tile_row0;
     const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
     const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
@@ -769,65 +851,41 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     }
 }
 
-// Which tile each workgroup of the next k_composite_px launch takes: the tiles that took longest LAST time first.
-// The kernel's duration is its longest tile's plus the time that tile spent sharing its SIMD before it was left alone:
-// with every tile resident from the start (C2: 4969 workgroups with entries on 3840 slots) a silhouette tile that walks
-// a thousand entries of pixels that never saturate finishes 60 us after tiles that need 150 — unless it is dispatched
-// first: the hardware favours the oldest waves, and by the time the bulk has drained the long tiles are done as well
-// (C2: 71 -> 57 us with the exact descending order, profiles/r03_c_px_tile_order.txt).  Which tiles are long is not
-// known before they are walked, but a frame resembles the one before it: every launch leaves each tile's cost (chunks
-// walked) behind, and this one-workgroup kernel sorts the tiles by it, longest first, empty tiles last.  The order only says who goes first — any order (also a stale one) gives the same image.
-__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t *__restrict__ cost, uint32_t tiles, uint32_t *__restrict__ order) {
-    // a counting sort on min(cost, 255), descending; the order inside one cost is whatever the atomics give (it only
-    // decides who is dispatched first)
-    __shared__ uint32_t s_cnt[256];
-    __shared__ uint32_t s_wsum[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 256) s_cnt[tid] = 0;
-    __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&s_cnt[255u - min(cost[t], 255u)], 1u); // bin 0 = the longest
-    __syncthreads();
-    if (tid < 256) { // exclusive scan of the 256 bins (four waves)
-        const uint32_t v = s_cnt[tid];
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t x = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += x;
-        }
-        if (lane == 63) s_wsum[w] = incl;
-        s_cnt[tid] = incl - v;
-    }
-    __syncthreads();
-    if (tid < 256) s_cnt[tid] += (w > 0 ? s_wsum[0] : 0u) + (w > 1 ? s_wsum[1] : 0u) + (w > 2 ? s_wsum[2] : 0u);
-    __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&s_cnt[255u - min(cost[t], 255u)], 1u)] = t;
-}
-
 static bool g_px_order_on = true; // SPLAT_TILE_ORDER=0 switches the ordering off (read once per process)
 
-// the per-band ordering state of a context (see k_tile_order): arrays for `tiles` tiles of the band described by `key`
-static int px_order_prepare(splat_ctx *ctx, uint32_t band_tiles, uint64_t key, const uint32_t **order_out, uint32_t **cost_out) {
-    *order_out = nullptr;
-    *cost_out = nullptr;
+// The per-band ordering state of a context (px_make_order): two cost arrays and two order arrays, alternating.  Launch k
+// over a band writes cost[k & 1], takes its tiles in order[k & 1] — which launch k - 1's ordering workgroup derived from
+// cost[k & 1] as launch k - 2 had left it — and derives order[(k + 1) & 1] from cost[(k + 1) & 1] (launch k - 1's).
+static int px_order_prepare(splat_ctx *ctx, uint32_t band_tiles, uint64_t key, CompositeParams &p) {
+    p.tile_order = nullptr;
+    p.tile_cost = nullptr;
+    p.order_src = nullptr;
+    p.order_dst = nullptr;
+    if (!g_px_order_on) return SPLAT_OK;
     if (band_tiles > ctx->px_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (a launch in flight may still write the old arrays)
-        if (ctx->px_cost) (void)hipFree(ctx->px_cost);
-        if (ctx->px_order) (void)hipFree(ctx->px_order);
-        ctx->px_cost = ctx->px_order = nullptr;
+        if (ctx->px_mem) (void)hipFree(ctx->px_mem);
+        ctx->px_mem = nullptr;
         ctx->px_cap = 0;
         ctx->px_key = 0;
-        if (hipMalloc((void **)&ctx->px_cost, (size_t)band_tiles * 4) != hipSuccess || hipMalloc((void **)&ctx->px_order, (size_t)band_tiles * 4) != hipSuccess)
-            return ctx_fail(ctx, SPLAT_ERR_OOM, "composite tile order hipMalloc");
-        ctx->px_cap = band_tiles;
+        // (each array padded so that px_make_order's 128 threads read whole 64-byte groups of costs past the last tile)
+        const uint32_t cap = (band_tiles + 128u * 16u + 1023u) & ~1023u;
+        if (hipMalloc((void **)&ctx->px_mem, (size_t)cap * 16) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "composite tile order hipMalloc");
+        (void)hipMemsetAsync(ctx->px_mem, 0, (size_t)cap * 16, ctx->stream);
+        ctx->px_cap = cap;
     }
-    if (ctx->px_key == key && g_px_order_on) { // the previous launch over this very band left its costs: order by them
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, ctx->px_cost, band_tiles, ctx->px_order);
-        LAUNCH_CHECK(ctx, "k_tile_order");
-        *order_out = ctx->px_order;
-    }
+    if (ctx->px_key != key) ctx->px_streak = 0; // another band, screen or context history: start over
     ctx->px_key = key;
-    *cost_out = ctx->px_cost;
+    uint32_t *cost[2] = {ctx->px_mem, ctx->px_mem + ctx->px_cap}, *order[2] = {ctx->px_mem + 2 * (size_t)ctx->px_cap, ctx->px_mem + 3 * (size_t)ctx->px_cap};
+    const uint32_t q = ctx->px_parity & 1u;
+    p.tile_cost = cost[q];
+    if (ctx->px_streak >= 2) p.tile_order = order[q]; // written by the previous launch from the costs of the one before it
+    if (ctx->px_streak >= 1) {                         // the previous launch left its costs: sort them for the next launch
+        p.order_src = cost[q ^ 1u];
+        p.order_dst = order[q ^ 1u];
+    }
+    ctx->px_parity ^= 1u;
+    if (ctx->px_streak < 2) ctx->px_streak++;
     return SPLAT_OK;
 }
 
@@ -930,6 +988,8 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     p.report_seq = report_seq;
     p.tile_order = nullptr;
     p.tile_cost = nullptr;
+    p.order_src = nullptr;
+    p.order_dst = nullptr;
     *launched = true;
     dim3 grid(ntx, r1 - r0), block(256);
     const bool eo = cfg->early_out != 0;
@@ -963,13 +1023,12 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     const uint32_t band_tiles = ntx * (r1 - r0);
     const bool use_px = !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && (s_px == 1 || (s_px == -1 && ntx * nty >= PX_MIN_TILES));
     if (use_px) {
-        p.tile_order = ctx->debug_tile_order;
-        const uint64_t key = ((uint64_t)ntx << 40) ^ ((uint64_t)r0 << 20) ^ (uint64_t)r1 ^ ((uint64_t)width << 50);
-        const uint32_t *order = nullptr;
-        int orc = px_order_prepare(ctx, band_tiles, key, &order, &p.tile_cost);
+        const uint64_t key = ((uint64_t)ntx << 40) ^ ((uint64_t)r0 << 20) ^ (uint64_t)r1 ^ ((uint64_t)width << 50) ^ 1u;
+        int orc = px_order_prepare(ctx, band_tiles, key, p);
         if (orc != SPLAT_OK) return orc;
-        if (!p.tile_order) p.tile_order = order;
-        const dim3 pgrid(band_tiles), pblock(128); // one workgroup of two waves (consumer, builder) per tile
+        if (ctx->debug_tile_order) p.tile_order = ctx->debug_tile_order;
+        // one workgroup of two waves (consumer, builder) per tile, behind workgroup 0 (report, next launch's tile order)
+        const dim3 pgrid(band_tiles + 1u), pblock(128);
 #define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT)                                                                                   \
     do {                                                                                                                     \
         if (timed && p.consumed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, true>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \

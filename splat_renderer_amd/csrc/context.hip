@@ -139,8 +139,7 @@ void splat_ctx_destroy(splat_ctx *ctx) {
         for (auto e : t.end) (void)hipEventDestroy(e);
     }
     if (ctx->d_consumed) (void)hipFree(ctx->d_consumed);
-    if (ctx->px_cost) (void)hipFree(ctx->px_cost);
-    if (ctx->px_order) (void)hipFree(ctx->px_order);
+    if (ctx->px_mem) (void)hipFree(ctx->px_mem);
     if (ctx->scan_ws) (void)hipFree(ctx->scan_ws);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
