@@ -120,7 +120,7 @@ def time_composite_alone(dev, r, u, pbuf, nbuf, width, height, tile, early_out, 
     csr = sr.ComputeShaderRenderer(dev, None, "rgba8unorm", earlyOut=early_out, footprint=r.footprint, recordFormat=r.recordFormat)
     csr.consumedBuffer = dev.createBuffer(ntx * nty * 16)
     b = r.binner
-    records = r.projector.getProjectedBuffer()
+    records = r.projector.getRecordsBuffer()  # (lit composite records or ProjectedSplat: r.recordFormat)
     if r.footprint == _lib.FOOTPRINT_DISC:
         raise SystemExit("time_composite_alone: isotropic frames only")
     props = pbuf if not isinstance(pbuf, sr.host.PropertyPlanes) else None

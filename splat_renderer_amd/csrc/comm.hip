@@ -12,6 +12,7 @@
 // splat_comm_unique_id / splat_comm_init, never a silent fallback.
 #include "common.h"
 
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -34,14 +35,33 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void rccl_load() {
-    // a copy that is already in the process first (RTLD_NOLOAD), then the loader's search path, then ROCm's own
+    // a copy that is already in the process first (RTLD_NOLOAD), then the loader's search path, then ROCm's own.
+    // SPLAT_RCCL_LIB (developer / test hook) names the one library to use instead.
+    const char *forced = getenv("SPLAT_RCCL_LIB");
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names)
-        if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    for (const char *n : names)
-        if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    std::string why = "not found";
+    if (forced && forced[0]) {
+        (void)dlerror();
+        g_rccl.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.handle) {
+            const char *e = dlerror(); // (ONE call: dlerror() clears the message it returns)
+            if (e) why = e;
+        }
+    } else {
+        for (const char *n : names)
+            if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names) {
+            if (g_rccl.handle) break;
+            (void)dlerror();
+            g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (!g_rccl.handle) {
+                const char *e = dlerror(); // the message of a real attempt, not of the RTLD_NOLOAD probes
+                if (e) why = e;
+            }
+        }
+    }
     if (!g_rccl.handle) {
-        g_rccl.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        g_rccl.error = "librccl could not be loaded: " + why;
         return;
     }
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.handle, "ncclGetUniqueId");

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(ROWSCAN_THREADS) void k_radix_rowscan(uint32_t *__r
         return;
     }
     uint32_t *row = hist + (size_t)blockIdx.x * num_parts;
-    uint32_t carry = 0;
+    unsigned long long carry = 0; // (64 bits: a row total past 2^32 must not come back small — it is saturated below)
     for (uint32_t base = 0; base < num_parts; base += ROWSCAN_THREADS) {
         const uint32_t i = base + tid;
         const uint32_t v = (i < num_parts) ? row[i] : 0u;
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(ROWSCAN_THREADS) void k_radix_rowscan(uint32_t *__r
         const uint32_t wprefix = __shfl(wincl - ws, w);
         const uint32_t total = __shfl(wincl, ROWSCAN_THREADS / 64 - 1);
         __syncthreads(); // wsum is rewritten by the next round
-        if (i < num_parts) row[i] = carry + wprefix + incl - v;
+        if (i < num_parts) row[i] = (uint32_t)carry + wprefix + incl - v;
         carry += total;
     }
-    if (tid == 0) totals[blockIdx.x] = carry;
+    if (tid == 0) totals[blockIdx.x] = carry > 0x40000000ull ? 0x40000000u : (uint32_t)carry; // (every caller's limit is below 2^30)
 }
 
 // ---------------------------------------------------------------------------------------------

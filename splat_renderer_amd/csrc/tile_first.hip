@@ -173,22 +173,30 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     // there is one (align_m1 = TF2_PART - 1: every partition then holds pairs of ONE low digit, see k_tf_downsweep2);
     // the sum of the totals themselves is this frame's pair total
     const uint32_t digit_room = (digit_total + align_m1) & ~align_m1;
+    // (the frame's pair total in 64 bits: a sum that wrapped would pass the `fits` test below with a small value and let
+    // the scatter write out of bounds; k_radix_rowscan saturates each digit's total at 2^30)
     uint32_t gincl = digit_total, aincl = digit_room;
+    unsigned long long g64 = digit_total;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
         const uint32_t t = __shfl_up(gincl, s), a = __shfl_up(aincl, s);
+        const unsigned long long t64 = __shfl_up(g64, s);
         if ((int)lane >= s) {
             gincl += t;
             aincl += a;
+            g64 += t64;
         }
     }
+    __shared__ unsigned long long wsum64[4];
     if (lane == 63) {
         sh.wave_sums[w] = gincl;
         wsum[w] = aincl;
+        wsum64[w] = g64;
     }
     __syncthreads();
     const uint32_t aprefix = (w > 0 ? wsum[0] : 0u) + (w > 1 ? wsum[1] : 0u) + (w > 2 ? wsum[2] : 0u);
-    const uint32_t all_pairs = sh.wave_sums[0] + sh.wave_sums[1] + sh.wave_sums[2] + sh.wave_sums[3];
+    const unsigned long long all_pairs64 = wsum64[0] + wsum64[1] + wsum64[2] + wsum64[3];
+    const uint32_t all_pairs = all_pairs64 > 0xffffffffull ? 0xffffffffu : (uint32_t)all_pairs64; // saturated: it can only fail `fits`
     const uint32_t run_start = aprefix + aincl - digit_room; // where digit tid's pairs start in the output
     if (blockIdx.x == 0) {
         const bool fits = all_pairs <= pair_limit;

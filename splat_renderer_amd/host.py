@@ -342,6 +342,7 @@ class SplatProjector:
         self.device, self.numSplats = device, numSplats
         self.footprint = _footprint(footprint)
         self.projectedBuffer = device.createBuffer(numSplats * 32)  # :19-23
+        self.contents = "projected"  # what projectedBuffer holds: ProjectedSplat records, or a frame's lit composite records
         self.discBuffer = device.createBuffer(numSplats * 32) if self.footprint == _lib.FOOTPRINT_DISC else None
 
     def project(self, commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer=None, payloadBuffer=None,
@@ -363,6 +364,18 @@ class SplatProjector:
                                   paddedSize), d.ctx)
 
     def getProjectedBuffer(self):  # :196-198
+        """The reference's ProjectedSplat records {min.xy, max.xy | depth, radius, originalIndex, pad}
+        (src/SplatProjector.ts:119-128).  Raises when the last frame left the 32-byte LIT composite records {centre.xy,
+        radius, depth | lit rgb, opacity} here instead (Renderer(records='lit'), the default of the whole-frame facade):
+        code written against the reference's layout must not read those by accident — ask for them with
+        getRecordsBuffer(), or construct Renderer(records='projected')."""
+        if self.contents == "lit":
+            raise SplatError(-5, "the projector's buffer holds lit composite records (Renderer records='lit'), not ProjectedSplat "
+                                 "records: use getRecordsBuffer() and Renderer.recordFormat, or Renderer(records='projected')")
+        return self.projectedBuffer
+
+    def getRecordsBuffer(self):
+        """The record buffer whatever the last frame wrote into it (`contents`: 'projected' | 'lit')."""
         return self.projectedBuffer
 
     def getDiscBuffer(self):
@@ -736,11 +749,12 @@ class Renderer:
         prelit = isinstance(propertyBuffer, PropertyPlanes) and propertyBuffer.prelit
         ts = self.tileSize
         lit = self.records == "lit" and -(-width // ts) <= 256 and -(-height // ts) <= 256
-        self.recordFormat = _lib.RECORDS_LIT32 if lit else _lib.RECORDS_PROJECTED  # of getProjectedBuffer() after this frame
+        self.recordFormat = _lib.RECORDS_LIT32 if lit else _lib.RECORDS_PROJECTED  # of projector.getRecordsBuffer() after this frame
+        self.projector.contents = "lit" if lit else "projected"
         cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], self.recordFormat, int(prelit),
                            self.footprint)
         tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height,
-                self.projector.getProjectedBuffer().ptr if self.writeProjected else None, self.output.ptr,
+                self.projector.projectedBuffer.ptr if self.writeProjected else None, self.output.ptr,
                 self.outputFloat.ptr if wantFloat else None)
         head = (d.ctx, self.sorter._s, self.binner._b, C.byref(cfg), u.ctypes.data_as(C.POINTER(C.c_float)))
         if isinstance(propertyBuffer, PropertyPlanes):  # the native layout: SplatPropertyManager.getPropertyPlanes()

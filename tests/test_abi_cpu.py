@@ -56,3 +56,25 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
                 assert "liboracle" not in text, os.path.join(dirpath, f)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """include/splat.h: "when it cannot be loaded these return SPLAT_ERR_COMM (nothing falls back)".  A library that does
+    not exist (SPLAT_RCCL_LIB names the one to use) must come back as SPLAT_ERR_COMM with the loader's message — the
+    message is built from ONE dlerror() call (a second call returns NULL, and std::string + NULL crashed here)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from splat_renderer_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = C.create_string_buffer(_lib.COMM_ID_BYTES)\n"
+        "rc = lib.splat_comm_unique_id(buf)\n"
+        "msg = lib.splat_last_error(None)\n"
+        "print(rc, (msg or b'').decode())\n" % ROOT)
+    env = dict(os.environ, SPLAT_RCCL_LIB="/nonexistent/librccl_not_here.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) == -7 and "librccl could not be loaded" in msg and "librccl_not_here" in msg, out.stdout

@@ -407,8 +407,13 @@ def test_full_frame_C0(device, order, records):
     assert_same(r.binner.getTileIndicesBuffer().read(np.uint32), ref["indices"], "L390")
     check_image_against_oracle(r.readPixelsFloat(), r.readPixels(), want, want8, near)
     # what the frame's projector left behind: the reference's ProjectedSplat records, or the lit composite records
-    rec = bits(r.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8)
+    rec = bits(r.projector.getRecordsBuffer().read(np.float32)).reshape(n, 8)
     assert_same(rec, bits(lit_records(u, props, normals) if records == "lit" else ref["proj"]), "L394")
+    if records == "lit":  # code written against the reference's ProjectedSplat layout must not get these by accident
+        with pytest.raises(sr.SplatError):
+            r.projector.getProjectedBuffer()
+    else:
+        assert r.projector.getProjectedBuffer() is r.projector.getRecordsBuffer()
     r.destroy()
     pbuf.destroy()
     nbuf.destroy()
@@ -439,7 +444,7 @@ def test_lit_composite_records_give_the_same_frame_bit_for_bit(device, order):
                 b.render(u, pbuf, None if layout == "prelit" else nbuf, None, w, h, wantFloat=True)
             assert b.finish() == total, layout
             assert b.recordFormat == _lib.RECORDS_LIT32
-            assert_same(bits(b.projector.getProjectedBuffer().read(np.float32)).reshape(n, 8), want_rec, ("L425", layout))
+            assert_same(bits(b.projector.getRecordsBuffer().read(np.float32)).reshape(n, 8), want_rec, ("L425", layout))
             assert_same(b.binner.getTileIndicesBuffer().read(np.uint32, total), lists, ("L426", layout))
             assert_same(b.readPixelsFloat().view(np.uint32), img, ("L427", layout))
             b.destroy()
@@ -1024,7 +1029,7 @@ def test_full_size_frame_lists_and_pixels(device, name):
     assert_same(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32), "L916")
     # the frame's records against the oracle's projector (every splat)
     proj = O.project(u, props)
-    rec = r.projector.getProjectedBuffer().read(np.float32).reshape(n, 8)
+    rec = r.projector.getRecordsBuffer().read(np.float32).reshape(n, 8)  # (lit composite records: asserted above)
     assert np.array_equal(bits(rec[:, :3]), bits(O.project_compact(u, props)[:, :3])) and np.array_equal(bits(rec[:, 3]), bits(proj[:, 4]))
     # clamped tile ranges as TileBinner.binSorted forms them (src/TileBinner.ts:432-442), vectorised
     mnx, mny = np.maximum(proj[:, 0], 0), np.maximum(proj[:, 1], 0)
@@ -1245,7 +1250,7 @@ def test_property_planes_give_the_same_frame_as_interleaved_records(device):
         b.render(u, planes, nbuf, None, w, h, wantFloat=True)
     total = a.finish()
     assert b.finish() == total
-    assert_same(a.projector.getProjectedBuffer().read(np.uint32), b.projector.getProjectedBuffer().read(np.uint32), "L1140")
+    assert_same(a.projector.getRecordsBuffer().read(np.uint32), b.projector.getRecordsBuffer().read(np.uint32), "L1140")
     assert_same(a.binner.getTileIndicesBuffer().read(np.uint32, total), b.binner.getTileIndicesBuffer().read(np.uint32, total), "L1141")
     assert_same(a.readPixelsFloat().view(np.uint32), b.readPixelsFloat().view(np.uint32), "L1142")
     # K12 into planes == K12 into interleaved records
@@ -1312,7 +1317,7 @@ def test_new_entry_points_reject_bad_arguments(device):
     uf = np.ascontiguousarray(u, np.float32).ctypes.data_as(C.POINTER(C.c_float))
     planes = pm.getPropertyPlanes()
     cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF)
-    proj = r.projector.getProjectedBuffer().ptr
+    proj = r.projector.getRecordsBuffer().ptr
     # a missing colour plane
     assert lib.splat_render_frame_planes(ctx, r.sorter._s, r.binner._b, C.byref(cfg), uf, planes.posRadius.ptr, None, nbuf.ptr, n, w, h,
                                          proj, out.ptr, None) == -1

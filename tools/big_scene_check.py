@@ -22,7 +22,7 @@ for order in ("tileFirst", "sortFirst"):
     assert int(counts.sum(dtype=np.uint64)) == total
     assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)[:-1]]).astype(np.uint32))
     idx = r.binner.getTileIndicesBuffer().read(np.uint32, total)
-    proj = r.projector.getProjectedBuffer().read(np.float32).reshape(n, 8)
+    proj = r.projector.getRecordsBuffer().read(np.float32).reshape(n, 8)
     # (the frame leaves lit composite records {centre.xy, radius, depth | lit rgb, opacity} by default: depth is float 3;
     # ProjectedSplat records keep it in float 4)
     depth = proj[idx, 3 if r.recordFormat == sr._lib.RECORDS_LIT32 else 4]

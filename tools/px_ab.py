@@ -28,7 +28,7 @@ r.finish()
 ref8 = r.readPixels().copy()
 b = r.binner
 ntx, nty = -(-w // 16), -(-h // 16)
-records = r.projector.getProjectedBuffer()
+records = r.projector.getRecordsBuffer()
 args = (u, pbuf, b.getTileIndicesBuffer(), nbuf, records, b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h)
 cons = dev.createBuffer(ntx * nty * 16)
 out = []

@@ -26,7 +26,7 @@ r.finish()
 b = r.binner
 ntx, nty = -(-w // 16), -(-h // 16)
 counts = b.getTileCountsBuffer().read(np.uint32)
-args = (u, pbuf, b.getTileIndicesBuffer(), nbuf, r.projector.getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h)
+args = (u, pbuf, b.getTileIndicesBuffer(), nbuf, r.projector.getRecordsBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h)
 cons = dev.createBuffer(ntx * nty * 16)
 csr = sr.ComputeShaderRenderer(dev, None, "rgba8unorm", earlyOut=eo, recordFormat=_lib.RECORDS_LIT32)
 csr.consumedBuffer = cons
