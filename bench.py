@@ -35,10 +35,36 @@ def composite_alg_bytes(p_used, width, height):
 
 
 def composite_traffic_model(p_staged, width, height, records, prelit, disc=False):
-    """What the kernel as built is expected to move: per STAGED entry (256-entry batches) the 4-byte index and its
-    gathers — one 32-byte lit composite record; or ProjectedSplat 32 + colour 16 (+ normal 16 unless pre-lit)."""
+    """What the kernel as built is expected to move: per STAGED entry (k_composite_px: chunks of 32, fetched up to three
+    chunks past the last one walked; k_composite: 256-entry batches) the 4-byte index and its gathers — one 32-byte lit
+    composite record; or ProjectedSplat 32 + colour 16 (+ normal 16 unless pre-lit)."""
     per = 4 + (32 if (records == "lit" and not disc) else (48 if prelit else 64))
     return per * p_staged + 4 * width * height
+
+
+def per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, lit, disc):
+    """every kernel group of the tile-first frame against the 8 TB/s HBM roof, from the bytes each is
+    built to move (the tile-first frame's own byte table, which replaces SURVEY §8d's sort / count / fill
+    rows — the composite row IS SURVEY §8d's) and its HIP-event interval in the all-stages loop (each interval carries
+    the ~5 us of idle its event pair costs, so these fractions read slightly low next to a rocprofv3 kernel trace)."""
+    rows = [
+        ("project", "k_project_hist (projector + depth keys + tile ranges + first-pass histogram" + (", lit composite records)" if lit else ")"),
+         (88 if lit else 72 if disc else 56) * n, "B/splat: 16 pos/radius (+ 32 colour, normal) read; 32-byte record + 4 key + 4 range written"),
+        ("bin_scatter", "k_tf_scatter (pair expansion fused with the first tile-id sort pass)", 8 * n + 9 * pairs,
+         "8 B/splat read (key, range) + 9 B/pair written (1 B high tile digit, 8 B key+index)"),
+        ("bin_second_pass", "k_tf_upsweep2 + k_radix_rowscan + k_tf_downsweep2 + k_tf_offsets", 18 * pairs, "1 + 9 B/pair read, 8 B/pair written"),
+        ("bin_tile_sort", "k_tile_sort x2 (PerTileSorter; also checks every list's order)", 12 * pairs, "8 B/pair read, 4 B/pair (index list) written"),
+        ("composite", "k_composite_px / k_composite", composite_alg_bytes(p_used, width, height), "SURVEY 8d: 68 B x consumed entry + 4 B x pixel"),
+    ]
+    out = {}
+    for key, kernels, nbytes, what in rows:
+        ms = stage_ms.get(key, 0.0)
+        if ms <= 0:
+            continue
+        gbs = nbytes / (ms / 1e3) / 1e9
+        out[key] = {"kernels": kernels, "bytes_per_frame": int(nbytes), "bytes_model": what, "ms": round(ms, 4), "achieved_GBps": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def frame_alg_bytes(n, n_sorted, tiles, pairs, p_used, width, height, disc=False):
@@ -248,8 +274,8 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     for _ in range(min(args.steps, 10)):
         frame()
     dev.sync()
-    stage_ms = {sname: stage_avg(sid) for sid, sname in enumerate(_lib.STAGE_NAMES[:4])}
-    stage_ms["composite"] = composite_ms
+    stage_ms = {sname: stage_avg(sid) for sid, sname in enumerate(_lib.STAGE_NAMES) if sname != "exchange"}
+    stage_ms["composite"] = composite_ms  # (the timed region's own figure)
     dev.setTiming(False)
     pairs = r.binner.getTotalIndices()
 
@@ -263,14 +289,15 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     key = name + (("_disc" if prelit else "_unmeasured") if disc else "" if (args.records == "lit" and not prelit) else
                   "_projected_records_prelit_planes" if (args.records == "projected" and prelit) else "_unmeasured")
     pmc = load_traffic(key)
-    roofline = {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    px = (not disc) and ntx * nty >= 2048 and os.environ.get("SPLAT_COMPOSITE", "")[:1].lower() != "q" or os.environ.get("SPLAT_COMPOSITE", "")[:1].lower() == "p"
+    roofline = {"kernel": "k_composite_px" if px else "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"],
                 "formula": "SURVEY 8d: 68 B x pairs_consumed + 4 B x W x H, / avg launch (HIP events on the ctx stream inside the timed region)",
                 "pairs_consumed": round(p_used), "pairs_staged": round(p_staged),
                 "traffic_model": composite_traffic_model(p_staged, width, height, args.records, prelit, disc),
-                "traffic_model_note": "bytes the kernel as built is expected to move: per STAGED entry (256-entry batches) 4 B index + its "
-                                      "gathered record(s), + 4 B per pixel",
+                "traffic_model_note": "bytes the kernel as built is expected to move: per STAGED entry (k_composite_px: chunks of 32, fetched ahead; "
+                                      "k_composite: 256-entry batches) 4 B index + its gathered record(s), + 4 B per pixel",
                 "traffic": pmc.get("k_composite_hbm_bytes_per_launch"),
                 "traffic_source": pmc.get("source", "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not measured in this run)")
                                   if pmc.get("k_composite_hbm_bytes_per_launch") else None,
@@ -295,6 +322,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    "composite": "front-to-back, early-out at alpha>=0.99"},
         "roofline": roofline,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "roofline_per_kernel": per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, args.records == "lit" and not disc, disc),
         "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                            "achieved_GBps": frame_bytes / (dt / args.steps) / 1e9,
                            "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
@@ -525,9 +553,14 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     (local if local is not None else br).render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
     assert tstages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
     tstages.set_timing(False)
+    # self-checks of the exchange for the record (outside the timed region): what the communicator says about itself, and
+    # every other rank's gathered shard against this rank's own projection of that slice, bit for bit
+    rccl_view = gather.rccl_view() if hasattr(gather, "rccl_view") else (td.get_world_size(), td.get_rank())
+    br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
+    verified = br.verify_exchange(u, pt.data_ptr(), nt.data_ptr())
     r0, r1 = br.pixel_rows()
     kept = n if local is not None else stages.kept  # (no band filter without an exchange: every rank bins from all n splats)
-    info = torch.tensor([kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6)], dtype=torch.int64, device="cuda")
+    info = torch.tensor([kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6), rccl_view[0], rccl_view[1], verified], dtype=torch.int64, device="cuda")
     infos = [torch.zeros_like(info) for _ in range(world)]
     td.all_gather(infos, info)
     infos = [[int(v) for v in t.tolist()] for t in infos]
@@ -556,9 +589,17 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                                 ("" if local is not None else f", {stages.rec_floats * 4}-byte exchange records"),
                    "per_rank": [{"splats_kept": i[0], "tile_rows": [i[1], i[2]], "pairs_consumed": i[3],
                                  "composite_ms": i[4] / 1e6} for i in infos],
+                   "exchange": {"collective": collective, "record_bytes": stages.rec_floats * 4,
+                                "bytes_contributed_per_rank": per * stages.rec_floats * 4,
+                                "bytes_received_per_rank": (world - 1) * per * stages.rec_floats * 4,
+                                "rccl_ranks_seen": [i[5] for i in infos], "rccl_rank_of_each_process": [i[6] for i in infos],
+                                "shards_verified_per_rank": [i[7] for i in infos], "shards_expected_per_rank": world - 1,
+                                "verification": "after the timed region every rank re-projected every other rank's slice from its own copy of "
+                                                "the splats and compared it bit for bit with the block the all-gather delivered",
+                                "in_timed_region": local is None},
                    "composite": "front-to-back, early-out at alpha>=0.99"},
-        "roofline": {"kernel": "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": comp_bytes,
+        "roofline": {"kernel": "k_composite_px" if (ntx * nty >= 2048 and not stages.disc) else "k_composite", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": comp_bytes,
                      "avg_launch_ms": infos[slow][4] / 1e6, "rank": slow},
         "cpu_baseline": None,  # reported at N=1 only
     }

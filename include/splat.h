@@ -60,7 +60,11 @@ enum {
     SPLAT_STAGE_BIN = 2,     /* count + scan + fill */
     SPLAT_STAGE_COMPOSITE = 3,
     SPLAT_STAGE_EXCHANGE = 4, /* multi-GPU all-gather */
-    SPLAT_STAGE_COUNT = 5
+    /* parts of SPLAT_STAGE_BIN in the tile-first frame order (each inside the BIN interval): */
+    SPLAT_STAGE_BIN_SCATTER = 5,   /* first pass of the tile-id sort fused with the pair expansion (+ its row scan) */
+    SPLAT_STAGE_BIN_PASS2 = 6,     /* second pass (upsweep, row scan, downsweep) + tile offsets */
+    SPLAT_STAGE_BIN_TILE_SORT = 7, /* PerTileSorter: depth order inside every tile */
+    SPLAT_STAGE_COUNT = 8
 };
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -166,10 +170,10 @@ int splat_sort_set_mode(splat_sorter *s, int mode);
  * *order_faults = frames of this context whose tile lists failed the order check (each was reported with
  * SPLAT_ERR_RETRY).  Runs the probe if it has not run yet (synchronises then). */
 int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_t *order_faults);
-/* TEST HOOK: the next per-tile sort of this context swaps the first two entries of tile `tile`'s finished list just
- * before its order check, as an out-of-lane-order ranking would have left them: the check must raise the frame's flag,
- * the next call return SPLAT_ERR_RETRY, and the frame rendered again be right.  One shot. */
-int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile);
+/* TEST HOOK: the next per-tile sort of this context swaps entries `position` and `position + 1` of tile `tile`'s finished
+ * list just before its order check, as an out-of-lane-order ranking would have left them: the check must raise the
+ * frame's flag, the next call return SPLAT_ERR_RETRY, and the frame rendered again be right.  One shot. */
+int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t position);
 /* EXPERIMENT HOOK: the order in which the lane-efficient composite's workgroups take the tiles of the rendered band
  * (a permutation of 0 .. tiles - 1 as u32 on the device; NULL = row-major).  Any order gives the same image. */
 int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
@@ -425,6 +429,9 @@ int splat_comm_unique_id(void *id_out /* SPLAT_COMM_ID_BYTES host bytes */);
 int splat_comm_init(splat_ctx *ctx, int rank, int world, const void *unique_id, splat_comm **out);
 void splat_comm_destroy(splat_comm *comm);
 int splat_comm_rank(const splat_comm *comm, int *rank, int *world);
+/* What the communicator ITSELF reports (ncclCommCount / ncclCommUserRank), as opposed to what splat_comm_init was told:
+ * a frame loop that records these can show that the ranks it timed really formed one communicator. */
+int splat_comm_count(const splat_comm *comm, int *rccl_ranks, int *rccl_rank);
 /* All-gather of equal shards: rank r's bytes_per_rank bytes at `shard` land at gathered + r * bytes_per_rank on every
  * rank (in place when shard == gathered + rank * bytes_per_rank).  Asynchronous on the ctx stream (any ctx of the
  * communicator's device); timed as SPLAT_STAGE_EXCHANGE. */

@@ -15,8 +15,8 @@ ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -
 # "the previous frame must be rendered again" (its sync-free pair limit overflowed / its lists failed the order check)
 RENDER_AGAIN = (-4, -8)
 
-STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE = 0, 1, 2, 3, 4
-STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange")
+STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE, STAGE_BIN_SCATTER, STAGE_BIN_PASS2, STAGE_BIN_TILE_SORT = range(8)
+STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange", "bin_scatter", "bin_second_pass", "bin_tile_sort")
 MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
 RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_DISC48, RECORDS_LIT32 = 0, 1, 2, 3
 FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC = 0, 1
@@ -82,7 +82,7 @@ SIGNATURES = {
     "splat_probe_lds_atomic_order": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "splat_sort_set_mode": (_i, [_vp, _i]),
     "splat_rank_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32)]),
-    "splat_debug_inject_order_fault": (_i, [_vp, _u32]),
+    "splat_debug_inject_order_fault": (_i, [_vp, _u32, _u32]),
     "splat_debug_set_tile_order": (_i, [_vp, _vp]),
     "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),
     "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),
@@ -122,6 +122,7 @@ SIGNATURES = {
     "splat_comm_init": (_i, [_vp, _i, _i, _vp, _pvp]),
     "splat_comm_destroy": (None, [_vp]),
     "splat_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "splat_comm_count": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "splat_allgather_records": (_i, [_vp, _vp, _vp, _vp, _sz]),
 }
 COMM_ID_BYTES = 128

@@ -405,20 +405,26 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         // kernel, the composite (report_for_composite): the flags then include the per-tile sort's order check, which is
         // what allows these kernels to rank with returning LDS atomics (common.h: rank_atomic_ok).  The report is examined
         // at the next call (binner_settle).
+        stage_begin(ctx, SPLAT_STAGE_BIN_SCATTER); // (the row scan in front of it ran above: a few us not in this interval)
         rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
                                b->d_total + 1, b->tf_hi, b->wide_a, b->tf_block, tf_lo_bits, tf_hi_bits > 0, &b->tf_runs, b->offsets, tiles,
                                nullptr, 0u);
+        stage_end(ctx, SPLAT_STAGE_BIN_SCATTER);
         if (rc != SPLAT_OK) return rc;
         // second pass (high digit) into wide_b, and the tile offsets out of its histogram; a screen of at most 256
         // tiles is sorted by the first pass alone (which then writes the offsets too)
         const bool primary = tf_hi_bits == 0;
+        stage_begin(ctx, SPLAT_STAGE_BIN_PASS2);
         rc = tf_second_pass_launch(ctx, b->tf_hi, b->wide_a, b->wide_b, &b->tf_runs, total32, tiles, tf_lo_bits, tf_hi_bits, b->tf2_hist,
                                    b->offsets, b->d_total, nullptr, 0u);
+        stage_end(ctx, SPLAT_STAGE_BIN_PASS2);
         if (rc != SPLAT_OK) return rc;
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
         // (its first launch also writes the tile counts); every list's order is checked there
+        stage_begin(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
                               b->counts, b->d_total + 1);
+        stage_end(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
         b->report_for_composite = b->pinned_dev;

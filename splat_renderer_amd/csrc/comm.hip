@@ -28,6 +28,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;    // (optional: splat_comm_count)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     std::string error;
 };
 
@@ -69,6 +71,8 @@ void rccl_load() {
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.handle, "ncclCommDestroy");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.handle, "ncclAllGather");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.handle, "ncclGetErrorString");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.handle, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(g_rccl.handle, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
         g_rccl.error = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
 }
@@ -147,6 +151,21 @@ int splat_comm_rank(const splat_comm *comm, int *rank, int *world) {
     if (!comm) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "comm is NULL");
     if (rank) *rank = comm->rank;
     if (world) *world = comm->world;
+    return SPLAT_OK;
+}
+
+int splat_comm_count(const splat_comm *comm, int *rccl_ranks, int *rccl_rank) {
+    if (!comm || !comm->comm) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "comm is NULL");
+    std::string why;
+    const Rccl *r = rccl(why);
+    if (!r) return ctx_fail(comm->ctx, SPLAT_ERR_COMM, why.c_str());
+    if (!r->CommCount || !r->CommUserRank) return ctx_fail(comm->ctx, SPLAT_ERR_COMM, "librccl lacks ncclCommCount / ncclCommUserRank");
+    int n = 0, k = 0;
+    ncclResult_t e = r->CommCount(comm->comm, &n);
+    if (e == ncclSuccess) e = r->CommUserRank(comm->comm, &k);
+    if (e != ncclSuccess) return comm_fail(comm->ctx, r, "ncclCommCount", e);
+    if (rccl_ranks) *rccl_ranks = n;
+    if (rccl_rank) *rccl_rank = k;
     return SPLAT_OK;
 }
 

@@ -38,7 +38,8 @@ struct splat_ctx {
     uint32_t *px_mem = nullptr;
     uint32_t px_cap = 0, px_parity = 0, px_streak = 0;
     uint64_t px_key = 0;
-    uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps
+    uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps ...
+    uint32_t inject_order_position = 0; // ... at entries position, position + 1
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars

@@ -805,10 +805,11 @@ int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr) {
     return SPLAT_OK;
 }
 
-int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile) {
+int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t position) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, tile != 0xffffffffu);
     ctx->inject_order_fault = tile + 1u;
+    ctx->inject_order_position = position;
     return SPLAT_OK;
 }
 

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
                                                                                     uint32_t *__restrict__ out_idx,
                                                                                     uint32_t *__restrict__ counts,
                                                                                     uint32_t *__restrict__ frame_flags,
-                                                                                    uint32_t inject_tile) {
+                                                                                    uint32_t inject_tile, uint32_t inject_pos) {
     static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
     constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_LDS_ELEMS ? TS_MAX_ITEMS * TS_THREADS : TS_LDS_ELEMS;
     __shared__ TileSortShared sh;
@@ -456,10 +456,10 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
             }
             __syncthreads();
         }
-        if (t == inject_tile && tid == 0 && n >= 2) { // test hook (splat_debug_inject_order_fault): the check below must see this
-            const uint2 a = s_el[0];
-            s_el[0] = s_el[1];
-            s_el[1] = a;
+        if (t == inject_tile && tid == 0 && n >= inject_pos + 2u) { // test hook (splat_debug_inject_order_fault): the check below must see this
+            const uint2 a = s_el[inject_pos];
+            s_el[inject_pos] = s_el[inject_pos + 1];
+            s_el[inject_pos + 1] = a;
         }
         if (t == inject_tile) __syncthreads();
         // THE ORDER CHECK.  The tile's list must be in strictly increasing (depth key, splat index) order — that IS the
@@ -469,12 +469,33 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
         // order in the final list.  One LDS read per element (its successor); a violation raises the frame's flag, and
         // the host renders the frame again with ballot ranking (binner_settle).
         bool bad = false;
-        for (uint32_t p = tid; p < n; p += TS_THREADS) {
-            const uint2 a = s_el[p];
-            out_idx[base + p] = a.y;
-            if (p + 1 < n) {
-                const uint2 b = s_el[p + 1];
-                bad |= a.x > b.x || (a.x == b.x && a.y >= b.y);
+        for (uint32_t p0 = 0; p0 < n; p0 += 4 * TS_THREADS) { // (uniform trip count: the lane shifts below want whole waves)
+            uint2 a[4], b63[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) { // four reads in flight, as in the passes
+                const uint32_t p = p0 + i * TS_THREADS + tid;
+                a[i] = s_el[p < n ? p : n - 1];
+                b63[i] = a[i];
+            }
+            if (lane == 63) { // the successor of a wave's last lane is another wave's (or another round's) element
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint32_t p = p0 + i * TS_THREADS + tid;
+                    b63[i] = s_el[p + 1 < n ? p + 1 : n - 1];
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t p = p0 + i * TS_THREADS + tid;
+                if (p < n) out_idx[base + p] = a[i].y;
+                // the successor sits in the next lane (wave_shl:1, no LDS instruction: the kernel is bound by those)
+                uint2 b;
+                b.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[i].x, 0x130, 0xf, 0xf, false);
+                b.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[i].y, 0x130, 0xf, 0xf, false);
+                if (lane == 63) b = b63[i];
+#ifndef TS_NO_ORDER_CHECK // (measuring knob of tools/build_variant.sh: what the check costs, profiles/r03_d_order_check_cost.txt)
+                if (p + 1 < n) bad |= a[i].x > b.x || (a[i].x == b.x && a[i].y >= b.y);
+#endif
             }
         }
         if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
@@ -527,12 +548,13 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
     }
     bool bad = false; // the order check, as above
     for (uint32_t p = tid; p < n; p += TS_THREADS) {
+        const bool inj = t == inject_tile && n >= inject_pos + 2u;
         uint2 a = src[p];
-        if (t == inject_tile && p < 2) a = src[p ^ 1u];
+        if (inj && (p == inject_pos || p == inject_pos + 1)) a = src[p == inject_pos ? p + 1 : p - 1];
         out_idx[base + p] = a.y;
         if (p + 1 < n) {
             uint2 b = src[p + 1];
-            if (t == inject_tile && p == 0) b = src[0];
+            if (inj && (p + 1 == inject_pos || p + 1 == inject_pos + 1)) b = src[p + 1 == inject_pos ? p + 2 : p];
             bad |= a.x > b.x || (a.x == b.x && a.y >= b.y);
         }
     }
@@ -548,6 +570,7 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
     const bool ra = rank_atomic_ok(ctx, true); // (every list is checked below: atomics are allowed here by default)
     const uint32_t inject = ctx->inject_order_fault ? ctx->inject_order_fault - 1u : 0xffffffffu; // one-shot test hook
+    const uint32_t inject_pos = ctx->inject_order_position;
     ctx->inject_order_fault = 0;
     // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
@@ -555,7 +578,7 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     const bool one_class = tiles <= 3u * 256u;
 #define SPLAT_TILE_SORT(RA, ITEMS, LAST, ABOVE, COUNTS)                                                                                      \
     hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, scratch, \
-                       out_idx, COUNTS, frame_flags, inject)
+                       out_idx, COUNTS, frame_flags, inject, inject_pos)
     if (one_class) {
         if (ra) SPLAT_TILE_SORT(true, TS_LONG_ITEMS, true, 0u, counts);
         else SPLAT_TILE_SORT(false, TS_LONG_ITEMS, true, 0u, counts);

@@ -276,6 +276,12 @@ class AbiAllGather:
         ctx = self.ctx_of_stream[int(self.torch.cuda.current_stream().cuda_stream)]
         check(self.lib.splat_allgather_records(ctx, self.comm, shard.data_ptr(), out.data_ptr(), shard.numel() * shard.element_size()), ctx)
 
+    def rccl_view(self):
+        """(ranks, rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, k = C.c_int(), C.c_int()
+        check(self.lib.splat_comm_count(self.comm, C.byref(n), C.byref(k)))
+        return int(n.value), int(k.value)
+
     def destroy(self):
         if self.comm:
             self.lib.splat_comm_destroy(self.comm)
@@ -309,6 +315,24 @@ class BandRenderer:
         else:
             st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image)
         return self.image
+
+    def verify_exchange(self, uniforms, props_ptr, normals_ptr=None):
+        """Self-check of the frame's exchange (every rank holds all splats, so it can recompute any shard): projects each
+        OTHER rank's slice locally and compares it, bit for bit, with the block that rank contributed to the last
+        all-gather (render() with the same uniforms first).  Returns the number of other ranks whose block matched."""
+        st, torch = self.stages, self.stages.torch
+        tmp = st.new_records(self.per, fill_nan=True)
+        rec = self.gathered.reshape(self.world, self.per, -1)
+        ok = 0
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            first, count = slice_range(self.n, r, self.world)
+            st.project_slice(uniforms, props_ptr, first, count, tmp, normals_ptr)
+            if hasattr(torch, "cuda") and tmp.is_cuda:
+                torch.cuda.synchronize()
+            ok += int(torch.equal(tmp[:count].view(torch.int32), rec[r, :count].view(torch.int32)))
+        return ok
 
     def rebalance(self, all_reduce_sum):
         """Re-cut the bands from the pairs-per-row histogram of the frame just rendered.

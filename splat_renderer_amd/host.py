@@ -140,9 +140,10 @@ class Device:
         return {"policy": ("checked", "atomic", "ballot")[pol.value], "atomicsOrdered": bool(ordered.value == 1),
                 "orderFaults": int(faults.value)}
 
-    def injectOrderFault(self, tile):
-        """TEST HOOK (splat_debug_inject_order_fault): the next per-tile sort leaves tile `tile`'s first two entries swapped."""
-        check(self.lib.splat_debug_inject_order_fault(self.ctx, int(tile)), self.ctx)
+    def injectOrderFault(self, tile, position=0):
+        """TEST HOOK (splat_debug_inject_order_fault): the next per-tile sort leaves entries position, position + 1 of tile
+        `tile`'s list swapped."""
+        check(self.lib.splat_debug_inject_order_fault(self.ctx, int(tile), int(position)), self.ctx)
 
     def destroy(self):
         if self.ctx:

@@ -25,6 +25,7 @@ class OracleStages:
     def __init__(self, width, height, tile=16, disc=False):
         self.width, self.height, self.tile = width, height, tile
         self.kept = 0
+        self.torch = torch
         self.disc = disc  # the oriented-disc footprint: 48-byte exchange records {disc record, depth, 0, 0, 0}
 
     def new_records(self, count, fill_nan=False):
@@ -112,6 +113,8 @@ def _worker(rank, world, port, n, w, h, out_dir, disc=False, local=False):
     br = (dist.LocalBandRenderer(st, n, w, h, rank, world) if local else
           dist.BandRenderer(st, n, w, h, rank, world, td.all_gather_into_tensor))
     img = br.render(u, props, normals)
+    if not local:  # bench.py's self-check of the exchange: every other rank's gathered shard equals this rank's projection of it
+        assert br.verify_exchange(u, props, normals) == world - 1
     r0, r1 = br.pixel_rows()
     np.save(os.path.join(out_dir, f"band{rank}.npy"), img.numpy()[r0:r1])
     np.save(os.path.join(out_dir, f"rows{rank}.npy"), np.array([r0, r1, st.kept]))

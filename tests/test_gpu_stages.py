@@ -897,21 +897,24 @@ def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
     report must carry the flag, the facade must get SPLAT_ERR_RETRY and render the frame again, the context must rank
     with ballots from then on, and the lists and the image that come back must be the oracle's.  First (host-synchronised)
     frame, sync-free frame, both size classes and a list long enough for the global-memory passes."""
-    cases = [(3000, 128, 96, 71, 1.0, False), (20000, 640, 360, 72, 1.0, True), (30000, 48, 32, 73, 8.0, True), (6000, 16, 16, 74, 30.0, False)]
-    for n, w, h, seed, rs, sync_free in cases:
+    # (position of the swapped pair in the victim's list: 0; 63 | 64 and 255 | 256 are the pairs the check reads across a
+    # wave / a round of the workgroup; 4000 lies in the long class's in-LDS range)
+    cases = [(3000, 128, 96, 71, 1.0, False, 0), (20000, 640, 360, 72, 1.0, True, 63), (30000, 48, 32, 73, 8.0, True, 255),
+             (30000, 48, 32, 75, 8.0, False, 4000), (6000, 16, 16, 74, 30.0, False, 1000)]
+    for n, w, h, seed, rs, sync_free, position in cases:
         dev = sr.Device(0)  # (a failed check switches its context to ballots for good: one context per case)
         try:
             assert dev.rankStatus() == {"policy": "checked", "atomicsOrdered": True, "orderFaults": 0}
             props, normals, u = make_case(n, w, h, seed, rs)
             ref = oracle_pipeline(props, normals, u, w, h)
-            victim = int(np.argmax(ref["counts"]))  # the longest list (>= 2 entries)
-            assert ref["counts"][victim] >= 2
+            victim = int(np.argmax(ref["counts"]))  # the longest list
+            assert ref["counts"][victim] >= position + 2, (ref["counts"][victim], position)
             pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
             r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
             if sync_free:  # a good first frame, then the fault hits a frame whose report is only read at the next call
                 r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
                 good = r.readPixelsFloat().copy()
-            dev.injectOrderFault(victim)
+            dev.injectOrderFault(victim, position)
             r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
             total = r.finish()  # learns of the failed check, renders the frame again (with ballots)
             assert r.previousFrameOverflowed  # (the facade's "a frame had to be rendered again" flag)
