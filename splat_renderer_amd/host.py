@@ -241,17 +241,23 @@ class PropertyPlanes:
         self.colorOpacity.destroy()
 
 
+def default_properties(numSplats):
+    """SplatPropertyManager.initializeDefaults (src/SplatPropertyManager.ts:33-50): position 0, radius 0.04, white, opacity
+    0.7 — (numSplats, 8) f32.  Held to an execution of the reference's own loop (tests/golden/ref_host.json)."""
+    data = np.zeros((numSplats, 8), np.float32)
+    data[:, 3] = 0.04
+    data[:, 4:7] = 1.0
+    data[:, 7] = 0.7
+    return data
+
+
 class SplatPropertyManager:
     """src/SplatPropertyManager.ts:13-181 — owns the 32 B/splat interleaved property buffer."""
 
     def __init__(self, device, numSplats):
         self.device, self.numSplats = device, numSplats
         self.propertyBuffer = device.createBuffer(numSplats * 32)
-        data = np.zeros((numSplats, 8), np.float32)  # initializeDefaults :33-50
-        data[:, 3] = 0.04
-        data[:, 4:7] = 1.0
-        data[:, 7] = 0.7
-        self.propertyBuffer.write(data)
+        self.propertyBuffer.write(default_properties(numSplats))  # initializeDefaults :33-50
         self._planes, self._planes_valid = None, False
         self._lit, self._lit_valid, self._lit_normals = None, False, None
 

@@ -19,15 +19,25 @@ const RECORDS_PROJECTED = 0, RECORDS_COMPACT = 1, RECORDS_LIT32 = 3;
 
 class Buffer_ {
   constructor(device, ptr, size, owned = true) {
-    this.device = device; this.ptr = ptr; this.size = size; this.owned = owned; this.hostShadow = null;
+    this.device = device;
+    this.ptr = ptr;
+    this.size = size;
+    this.owned = owned;
+    this.hostShadow = null;
   }
-  destroy() { if (this.owned && this.ptr) native.buf_free(this.device.ctx, this.ptr); this.ptr = 0; }
+  destroy() {
+    if (this.owned && this.ptr) native.buf_free(this.device.ctx, this.ptr);
+    this.ptr = 0;
+  }
   write(typedArray) {
     native.buf_upload(this.device.ctx, this.ptr, typedArray);
     if (this.size <= 256) this.hostShadow = new Float32Array(typedArray.buffer.slice(typedArray.byteOffset, typedArray.byteOffset + typedArray.byteLength));
     return this;
   }
-  read(typedArray) { native.buf_download(this.device.ctx, typedArray, this.ptr); return typedArray; }
+  read(typedArray) {
+    native.buf_download(this.device.ctx, typedArray, this.ptr);
+    return typedArray;
+  }
   zero() { native.buf_zero(this.device.ctx, this.ptr, this.size); }
 }
 
@@ -36,16 +46,28 @@ class Device {
     this.ctx = native.ctx_create(ordinal);
     const self = this;
     this.queue = {
-      writeBuffer(buffer, offset, data) { if (offset !== 0) throw new Error('writeBuffer: only offset 0 is supported'); buffer.write(data); },
+      writeBuffer(buffer, offset, data) {
+        if (offset !== 0) throw new Error('writeBuffer: only offset 0 is supported');
+        buffer.write(data);
+      },
       submit() {},
-      onSubmittedWorkDone() { self.sync(); return Promise.resolve(); },
+      onSubmittedWorkDone() {
+        self.sync();
+        return Promise.resolve();
+      },
     };
   }
-  createBuffer(desc) { const size = typeof desc === 'number' ? desc : desc.size; return new Buffer_(this, native.buf_alloc(this.ctx, size), size); }
+  createBuffer(desc) {
+    const size = typeof desc === 'number' ? desc : desc.size;
+    return new Buffer_(this, native.buf_alloc(this.ctx, size), size);
+  }
   createBufferFrom(typedArray) { return this.createBuffer(Math.max(typedArray.byteLength, 16)).write(typedArray); }
   createCommandEncoder() { return { finish() { return null; } }; }
   sync() { native.sync(this.ctx); }
-  destroy() { if (this.ctx) native.ctx_destroy(this.ctx); this.ctx = null; }
+  destroy() {
+    if (this.ctx) native.ctx_destroy(this.ctx);
+    this.ctx = null;
+  }
 }
 
 function uniformFloats(u) {
@@ -60,22 +82,41 @@ function uniformFloats(u) {
 /** src/SplatPropertyManager.ts:13-181 */
 class SplatPropertyManager {
   constructor(device, numSplats) {
-    this.device = device; this.numSplats = numSplats;
+    this.device = device;
+    this.numSplats = numSplats;
     this.propertyBuffer = device.createBuffer(numSplats * 32);
-    const data = new Float32Array(numSplats * 8); // initializeDefaults :33-50
-    for (let i = 0; i < numSplats; i++) { data[i * 8 + 3] = 0.04; data[i * 8 + 4] = 1; data[i * 8 + 5] = 1; data[i * 8 + 6] = 1; data[i * 8 + 7] = 0.7; }
-    this.propertyBuffer.write(data);
+    this.propertyBuffer.write(SplatPropertyManager.defaultProperties(numSplats)); // initializeDefaults :33-50
+  }
+  // :33-50: position 0, radius 0.04, white, opacity 0.7 (held to an execution of the reference's loop: tests/golden/ref_host.json)
+  static defaultProperties(numSplats) {
+    const data = new Float32Array(numSplats * 8);
+    for (let i = 0; i < numSplats; i++) {
+      data[i * 8 + 3] = 0.04;
+      data[i * 8 + 4] = 1;
+      data[i * 8 + 5] = 1;
+      data[i * 8 + 6] = 1;
+      data[i * 8 + 7] = 0.7;
+    }
+    return data;
   }
   updateFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) { // :153-173
     native.update_props(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, this.propertyBuffer.ptr);
-    this.planesValid = false; this.litValid = false;
+    this.planesValid = false;
+    this.litValid = false;
   }
-  setFromArrays(props) { this.propertyBuffer.write(props); this.planesValid = false; this.litValid = false; }
+  setFromArrays(props) {
+    this.propertyBuffer.write(props);
+    this.planesValid = false;
+    this.litValid = false;
+  }
   getPropertyBuffer() { return this.propertyBuffer; } // :175-177
   // the MI355X-native layout: two vec4 planes {posRadius, colorOpacity}; Renderer.render takes either
   getPropertyPlanes() {
     if (!this.planes) this.planes = { posRadius: this.device.createBuffer(this.numSplats * 16), colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true };
-    if (!this.planesValid) { native.props_to_planes(this.device.ctx, this.propertyBuffer.ptr, this.numSplats, this.planes.posRadius.ptr, this.planes.colorOpacity.ptr); this.planesValid = true; }
+    if (!this.planesValid) {
+      native.props_to_planes(this.device.ctx, this.propertyBuffer.ptr, this.numSplats, this.planes.posRadius.ptr, this.planes.colorOpacity.ptr);
+      this.planesValid = true;
+    }
     return this.planes;
   }
   // the planes with the colour plane already lit by the given normals (kd = 0.85 + 0.15 max(n.l, 0), once per
@@ -85,7 +126,8 @@ class SplatPropertyManager {
     if (!this.lit) this.lit = { posRadius: p.posRadius, colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true, prelit: true };
     if (!this.litValid || this.litNormals !== normalsBuffer.ptr) {
       native.lit_colors(this.device.ctx, p.colorOpacity.ptr, 1, normalsBuffer.ptr, 1, this.numSplats, this.lit.colorOpacity.ptr);
-      this.litValid = true; this.litNormals = normalsBuffer.ptr;
+      this.litValid = true;
+      this.litNormals = normalsBuffer.ptr;
     }
     return this.lit;
   }
@@ -96,8 +138,15 @@ class SplatPropertyManager {
   }
   destroy() { // :179-181
     this.propertyBuffer.destroy();
-    if (this.planes) { this.planes.posRadius.destroy(); this.planes.colorOpacity.destroy(); this.planes = null; }
-    if (this.lit) { this.lit.colorOpacity.destroy(); this.lit = null; }
+    if (this.planes) {
+      this.planes.posRadius.destroy();
+      this.planes.colorOpacity.destroy();
+      this.planes = null;
+    }
+    if (this.lit) {
+      this.lit.colorOpacity.destroy();
+      this.lit = null;
+    }
   }
 }
 
@@ -111,8 +160,11 @@ function footprintCode(f) {
  * the disc's exact screen extent and getDiscBuffer() holds the 32-byte records the composite evaluates. */
 class SplatProjector {
   constructor(device, numSplats, footprint = 'isotropic') {
-    this.device = device; this.numSplats = numSplats; this.footprint = footprintCode(footprint);
+    this.device = device;
+    this.numSplats = numSplats;
+    this.footprint = footprintCode(footprint);
     this.projectedBuffer = device.createBuffer(numSplats * 32);
+    this.contents = 'projected';
     this.discBuffer = this.footprint === FOOTPRINT_DISC ? device.createBuffer(numSplats * 32) : null;
   }
   project(commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer = null, payloadBuffer = null, paddedSize = 0, normalsBuffer = null) { // :174-194
@@ -127,9 +179,25 @@ class SplatProjector {
     }
     native.project(this.device.ctx, u, splatPropertyBuffer.ptr, 2, this.numSplats, this.projectedBuffer.ptr, keys, payload, paddedSize);
   }
-  getProjectedBuffer() { return this.projectedBuffer; } // :196-198
-  getDiscBuffer() { if (!this.discBuffer) throw new Error("getDiscBuffer: this projector was not created with footprint 'disc'"); return this.discBuffer; }
-  destroy() { this.projectedBuffer.destroy(); if (this.discBuffer) this.discBuffer.destroy(); }          // :200-202
+  // :196-198.  Throws when the last frame left the 32-byte LIT composite records {centre.xy, radius, depth | lit rgb,
+  // opacity} here instead of ProjectedSplat records (Renderer records 'lit', the whole-frame facade's default): code
+  // written against the reference's layout must not read those by accident — getRecordsBuffer() hands them out.
+  getProjectedBuffer() {
+    if (this.contents === 'lit') {
+      throw new Error("the projector's buffer holds lit composite records (Renderer records 'lit'), not ProjectedSplat records: " +
+        "use getRecordsBuffer() and Renderer.recordFormat, or new Renderer(..., { records: 'projected' })");
+    }
+    return this.projectedBuffer;
+  }
+  getRecordsBuffer() { return this.projectedBuffer; } // whatever the last frame wrote (this.contents: 'projected' | 'lit')
+  getDiscBuffer() {
+    if (!this.discBuffer) throw new Error("getDiscBuffer: this projector was not created with footprint 'disc'");
+    return this.discBuffer;
+  }
+  destroy() {
+    this.projectedBuffer.destroy();
+    if (this.discBuffer) this.discBuffer.destroy();
+  }          // :200-202
 }
 
 /** src/DepthKeyExtractor.ts:5-115 */
@@ -144,16 +212,21 @@ class DepthKeyExtractor {
 /** src/RadixSorter.ts:21-301 */
 class RadixSorter {
   constructor(device, numSplats) {
-    this.device = device; this.numSplats = numSplats;
+    this.device = device;
+    this.numSplats = numSplats;
     this.handle = native.sort_create(device.ctx, numSplats);
-    this.paddedSize = native.sort_capacity(this.handle); // :46-52
+    this.paddedSize = native.sort_capacity(this.handle);
+    // :46-52
   }
   sort(numKeys = this.numSplats, bitBegin = 0, bitEnd = 32) { native.sort_run(this.device.ctx, this.handle, numKeys, bitBegin, bitEnd); } // :197-264
   getSortedIndicesBuffer() { return new Buffer_(this.device, native.sort_sorted_payload(this.handle), this.paddedSize * 4, false); } // :269-271
   getKeysBuffer() { return new Buffer_(this.device, native.sort_keys(this.handle), this.paddedSize * 4, false); }       // :273-275
   getPayloadBuffer() { return new Buffer_(this.device, native.sort_payload(this.handle), this.paddedSize * 4, false); } // :277-279
   cleanupTempBuffers() {}
-  destroy() { if (this.handle) native.sort_destroy(this.handle); this.handle = null; }
+  destroy() {
+    if (this.handle) native.sort_destroy(this.handle);
+    this.handle = null;
+  }
 }
 
 /** src/PrefixSumScanner.ts:8-168 */
@@ -168,8 +241,11 @@ class PrefixSumScanner {
 /** src/GPUTileBinner.ts:11-378 */
 class GPUTileBinner {
   constructor(device, tileSize) {
-    this.device = device; this.tileSize = tileSize; this.handle = native.bin_create(device.ctx, tileSize);
-    this.prefixSumScanner = new PrefixSumScanner(device); // :49
+    this.device = device;
+    this.tileSize = tileSize;
+    this.handle = native.bin_create(device.ctx, tileSize);
+    this.prefixSumScanner = new PrefixSumScanner(device);
+    // :49
     this.numTiles = 0;
   }
   // order of work of the whole-frame call: 'tileFirst' (bin in index order, PerTileSorter-style depth sort per tile;
@@ -181,19 +257,29 @@ class GPUTileBinner {
   }
   // the natives throw Error("... Tile offsets buffer not initialized") etc. before binSplats, as :340-359
   getTileOffsetsBuffer() { return new Buffer_(this.device, native.bin_offsets(this.device.ctx, this.handle), this.numTiles * 4, false); }
-  getTileIndicesBuffer() { const p = native.bin_indices(this.device.ctx, this.handle); return new Buffer_(this.device, p, Math.max(4, this.getTotalIndices() * 4), false); }
+  getTileIndicesBuffer() {
+    const p = native.bin_indices(this.device.ctx, this.handle);
+    return new Buffer_(this.device, p, Math.max(4, this.getTotalIndices() * 4), false);
+  }
   getTileCountsBuffer() { return new Buffer_(this.device, native.bin_counts(this.device.ctx, this.handle), this.numTiles * 4, false); }
   getTotalIndices() { return native.bin_total(this.device.ctx, this.handle); }
   getTileSize() { return this.tileSize; } // :361-363
   cleanupTempBuffers() { this.prefixSumScanner.cleanupTempBuffers(); }
-  destroy() { if (this.handle) native.bin_destroy(this.handle); this.handle = null; }
+  destroy() {
+    if (this.handle) native.bin_destroy(this.handle);
+    this.handle = null;
+  }
 }
 
 /** src/PerTileSorter.ts:6-223 — lists leave GPUTileBinner already in (depth key, index) order, so sort()
  * reorders nothing; with validate=true it runs the order check on the device and returns the number
  * of out-of-order neighbours (0). */
 class PerTileSorter {
-  constructor(device, validate = false) { this.device = device; this.validate = validate; this.violations = 0; }
+  constructor(device, validate = false) {
+    this.device = device;
+    this.validate = validate;
+    this.violations = 0;
+  }
   sort(commandEncoder, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, splatIndicesBuffer, numTiles, maxSplatsPerTile, totalPairs) { // :174-213
     if (!this.validate) return undefined;
     const total = totalPairs === undefined ? splatIndicesBuffer.size / 4 : totalPairs;
@@ -207,14 +293,21 @@ class PerTileSorter {
 /** src/ComputeShaderRenderer.ts:5-469 (the canvas blit :268-338 is out of scope) */
 class ComputeShaderRenderer {
   constructor(device, context = null, presentationFormat = 'rgba8unorm', options = {}) {
-    this.device = device; this.mode = options.mode || MODE_FRONT_TO_BACK; this.earlyOut = options.earlyOut !== false;
-    this.footprint = footprintCode(options.footprint); // 'disc': projectedBuffer in render() is the disc projector's getDiscBuffer()
-    this.outputTexture = null; this.width = 0; this.height = 0;
+    this.device = device;
+    this.mode = options.mode || MODE_FRONT_TO_BACK;
+    this.earlyOut = options.earlyOut !== false;
+    this.footprint = footprintCode(options.footprint);
+    // 'disc': projectedBuffer in render() is the disc projector's getDiscBuffer()
+    this.outputTexture = null;
+    this.width = 0;
+    this.height = 0;
   }
   ensureOutputTexture(width, height) { // :340-360
     if (this.width !== width || this.height !== height) {
       if (this.outputTexture) this.outputTexture.destroy();
-      this.outputTexture = this.device.createBuffer(width * height * 4); this.width = width; this.height = height;
+      this.outputTexture = this.device.createBuffer(width * height * 4);
+      this.width = width;
+      this.height = height;
     }
   }
   render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, tileSize, numTilesX, width, height) { // :362-462
@@ -224,7 +317,10 @@ class ComputeShaderRenderer {
       projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr, width, height, this.outputTexture.ptr, null);
   }
   readPixels() { return this.outputTexture.read(new Uint8Array(this.width * this.height * 4)); }
-  destroy() { if (this.outputTexture) this.outputTexture.destroy(); this.outputTexture = null; } // :464-468
+  destroy() {
+    if (this.outputTexture) this.outputTexture.destroy();
+    this.outputTexture = null;
+  } // :464-468
 }
 
 /** src/TileRenderer.ts:5-355 — fronts the same composite; bindTileData supplies what render()'s reference signature lacks */
@@ -242,13 +338,22 @@ class TileRenderer extends ComputeShaderRenderer {
  * composites the same order with ComputeShaderRenderer's screen-space Gaussian. */
 class SequentialRenderer {
   constructor(device, context = null, presentationFormat = 'rgba8unorm', numSplats = 0, tileSize = 16, footprint = 'disc') {
-    this.device = device; this.numSplats = numSplats; this.tileSize = tileSize;
-    this.projector = new SplatProjector(device, numSplats, footprint); this.binner = new GPUTileBinner(device, tileSize);
+    this.device = device;
+    this.numSplats = numSplats;
+    this.tileSize = tileSize;
+    this.projector = new SplatProjector(device, numSplats, footprint);
+    this.binner = new GPUTileBinner(device, tileSize);
     this.compositor = new ComputeShaderRenderer(device, context, presentationFormat, { footprint });
   }
   render(uniformData, splatPropertyBuffer, sortedIndexBuffer, curvatureBuffer, width, height) { // :233-314
     let u = uniformFloats(uniformData);
-    if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
+    if (u.length < 22) {
+      const v = new Float32Array(22);
+      v.set(u.subarray(0, 20));
+      v[20] = width;
+      v[21] = height;
+      u = v;
+    }
     const disc = this.projector.footprint === FOOTPRINT_DISC;
     this.projector.project(null, u, splatPropertyBuffer, null, null, 0, disc ? curvatureBuffer : null);
     native.bin_run(this.device.ctx, this.binner.handle, this.projector.getProjectedBuffer().ptr, this.numSplats, sortedIndexBuffer.ptr, this.numSplats, width, height, 0, U32_MAX);
@@ -257,62 +362,132 @@ class SequentialRenderer {
       this.binner.getTileCountsBuffer(), this.binner.getTileOffsetsBuffer(), this.tileSize, Math.ceil(width / this.tileSize), width, height);
   }
   readPixels() { return this.compositor.readPixels(); }
-  destroy() { this.projector.destroy(); this.binner.destroy(); this.compositor.destroy(); } // :316-320
+  destroy() {
+    this.projector.destroy();
+    this.binner.destroy();
+    this.compositor.destroy();
+  } // :316-320
 }
 
 /** src/Renderer.ts:13,250,311 — name kept as the whole-frame facade (project -> keys -> sort -> bin -> composite) */
 class Renderer {
   constructor(device, context = null, presentationFormat = 'rgba8unorm', numPoints = 0, tileSize = 16, options = {}) {
-    this.device = device; this.numPoints = numPoints; this.tileSize = tileSize;
-    this.footprint = footprintCode(options.footprint); // 'disc': SequentialRenderer's oriented discs (normalsBuffer then always required)
+    this.device = device;
+    this.numPoints = numPoints;
+    this.tileSize = tileSize;
+    this.footprint = footprintCode(options.footprint);
+    // 'disc': SequentialRenderer's oriented discs (normalsBuffer then always required)
     // records 'lit' (default, isotropic frames): the projector leaves 32-byte lit composite records (centre, radius, depth |
     // lit colour) in projector.getProjectedBuffer() and the composite gathers ONE line per staged list entry;
     // 'projected': the reference's ProjectedSplat records, colour and normal gathered per entry.  Same image.
     this.records = options.records === 'projected' || this.footprint === FOOTPRINT_DISC ? 'projected' : 'lit';
-    this.projector = new SplatProjector(device, numPoints); this.sorter = new RadixSorter(device, numPoints); this.binner = new GPUTileBinner(device, tileSize);
-    this.output = null; this.width = 0; this.height = 0;
+    this.projector = new SplatProjector(device, numPoints);
+    this.sorter = new RadixSorter(device, numPoints);
+    this.binner = new GPUTileBinner(device, tileSize);
+    this.output = null;
+    this.width = 0;
+    this.height = 0;
   }
   render(uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height) {
+    this.last = [uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height]; // (finish() may render it again)
     let u = uniformFloats(uniformData);
-    if (u.length < 22) { const v = new Float32Array(22); v.set(u.subarray(0, 20)); v[20] = width; v[21] = height; u = v; }
-    if (this.width !== width || this.height !== height) { if (this.output) this.output.destroy(); this.output = this.device.createBuffer(width * height * 4); this.width = width; this.height = height; }
+    if (u.length < 22) {
+      const v = new Float32Array(22);
+      v.set(u.subarray(0, 20));
+      v[20] = width;
+      v[21] = height;
+      u = v;
+    }
+    if (this.width !== width || this.height !== height) {
+      if (this.output) this.output.destroy();
+      this.output = this.device.createBuffer(width * height * 4);
+      this.width = width;
+      this.height = height;
+    }
     const small = Math.ceil(width / this.tileSize) <= 256 && Math.ceil(height / this.tileSize) <= 256;
-    this.recordFormat = this.records === 'lit' && small ? RECORDS_LIT32 : RECORDS_PROJECTED; // of getProjectedBuffer() after this frame
+    this.recordFormat = this.records === 'lit' && small ? RECORDS_LIT32 : RECORDS_PROJECTED; // of projector.getRecordsBuffer() after this frame
+    this.projector.contents = this.recordFormat === RECORDS_LIT32 ? 'lit' : 'projected';
     const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, this.recordFormat, propertyBuffer.prelit ? 1 : 0, this.footprint];
     if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
       native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,
-        normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
+        normalsBuffer.ptr, this.numPoints, width, height, this.projector.projectedBuffer.ptr, this.output.ptr, null);
     } else {
       native.render_frame(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u,
-        propertyBuffer.ptr, normalsBuffer.ptr, this.numPoints, width, height, this.projector.getProjectedBuffer().ptr, this.output.ptr, null);
+        propertyBuffer.ptr, normalsBuffer.ptr, this.numPoints, width, height, this.projector.projectedBuffer.ptr, this.output.ptr, null);
     }
     this.binner.numTiles = Math.ceil(width / this.tileSize) * Math.ceil(height / this.tileSize);
     return this.output;
   }
-  readPixels() { return this.output.read(new Uint8Array(this.width * this.height * 4)); }
-  destroy() { this.projector.destroy(); this.sorter.destroy(); this.binner.destroy(); if (this.output) this.output.destroy(); }
+  // Settles a sync-free frame: waits for its report (pair total, overflow and order-check flags: include/splat.h) and, if
+  // the frame has to be rendered again — it outgrew the pair limit sized from the frame before it, or its tile lists
+  // failed the per-tile sort's order check — does so.  Returns the frame's pair total.  Called before results are read.
+  finish() {
+    try {
+      return native.bin_total(this.device.ctx, this.binner.handle);
+    } catch (e) {
+      if (!this.last || !/libsplat_hip -(4|8):/.test(e.message)) throw e;
+      this.render(...this.last);
+      return native.bin_total(this.device.ctx, this.binner.handle);
+    }
+  }
+  readPixels() {
+    this.finish();
+    return this.output.read(new Uint8Array(this.width * this.height * 4));
+  }
+  destroy() {
+    this.projector.destroy();
+    this.sorter.destroy();
+    this.binner.destroy();
+    if (this.output) this.output.destroy();
+  }
 }
 
 /** src/Camera.ts:3-139 with gl-matrix 3.4.4 semantics (Float32Array stores, f64 arithmetic) */
 class Camera {
   constructor() {
-    this.target = new Float32Array([0, 0, 0]); this.distance = 3.0; this.azimuth = 0.5; this.elevation = 0.5;
-    this.fov = 45; this.aspect = 1.0; this.near = 0.1; this.far = 100.0;
-    this.viewProjectionMatrix = new Float32Array(16); this.cameraPosition = new Float32Array(3); this.isDirty = true;
+    this.target = new Float32Array([0, 0, 0]);
+    this.distance = 3.0;
+    this.azimuth = 0.5;
+    this.elevation = 0.5;
+    this.fov = 45;
+    this.aspect = 1.0;
+    this.near = 0.1;
+    this.far = 100.0;
+    this.viewProjectionMatrix = new Float32Array(16);
+    this.cameraPosition = new Float32Array(3);
+    this.isDirty = true;
   }
-  setAspect(aspect) { this.aspect = aspect; this.isDirty = true; }
-  rotate(dAz, dEl) { this.azimuth += dAz; this.elevation += dEl; const m = Math.PI / 2 - 0.01; this.elevation = Math.max(-m, Math.min(m, this.elevation)); this.isDirty = true; }
-  zoom(d) { this.distance += d; this.distance = Math.max(0.5, Math.min(20.0, this.distance)); this.isDirty = true; }
+  setAspect(aspect) {
+    this.aspect = aspect;
+    this.isDirty = true;
+  }
+  rotate(dAz, dEl) {
+    this.azimuth += dAz;
+    this.elevation += dEl;
+    const m = Math.PI / 2 - 0.01;
+    this.elevation = Math.max(-m, Math.min(m, this.elevation));
+    this.isDirty = true;
+  }
+  zoom(d) {
+    this.distance += d;
+    this.distance = Math.max(0.5, Math.min(20.0, this.distance));
+    this.isDirty = true;
+  }
   pan(deltaX, deltaY) { // :61-83 with gl-matrix's vec3 semantics (every result stored in a Float32Array)
     const f32 = (x, y, z) => new Float32Array([x, y, z]);
-    const normalize = (a) => { let len = a[0] * a[0] + a[1] * a[1] + a[2] * a[2]; if (len > 0) len = 1 / Math.sqrt(len); return f32(a[0] * len, a[1] * len, a[2] * len); };
+    const normalize = (a) => {
+      let len = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+      if (len > 0) len = 1 / Math.sqrt(len);
+      return f32(a[0] * len, a[1] * len, a[2] * len);
+    };
     const cross = (a, b) => f32(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
     const position = this.getCameraPosition();
     const forward = normalize(f32(this.target[0] - position[0], this.target[1] - position[1], this.target[2] - position[2]));
     const right = normalize(cross(forward, f32(0, 1, 0)));
     const up = normalize(cross(right, forward));
     let offset = f32(0, 0, 0);
-    offset = f32(offset[0] + right[0] * deltaX, offset[1] + right[1] * deltaX, offset[2] + right[2] * deltaX); // vec3.scaleAndAdd
+    offset = f32(offset[0] + right[0] * deltaX, offset[1] + right[1] * deltaX, offset[2] + right[2] * deltaX);
+    // vec3.scaleAndAdd
     offset = f32(offset[0] + up[0] * deltaY, offset[1] + up[1] * deltaY, offset[2] + up[2] * deltaY);
     this.target = f32(this.target[0] + offset[0], this.target[1] + offset[1], this.target[2] + offset[2]);
     this.isDirty = true;
@@ -323,47 +498,107 @@ class Camera {
   }
   updateMatrices() {
     if (!this.isDirty) return;
-    const eye = this.getCameraPosition(); this.cameraPosition = eye;
+    const eye = this.getCameraPosition();
+    this.cameraPosition = eye;
     const view = new Float32Array(16), proj = new Float32Array(16);
     let z0 = eye[0] - this.target[0], z1 = eye[1] - this.target[1], z2 = eye[2] - this.target[2];
     if (Math.abs(z0) < 1e-6 && Math.abs(z1) < 1e-6 && Math.abs(z2) < 1e-6) { view[0] = view[5] = view[10] = view[15] = 1; } else {
-      let len = 1 / Math.sqrt(z0 * z0 + z1 * z1 + z2 * z2); z0 *= len; z1 *= len; z2 *= len;
-      let x0 = 1 * z2 - 0 * z1, x1 = 0 * z0 - 0 * z2, x2 = 0 * z1 - 1 * z0; // up = (0,1,0)
-      len = Math.sqrt(x0 * x0 + x1 * x1 + x2 * x2); if (!len) { x0 = x1 = x2 = 0; } else { len = 1 / len; x0 *= len; x1 *= len; x2 *= len; }
+      let len = 1 / Math.sqrt(z0 * z0 + z1 * z1 + z2 * z2);
+      z0 *= len;
+      z1 *= len;
+      z2 *= len;
+      let x0 = 1 * z2 - 0 * z1, x1 = 0 * z0 - 0 * z2, x2 = 0 * z1 - 1 * z0;
+      // up = (0,1,0)
+      len = Math.sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+      if (!len) { x0 = x1 = x2 = 0; } else { len = 1 / len; x0 *= len; x1 *= len; x2 *= len; }
       let y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
-      len = Math.sqrt(y0 * y0 + y1 * y1 + y2 * y2); if (!len) { y0 = y1 = y2 = 0; } else { len = 1 / len; y0 *= len; y1 *= len; y2 *= len; }
+      len = Math.sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+      if (!len) { y0 = y1 = y2 = 0; } else { len = 1 / len; y0 *= len; y1 *= len; y2 *= len; }
       view.set([x0, y0, z0, 0, x1, y1, z1, 0, x2, y2, z2, 0, -(x0 * eye[0] + x1 * eye[1] + x2 * eye[2]), -(y0 * eye[0] + y1 * eye[1] + y2 * eye[2]), -(z0 * eye[0] + z1 * eye[1] + z2 * eye[2]), 1]);
     }
     const f = 1 / Math.tan(((this.fov * Math.PI) / 180) / 2), nf = 1 / (this.near - this.far);
-    proj[0] = f / this.aspect; proj[5] = f; proj[11] = -1; proj[10] = (this.far + this.near) * nf; proj[14] = 2 * this.far * this.near * nf;
+    proj[0] = f / this.aspect;
+    proj[5] = f;
+    proj[11] = -1;
+    proj[10] = (this.far + this.near) * nf;
+    proj[14] = 2 * this.far * this.near * nf;
     const out = this.viewProjectionMatrix;
     for (let c = 0; c < 4; c++) for (let k = 0; k < 4; k++) out[c * 4 + k] = view[c * 4] * proj[k] + view[c * 4 + 1] * proj[4 + k] + view[c * 4 + 2] * proj[8 + k] + view[c * 4 + 3] * proj[12 + k];
     this.isDirty = false;
   }
-  getViewProjectionMatrix() { this.updateMatrices(); return this.viewProjectionMatrix; }
-  getPosition() { this.updateMatrices(); return this.cameraPosition; }
-  uniforms(width, height, time = 0) { const u = new Float32Array(22); u.set(this.getViewProjectionMatrix(), 0); u.set(this.getPosition(), 16); u[19] = time; u[20] = width; u[21] = height; return u; }
+  getViewProjectionMatrix() {
+    this.updateMatrices();
+    return this.viewProjectionMatrix;
+  }
+  getPosition() {
+    this.updateMatrices();
+    return this.cameraPosition;
+  }
+  uniforms(width, height, time = 0) {
+    const u = new Float32Array(22);
+    u.set(this.getViewProjectionMatrix(), 0);
+    u.set(this.getPosition(), 16);
+    u[19] = time;
+    u[20] = width;
+    u[21] = height;
+    return u;
+  }
 }
 
 /** src/PointManager.ts:41,220-252 — ping-pong position buffers.  The reference seeds points with unseeded Math.random on an
  * SDF surface (out of scope: upstream splat generation); here `scene` is a Float32Array of vec4 positions, or
  * {numPoints, seed} for a deterministic uniform cloud in [-1,1]^3, and reinitialize() uploads it again. */
+// src/sdf/Primitive.ts:283-290 AS WRITTEN: centre = min + max / 2 (vec3.scaleAndAdd(_, min, max, 1 / 2)), not the midpoint — kept, so
+// that seeding boxes equal the reference's; plain arrays, i.e. double precision (held to an execution of the reference's
+// statements: tests/golden/ref_host.json)
+function scaleAABB(aabb, scale) {
+  const min = [0, 0, 0];
+  const max = [0, 0, 0];
+  for (let k = 0; k < 3; k++) {
+    const center = aabb.min[k] + aabb.max[k] * (1 / 2);
+    const currentScale = aabb.max[k] - aabb.min[k];
+    min[k] = center + currentScale * (-scale / 2);
+    max[k] = center + currentScale * (scale / 2);
+  }
+  return { min, max };
+}
+
 class PointManager {
   // (device, Float32Array of vec4 positions) | (device, { numPoints, seed }) | (device, SDFScene[, seed]): the reference's constructor —
   // point count from the primitives' surface areas (src/PointManager.ts:22-39), a fresh cloud on the faces of the scene's scaled box
   // at every reinitialize() (:96-189, :220-231), drawn on the device (native.sdf_seed_positions: point i a pure function of (seed, i))
   constructor(device, scene, seed = 0) {
-    this.device = device; this.scene = null; this.seed = seed;
-    if (scene instanceof Float32Array) { this.positions = scene; this.numPoints = scene.length / 4; } else if (scene && typeof scene.getPrimitives === 'function') {
+    this.device = device;
+    this.scene = null;
+    this.seed = seed;
+    if (scene instanceof Float32Array) {
+      this.positions = scene;
+      this.numPoints = scene.length / 4;
+    } else if (scene && typeof scene.getPrimitives === 'function') {
       const prims = scene.getPrimitives();
-      if (!prims.length) throw new Error('Scene must have at least one primitive'); // :47-49
+      if (!prims.length) throw new Error('Scene must have at least one primitive');
+      // :47-49
       this.scene = scene;
-      this.numPoints = Math.max(10000, Math.min(prims.reduce((t, p) => t + Math.floor(30000 * Math.sqrt(p.getSurfaceArea())), 0), 200000)); // :22-39
+      this.numPoints = PointManager.calculatePointCount(scene); // :22-39
     } else {
-      const n = scene.numPoints; let state = (scene.seed === undefined ? 1 : scene.seed) >>> 0 || 1;
-      const next = () => { state ^= state << 13; state >>>= 0; state ^= state >>> 17; state ^= state << 5; state >>>= 0; return state / 4294967296; }; // xorshift32
+      const n = scene.numPoints;
+      let state = (scene.seed === undefined ? 1 : scene.seed) >>> 0 || 1;
+      const next = () => {
+        state ^= state << 13;
+        state >>>= 0;
+        state ^= state >>> 17;
+        state ^= state << 5;
+        state >>>= 0;
+        return state / 4294967296;
+      };
+      // xorshift32
       this.positions = new Float32Array(n * 4);
-      for (let i = 0; i < n; i++) { this.positions[i * 4] = next() * 2 - 1; this.positions[i * 4 + 1] = next() * 2 - 1; this.positions[i * 4 + 2] = next() * 2 - 1; this.positions[i * 4 + 3] = 1; }
+      for (let i = 0; i < n; i++) {
+        this.positions[i * 4] = next() * 2 - 1;
+        this.positions[i * 4 + 1] = next() * 2 - 1;
+        this.positions[i * 4 + 2] = next() * 2 - 1;
+        this.positions[i * 4 + 3] = 1;
+      }
       this.numPoints = n;
     }
     this.buffers = [device.createBuffer(this.numPoints * 16), device.createBuffer(this.numPoints * 16)];
@@ -374,13 +609,29 @@ class PointManager {
   // (centre = min + max / 2: src/sdf/Primitive.ts:283-290), in double precision, then rounded to float32
   seedingBox() {
     const mn = [Infinity, Infinity, Infinity], mx = [-Infinity, -Infinity, -Infinity];
-    for (const p of this.scene.getPrimitives()) { const [a, b] = p.getAABB(); for (let k = 0; k < 3; k++) { mn[k] = Math.min(mn[k], a[k]); mx[k] = Math.max(mx[k], b[k]); } }
-    const lo = new Float32Array(3), hi = new Float32Array(3);
-    for (let k = 0; k < 3; k++) { const c = mn[k] + mx[k] * 0.5, e = mx[k] - mn[k]; lo[k] = c + e * (-1.5 / 2); hi[k] = c + e * (1.5 / 2); }
-    return [lo, hi];
+    for (const p of this.scene.getPrimitives()) {
+      const [a, b] = p.getAABB();
+      for (let k = 0; k < 3; k++) {
+        mn[k] = Math.min(mn[k], a[k]);
+        mx[k] = Math.max(mx[k], b[k]);
+      }
+    }
+    const scaled = scaleAABB({ min: mn, max: mx }, 1.5);
+    return [Float32Array.from(scaled.min), Float32Array.from(scaled.max)];
+  }
+  // :22-39: floor(30000 sqrt(area)) per primitive, clamped to [10000, 200000]; 50000 for a scene without primitives
+  static calculatePointCount(scene) {
+    const prims = scene.getPrimitives();
+    if (prims.length === 0) return 50000;
+    const total = prims.reduce((t, p) => t + Math.floor(30000 * Math.sqrt(p.getSurfaceArea())), 0);
+    return Math.max(10000, Math.min(total, 200000));
   }
   reinitialize() { // :220-231
-    if (this.scene) { const [lo, hi] = this.seedingBox(); native.sdf_seed_positions(this.device.ctx, lo, hi, this.numPoints, this.seed++, this.buffers[this.current].ptr); return; }
+    if (this.scene) {
+      const [lo, hi] = this.seedingBox();
+      native.sdf_seed_positions(this.device.ctx, lo, hi, this.numPoints, this.seed++, this.buffers[this.current].ptr);
+      return;
+    }
     this.buffers[this.current].write(this.positions);
   }
   getCurrentPositionBuffer() { return this.buffers[this.current]; }     // :233-235
@@ -398,71 +649,273 @@ const SDF = { sphere: 0, box: 1, torus: 2, capsule: 3, union: 16, intersection: 
 let nextPrimId = 0, nextSminId = 0;
 // a primitive's box (src/sdf/Primitive.ts: getAABB): position -/+ extent in double precision, rounded to float32 like the reference's vec3
 const aabb = (p, e) => [Float32Array.from([p[0] - e[0], p[1] - e[1], p[2] - e[2]]), Float32Array.from([p[0] + e[0], p[1] + e[1], p[2] + e[2]])];
-class Primitive { constructor(id, position) { this.id = id || `prim_${nextPrimId++}`; this.position = Float32Array.from(position || [0, 0, 0]); } }
+class Primitive {
+  constructor(id, position) {
+    this.id = id || `prim_${nextPrimId++}`;
+    this.position = Float32Array.from(position || [0, 0, 0]);
+  }
+}
 class Sphere extends Primitive {
-  constructor(p = {}) { super(p.id, p.position); this.radius = p.radius === undefined ? 0.5 : p.radius; }
-  getType() { return 'sphere'; } getParamNames() { return [`${this.id}_center`, `${this.id}_radius`]; } getParamValues() { return [...this.position, this.radius]; }
-  getSurfaceArea() { return 4 * Math.PI * this.radius * this.radius; } instr() { return [SDF.sphere, ...this.position, this.radius]; }
+  constructor(p = {}) {
+    super(p.id, p.position);
+    this.radius = p.radius === undefined ? 0.5 : p.radius;
+  }
+  getType() { return 'sphere'; }
+  getParamNames() { return [`${this.id}_center`, `${this.id}_radius`]; }
+  getParamValues() { return [...this.position, this.radius]; }
+  getSurfaceArea() { return 4 * Math.PI * this.radius * this.radius; }
+  instr() { return [SDF.sphere, ...this.position, this.radius]; }
   getAABB() { return aabb(this.position, [this.radius, this.radius, this.radius]); }
 }
 class Box extends Primitive {
-  constructor(p = {}) { super(p.id, p.position); this.size = Float32Array.from(p.size || [0.5, 0.5, 0.5]); }
-  getType() { return 'box'; } getParamNames() { return [`${this.id}_center`, `${this.id}_size`]; } getParamValues() { return [...this.position, 0, ...this.size, 0]; }
-  getSurfaceArea() { const w = this.size[0] * 2, h = this.size[1] * 2, d = this.size[2] * 2; return 2 * (w * h + w * d + h * d); } instr() { return [SDF.box, ...this.position, ...this.size]; }
+  constructor(p = {}) {
+    super(p.id, p.position);
+    this.size = Float32Array.from(p.size || [0.5, 0.5, 0.5]);
+  }
+  getType() { return 'box'; }
+  getParamNames() { return [`${this.id}_center`, `${this.id}_size`]; }
+  getParamValues() { return [...this.position, 0, ...this.size, 0]; }
+  getSurfaceArea() {
+    const w = this.size[0] * 2, h = this.size[1] * 2, d = this.size[2] * 2;
+    return 2 * (w * h + w * d + h * d);
+  }
+  instr() { return [SDF.box, ...this.position, ...this.size]; }
   getAABB() { return aabb(this.position, this.size); }
 }
 class Torus extends Primitive {
-  constructor(p = {}) { super(p.id, p.position); this.majorRadius = p.majorRadius === undefined ? 0.5 : p.majorRadius; this.minorRadius = p.minorRadius === undefined ? 0.2 : p.minorRadius; }
-  getType() { return 'torus'; } getParamNames() { return [`${this.id}_center`, `${this.id}_radii`]; } getParamValues() { return [...this.position, 0, this.majorRadius, this.minorRadius, 0, 0]; }
-  getSurfaceArea() { return 4 * Math.PI * Math.PI * this.majorRadius * this.minorRadius; } instr() { return [SDF.torus, ...this.position, this.majorRadius, this.minorRadius]; }
+  constructor(p = {}) {
+    super(p.id, p.position);
+    this.majorRadius = p.majorRadius === undefined ? 0.5 : p.majorRadius;
+    this.minorRadius = p.minorRadius === undefined ? 0.2 : p.minorRadius;
+  }
+  getType() { return 'torus'; }
+  getParamNames() { return [`${this.id}_center`, `${this.id}_radii`]; }
+  getParamValues() { return [...this.position, 0, this.majorRadius, this.minorRadius, 0, 0]; }
+  getSurfaceArea() { return 4 * Math.PI * Math.PI * this.majorRadius * this.minorRadius; }
+  instr() { return [SDF.torus, ...this.position, this.majorRadius, this.minorRadius]; }
   getAABB() { return aabb(this.position, [this.majorRadius + this.minorRadius, this.minorRadius, this.majorRadius + this.minorRadius]); }
 }
 class Capsule extends Primitive {
-  constructor(p = {}) { super(p.id, p.position); this.height = p.height === undefined ? 1.0 : p.height; this.radius = p.radius === undefined ? 0.3 : p.radius; }
-  getType() { return 'capsule'; } getParamNames() { return [`${this.id}_center`, `${this.id}_params`]; } getParamValues() { return [...this.position, 0, this.height, this.radius, 0, 0]; }
-  getSurfaceArea() { return 2 * Math.PI * this.radius * this.height + 4 * Math.PI * this.radius * this.radius; } instr() { return [SDF.capsule, ...this.position, this.height, this.radius]; }
+  constructor(p = {}) {
+    super(p.id, p.position);
+    this.height = p.height === undefined ? 1.0 : p.height;
+    this.radius = p.radius === undefined ? 0.3 : p.radius;
+  }
+  getType() { return 'capsule'; }
+  getParamNames() { return [`${this.id}_center`, `${this.id}_params`]; }
+  getParamValues() { return [...this.position, 0, this.height, this.radius, 0, 0]; }
+  getSurfaceArea() { return 2 * Math.PI * this.radius * this.height + 4 * Math.PI * this.radius * this.radius; }
+  instr() { return [SDF.capsule, ...this.position, this.height, this.radius]; }
   getAABB() { return aabb(this.position, [this.radius, this.height / 2 + this.radius, this.radius]); }
 }
-class Operation { constructor(type, params = []) { this.type = type; this.params = params; } getType() { return this.type; } getParamNames() { return []; } getParamValues() { return this.params; } }
-class SmoothUnion extends Operation { constructor(k = 0.1) { super('smooth_union', [k]); this.k = k; this.id = `smin_${nextSminId++}`; } getParamNames() { return [`${this.id}_k`]; } getParamValues() { return [this.k]; } }
+class Operation {
+  constructor(type, params = []) {
+    this.type = type;
+    this.params = params;
+  }
+  getType() { return this.type; }
+  getParamNames() { return []; }
+  getParamValues() { return this.params; }
+}
+class SmoothUnion extends Operation {
+  constructor(k = 0.1) {
+    super('smooth_union', [k]);
+    this.k = k;
+    this.id = `smin_${nextSminId++}`;
+  }
+  getParamNames() { return [`${this.id}_k`]; }
+  getParamValues() { return [this.k]; }
+}
 const primitive = (p) => (p && p.type === 'primitive') || (p && p.type === 'operation') ? p : { type: 'primitive', primitive: p };
 const binary = (op, a, b) => ({ type: 'operation', operation: op, children: [primitive(a), primitive(b)] });
 const union = (a, b) => binary(new Operation('union'), a, b), intersection = (a, b) => binary(new Operation('intersection'), a, b);
 const subtraction = (a, b) => binary(new Operation('subtraction'), a, b), smoothUnion = (k, a, b) => binary(new SmoothUnion(k), a, b);
 class SDFScene { // src/sdf/Scene.ts:72-152
-  constructor() { this.root = null; this.primitiveMap = new Map(); }
-  setRoot(node) { this.root = primitive(node); this.primitiveMap.clear(); const walk = (n) => { if (n.type === 'primitive') this.primitiveMap.set(n.primitive.id, n.primitive); else n.children.forEach(walk); }; walk(this.root); }
-  get(id) { return this.primitiveMap.get(id); } getPrimitives() { return Array.from(this.primitiveMap.values()); } getRoot() { return this.root; }
-  getOperations() { const ops = []; const walk = (n) => { if (n.type === 'operation') { ops.push(n.operation); n.children.forEach(walk); } }; if (this.root) walk(this.root); return ops; }
-  getStructureHash() { const walk = (n) => (n.type === 'primitive' ? `P:${n.primitive.getType()}:${n.primitive.id}` : `O:${n.operation.getType()}:(${n.children.map(walk).join(',')})`); return this.root ? walk(this.root) : ''; }
-  program() { // Float32Array, 8 floats per instruction: [op, a0..a6]
-    const rows = []; const walk = (n) => { if (n.type === 'primitive') rows.push(n.primitive.instr()); else { n.children.forEach(walk); rows.push([SDF[n.operation.getType()], ...n.operation.getParamValues()]); } };
+  constructor() {
+    this.root = null;
+    this.primitiveMap = new Map();
+  }
+  setRoot(node) {
+    this.root = primitive(node);
+    this.primitiveMap.clear();
+    const walk = (n) => {
+      if (n.type === 'primitive') this.primitiveMap.set(n.primitive.id, n.primitive);
+      else n.children.forEach(walk);
+    };
+    walk(this.root);
+  }
+  get(id) { return this.primitiveMap.get(id); }
+  getPrimitives() { return Array.from(this.primitiveMap.values()); }
+  getRoot() { return this.root; }
+  getOperations() {
+    const ops = [];
+    const walk = (n) => {
+      if (n.type === 'operation') {
+        ops.push(n.operation);
+        n.children.forEach(walk);
+      }
+    };
     if (this.root) walk(this.root);
-    const out = new Float32Array(rows.length * 8); rows.forEach((r, k) => out.set(r, k * 8)); return out;
+    return ops;
+  }
+  getStructureHash() {
+    const walk = (n) => (n.type === 'primitive' ? `P:${n.primitive.getType()}:${n.primitive.id}` : `O:${n.operation.getType()}:(${n.children.map(walk).join(',')})`);
+    return this.root ? walk(this.root) : '';
+  }
+  program() { // Float32Array, 8 floats per instruction: [op, a0..a6]
+    const rows = [];
+    const walk = (n) => {
+      if (n.type === 'primitive') rows.push(n.primitive.instr());
+      else {
+        n.children.forEach(walk);
+        rows.push([SDF[n.operation.getType()], ...n.operation.getParamValues()]);
+      }
+    };
+    if (this.root) walk(this.root);
+    const out = new Float32Array(rows.length * 8);
+    rows.forEach((r, k) => out.set(r, k * 8));
+    return out;
   }
 }
 class SceneStage {
-  constructor(device, scene, numPoints) { this.device = device; this.scene = scene; this.numPoints = numPoints; this.currentStructureHash = scene.getStructureHash(); this.updateSceneParameters(); }
+  constructor(device, scene, numPoints) {
+    this.device = device;
+    this.scene = scene;
+    this.numPoints = numPoints;
+    this.currentStructureHash = scene.getStructureHash();
+    this.updateSceneParameters();
+  }
   updateSceneParameters() { this.program = this.scene.program(); }
-  rebuildIfNeeded() { const h = this.scene.getStructureHash(); if (h !== this.currentStructureHash) { this.currentStructureHash = h; this.updateSceneParameters(); } }
+  rebuildIfNeeded() {
+    const h = this.scene.getStructureHash();
+    if (h !== this.currentStructureHash) {
+      this.currentStructureHash = h;
+      this.updateSceneParameters();
+    }
+  }
   getScene() { return this.scene; }
 }
 class GradientSampler extends SceneStage { // src/GradientSampler.ts
-  constructor(device, scene, numPoints) { super(device, scene, numPoints); this.gradientBuffer = device.createBuffer(numPoints * 16); }
+  constructor(device, scene, numPoints) {
+    super(device, scene, numPoints);
+    this.gradientBuffer = device.createBuffer(numPoints * 16);
+  }
   evaluateGradients(commandEncoder, uniformBuffer, positionBuffer) { native.sdf_gradients(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.gradientBuffer.ptr); }
-  getGradientBuffer() { return this.gradientBuffer; } destroy() { this.gradientBuffer.destroy(); }
+  getGradientBuffer() { return this.gradientBuffer; }
+  destroy() { this.gradientBuffer.destroy(); }
 }
 class PositionUpdater { // src/PositionUpdater.ts
-  constructor(device, shaderCode, numPoints) { this.device = device; this.numPoints = numPoints; }
+  constructor(device, shaderCode, numPoints) {
+    this.device = device;
+    this.numPoints = numPoints;
+  }
   updatePositions(commandEncoder, uniformBuffer, currentPositionBuffer, gradientBuffer, nextPositionBuffer) { native.sdf_update_positions(this.device.ctx, currentPositionBuffer.ptr, gradientBuffer.ptr, this.numPoints, nextPositionBuffer.ptr); }
 }
 class CurvatureSampler extends SceneStage { // src/CurvatureSampler.ts
-  constructor(device, scene, numPoints) { super(device, scene, numPoints); this.scaleFactorsBuffer = device.createBuffer(numPoints * 4); this.curvatureBuffer = null; }
+  constructor(device, scene, numPoints) {
+    super(device, scene, numPoints);
+    this.scaleFactorsBuffer = device.createBuffer(numPoints * 4);
+    this.curvatureBuffer = null;
+  }
   computeScaleFactors(commandEncoder, positionBuffer) { native.sdf_scale_factors(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.scaleFactorsBuffer.ptr); }
   getScaleFactorsBuffer() { return this.scaleFactorsBuffer; }
   // vec4(normal, scaleFactor): the curvatureData buffer SplatPropertyManager.updateFromCurvature binds (the reference's samplers write its halves apart)
-  getCurvatureBuffer(gradientBuffer) { if (!this.curvatureBuffer) this.curvatureBuffer = this.device.createBuffer(this.numPoints * 16); native.sdf_curvature(this.device.ctx, gradientBuffer.ptr, this.scaleFactorsBuffer.ptr, this.numPoints, this.curvatureBuffer.ptr); return this.curvatureBuffer; }
-  destroy() { this.scaleFactorsBuffer.destroy(); if (this.curvatureBuffer) this.curvatureBuffer.destroy(); }
+  getCurvatureBuffer(gradientBuffer) {
+    if (!this.curvatureBuffer) this.curvatureBuffer = this.device.createBuffer(this.numPoints * 16);
+    native.sdf_curvature(this.device.ctx, gradientBuffer.ptr, this.scaleFactorsBuffer.ptr, this.numPoints, this.curvatureBuffer.ptr);
+    return this.curvatureBuffer;
+  }
+  destroy() {
+    this.scaleFactorsBuffer.destroy();
+    if (this.curvatureBuffer) this.curvatureBuffer.destroy();
+  }
+}
+
+/** src/OrbitCameraController.ts:3-75 — the same speeds and the same mapping of mouse buttons and the wheel onto
+ * Camera.rotate / pan / zoom.  `canvas` is anything with addEventListener(type, handler) (a DOM canvas, a Node
+ * EventEmitter adapter) or null: without one, feed the handlers synthetic events {clientX, clientY, button, deltaY}. */
+class OrbitCameraController {
+  constructor(camera, canvas = null) {
+    this.camera = camera;
+    this.canvas = canvas;
+    this.isDragging = false; // :7
+    this.dragButton = -1; // :8
+    this.lastMouseX = 0; // :9
+    this.lastMouseY = 0; // :10
+    this.rotationSpeed = 0.005; // :12
+    this.panSpeed = 0.002; // :13
+    this.zoomSpeed = 0.001; // :14
+    this.setupEventListeners();
+  }
+  setupEventListeners() { // :23-33
+    if (!this.canvas || typeof this.canvas.addEventListener !== 'function') return;
+    this.canvas.addEventListener('mousedown', this.onMouseDown.bind(this));
+    this.canvas.addEventListener('mousemove', this.onMouseMove.bind(this));
+    this.canvas.addEventListener('mouseup', this.onMouseUp.bind(this));
+    this.canvas.addEventListener('wheel', this.onWheel.bind(this), { passive: false });
+    this.canvas.addEventListener('contextmenu', (e) => e.preventDefault());
+  }
+  onMouseDown(event) { // :35-40
+    this.isDragging = true;
+    this.dragButton = event.button;
+    this.lastMouseX = event.clientX;
+    this.lastMouseY = event.clientY;
+  }
+  onMouseMove(event) { // :42-58
+    if (!this.isDragging) return;
+    const dx = event.clientX - this.lastMouseX;
+    const dy = event.clientY - this.lastMouseY;
+    if (this.dragButton === 0) { // left button: rotate
+      this.camera.rotate(dx * this.rotationSpeed, -dy * this.rotationSpeed);
+    } else if (this.dragButton === 1 || this.dragButton === 2) { // middle or right button: pan
+      this.camera.pan(-dx * this.panSpeed, dy * this.panSpeed);
+    }
+    this.lastMouseX = event.clientX;
+    this.lastMouseY = event.clientY;
+  }
+  onMouseUp(_event) { // :60-63
+    this.isDragging = false;
+    this.dragButton = -1;
+  }
+  onWheel(event) { // :65-70
+    if (event.preventDefault) event.preventDefault();
+    const delta = event.deltaY * this.zoomSpeed;
+    this.camera.zoom(delta);
+  }
+  destroy() {} // :72-74
+}
+
+/** The render loop of src/main.ts:110-193 for the tile-raster path, without a browser: per frame the camera's uniform
+ * block (VP, eye, time, W, H — :126-144) and one Renderer.render call (:183-190).  Frames are enqueued back to back
+ * (sync-free after the first); a frame's pixels are read only when asked for.  splat_renderer_amd/frameloop.py is the
+ * same loop in Python: the two give the same images byte for byte (tests/test_napi.py). */
+class FrameLoop {
+  constructor(device, numPoints, width, height, tileSize = 16, camera = null, rendererOptions = {}) {
+    this.device = device;
+    this.width = width;
+    this.height = height;
+    this.camera = camera || new Camera();
+    this.camera.setAspect(width / height); // resizeCanvas, main.ts:97-101
+    this.renderer = new Renderer(device, null, 'rgba8unorm', numPoints, tileSize, rendererOptions);
+    this.frame = 0;
+  }
+  // one frame with the camera as it stands; returns the output buffer (pixels stay on the device)
+  render(propertyBuffer, normalsBuffer, time) {
+    const t = time === undefined ? this.frame / 60.0 : time;
+    const out = this.renderer.render(this.camera.uniforms(this.width, this.height, t), propertyBuffer, normalsBuffer, null, this.width, this.height);
+    this.frame += 1;
+    return out;
+  }
+  readPixels() { return this.renderer.readPixels(); }
+  // `frames` frames of a full orbit (Camera.rotate by 2 pi / frames after each); onFrame(k, rgba8) gets every frame's pixels
+  turntable(propertyBuffer, normalsBuffer, frames, onFrame) {
+    for (let k = 0; k < frames; k++) {
+      this.render(propertyBuffer, normalsBuffer);
+      if (onFrame) onFrame(k, this.readPixels());
+      this.camera.rotate((2.0 * Math.PI) / frames, 0.0);
+    }
+  }
+  destroy() { this.renderer.destroy(); }
 }
 
 /** The multi-GPU frame's exchange (no reference counterpart: the reference is single-device): one process per GPU, an
@@ -470,9 +923,17 @@ class CurvatureSampler extends SceneStage { // src/CurvatureSampler.ts
  * any channel (a file, a socket, an environment variable); every rank then constructs Comm with the same bytes. */
 class Comm {
   static uniqueId() { return new Uint8Array(native.comm_unique_id()); }
-  constructor(device, rank, world, idBytes) { this.device = device; this.rank = rank; this.world = world; this.handle = native.comm_init(device.ctx, rank, world, idBytes); }
+  constructor(device, rank, world, idBytes) {
+    this.device = device;
+    this.rank = rank;
+    this.world = world;
+    this.handle = native.comm_init(device.ctx, rank, world, idBytes);
+  }
   allGather(shardBuffer, gatheredBuffer, bytesPerRank) { native.allgather_records(this.device.ctx, this.handle, shardBuffer.ptr, gatheredBuffer.ptr, bytesPerRank); }
-  destroy() { if (this.handle) native.comm_destroy(this.handle); this.handle = null; }
+  destroy() {
+    if (this.handle) native.comm_destroy(this.handle);
+    this.handle = null;
+  }
 }
 
 /** One rank of north_star's multi-GPU frame (SURVEY §8e): project my 1/world of the splats into 16-byte exchange records
@@ -481,15 +942,27 @@ class Comm {
  * Everything is enqueued on the device's stream: no host synchronisation inside a frame. */
 class BandRenderer {
   constructor(device, comm, numPoints, width, height, tileSize = 16) {
-    this.device = device; this.comm = comm; this.numPoints = numPoints; this.width = width; this.height = height; this.tileSize = tileSize;
+    this.device = device;
+    this.comm = comm;
+    this.numPoints = numPoints;
+    this.width = width;
+    this.height = height;
+    this.tileSize = tileSize;
     const world = comm ? comm.world : 1, rank = comm ? comm.rank : 0;
-    this.per = Math.ceil(numPoints / world); this.first = Math.min(rank * this.per, numPoints); this.count = Math.min(this.per, numPoints - this.first);
+    this.per = Math.ceil(numPoints / world);
+    this.first = Math.min(rank * this.per, numPoints);
+    this.count = Math.min(this.per, numPoints - this.first);
     const nty = Math.ceil(height / tileSize);
-    this.row0 = Math.floor(nty * rank / world); this.row1 = Math.floor(nty * (rank + 1) / world);
-    this.sorter = new RadixSorter(device, this.per * world); this.binner = new GPUTileBinner(device, tileSize);
-    this.shard = device.createBuffer(this.per * 16); this.shard.write(new Float32Array(this.per * 4).fill(NaN)); // padding records bin nowhere
+    this.row0 = Math.floor(nty * rank / world);
+    this.row1 = Math.floor(nty * (rank + 1) / world);
+    this.sorter = new RadixSorter(device, this.per * world);
+    this.binner = new GPUTileBinner(device, tileSize);
+    this.shard = device.createBuffer(this.per * 16);
+    this.shard.write(new Float32Array(this.per * 4).fill(NaN));
+    // padding records bin nowhere
     this.gathered = world > 1 ? device.createBuffer(this.per * world * 16) : this.shard;
-    this.output = device.createBuffer(width * height * 4); this.output.zero();
+    this.output = device.createBuffer(width * height * 4);
+    this.output.zero();
   }
   render(uniformData, propertyBuffer, normalsBuffer) {
     const u = uniformFloats(uniformData), d = this.device, world = this.comm ? this.comm.world : 1;
@@ -502,11 +975,20 @@ class BandRenderer {
   }
   settle() { return native.band_settle(this.device.ctx, this.sorter.handle, this.binner.handle); }
   pixelRows() { return [this.row0 * this.tileSize, Math.min(this.row1 * this.tileSize, this.height)]; }
-  readPixels() { this.settle(); return this.output.read(new Uint8Array(this.width * this.height * 4)); }
-  destroy() { this.sorter.destroy(); this.binner.destroy(); this.shard.destroy(); if (this.gathered !== this.shard) this.gathered.destroy(); this.output.destroy(); }
+  readPixels() {
+    this.settle();
+    return this.output.read(new Uint8Array(this.width * this.height * 4));
+  }
+  destroy() {
+    this.sorter.destroy();
+    this.binner.destroy();
+    this.shard.destroy();
+    if (this.gathered !== this.shard) this.gathered.destroy();
+    this.output.destroy();
+  }
 }
 
-module.exports = { native, Device, Buffer: Buffer_, Camera, PointManager, Comm, BandRenderer, SDFScene, Sphere, Box, Torus, Capsule, SmoothUnion,
+module.exports = { native, Device, Buffer: Buffer_, Camera, OrbitCameraController, FrameLoop, PointManager, scaleAABB, Comm, BandRenderer, SDFScene, Sphere, Box, Torus, Capsule, SmoothUnion,
   union, intersection, subtraction, smoothUnion, GradientSampler, PositionUpdater, CurvatureSampler, SplatPropertyManager, SplatProjector, DepthKeyExtractor, RadixSorter, PrefixSumScanner,
   GPUTileBinner, PerTileSorter, ComputeShaderRenderer, TileRenderer, SequentialRenderer, Renderer, MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL,
   FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC, RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_LIT32 };

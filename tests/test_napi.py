@@ -194,3 +194,92 @@ def test_js_sdf_generation_matches_oracle(tmp_path):
     cur = O.sdf_curvature(grad, O.sdf_scale_factors(prog, pos))
     for k, want in enumerate((pos, grad, cur)):
         assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), k
+
+
+@pytest.mark.gpu
+def test_js_frame_loop_matches_the_python_one(tmp_path):
+    """FrameLoop + OrbitCameraController in the reference's own language (napi/index.js; the event
+    mapping of src/OrbitCameraController.ts:18-70, the loop of src/main.ts:110-193).  Four frames of an orbit driven from
+    Node — rotate, pan, wheel, left-button drag — against the same moves through splat_renderer_amd/frameloop.py: the
+    same uniform blocks bit for bit, the same pair totals, the same images byte for byte."""
+    ensure_built()
+    import splat_renderer_amd as sr
+    n, w, h = 12000, 320, 208
+    props, normals, _ = make_case(n, w, h, 61, 1.5)
+    props.tofile(tmp_path / "props.f32")
+    normals.tofile(tmp_path / "normals.f32")
+    r = subprocess.run([NODE, "frame_loop.js", str(tmp_path / "props.f32"), str(tmp_path / "normals.f32"), str(n), str(w), str(h),
+                        str(tmp_path / "js_")], cwd=NAPI, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["refused"] is True and info["recordFormat"] == 3
+    dev = sr.Device(0)
+    try:
+        pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
+        loop = sr.FrameLoop(dev, n, w, h)
+        ctl = sr.OrbitCameraController(loop.camera)
+        moves = [lambda: loop.camera.rotate(2 * np.pi / 4, 0.0), lambda: loop.camera.pan(0.2, -0.1),
+                 lambda: ctl.onWheel(sr.MouseEvent(deltaY=400.0)),
+                 lambda: (ctl.onMouseDown(sr.MouseEvent(10, 10, button=0)), ctl.onMouseMove(sr.MouseEvent(70, 40)), ctl.onMouseUp())]
+        last = None
+        for k, move in enumerate(moves):
+            u = loop.camera.uniforms(w, h, time=k / 60.0)
+            assert np.array_equal(np.array(info["uniforms"][k], np.float32).view(np.uint32), u.view(np.uint32)), k
+            loop.render(pbuf, nbuf)
+            want = loop.readPixels()
+            assert loop.renderer.finish() == info["pairs"][k], k
+            got = np.fromfile(tmp_path / f"js_{k}.rgba8", np.uint8).reshape(h, w, 4)
+            assert np.array_equal(got, want), k
+            last = want
+            move()
+        assert np.array_equal(np.fromfile(tmp_path / "js_sync_free_last.rgba8", np.uint8).reshape(h, w, 4), last)
+        for o in (loop, pbuf, nbuf):
+            o.destroy()
+    finally:
+        dev.destroy()
+
+
+def test_js_host_formulas_equal_the_reference_own_code():
+    """napi/index.js against tests/golden/ref_host.json (the reference's own statements executed under Node): surface areas,
+    scaleAABB, PointManager's point count, SplatPropertyManager's defaults, and the order of SDFScene.program()."""
+    ensure_built()
+    here = os.path.join(ROOT, "tests", "golden", "ref_host.json")
+    script = r"""
+const sr = require('./index.js');
+const ref = JSON.parse(require('fs').readFileSync(process.argv[1], 'utf8'));
+const inp = ref.inputs, out = ref.outputs;
+const prim = (d) => new ({ sphere: sr.Sphere, box: sr.Box, torus: sr.Torus, capsule: sr.Capsule }[d.prim])(d);
+const node = (d) => {
+  if (d.prim) return prim(d);
+  const a = node(d.children[0]), b = node(d.children[1]);
+  if (d.op === 'smooth_union') return sr.smoothUnion(d.k, a, b);
+  return { union: sr.union, intersection: sr.intersection, subtraction: sr.subtraction }[d.op](a, b);
+};
+const bad = [];
+inp.prims.forEach((d, i) => { if (prim(d).getSurfaceArea() !== out.areas[i]) bad.push(['area', i]); });
+inp.boxes.forEach((c, i) => {
+  const r = sr.scaleAABB({ min: c.min, max: c.max }, c.scale);
+  if (JSON.stringify([r.min, r.max]) !== JSON.stringify([out.scaleAABB[i].min, out.scaleAABB[i].max])) bad.push(['scaleAABB', i]);
+});
+const ops = {};
+for (const name of Object.keys(inp.scenes)) {
+  const sc = new sr.SDFScene();
+  sc.setRoot(node(inp.scenes[name]));
+  if (sr.PointManager.calculatePointCount(sc) !== out.scenes[name].pointCount) bad.push(['pointCount', name]);
+  const prog = sc.program();
+  ops[name] = [];
+  for (let k = 0; k < prog.length; k += 8) ops[name].push(prog[k]);
+}
+if (sr.PointManager.calculatePointCount(new sr.SDFScene()) !== out.pointCountEmptyScene) bad.push(['pointCount', 'empty']);
+if (JSON.stringify(Array.from(sr.SplatPropertyManager.defaultProperties(3))) !== JSON.stringify(Array.from(Float32Array.from(out.defaults)))) bad.push(['defaults']);
+console.log(JSON.stringify({ bad, ops }));
+"""
+    r = subprocess.run([NODE, "-e", script, here], cwd=NAPI, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["bad"] == [], d["bad"]
+    from tests.test_sdf_cpu import _emitted, _ref_host
+    code = {"sphere": 0, "box": 1, "torus": 2, "capsule": 3, "union": 16, "intersection": 17, "subtraction": 18, "smooth_union": 19}
+    ref = _ref_host()
+    for name, ops in d["ops"].items():
+        assert ops == [code[k] for k, _ in _emitted(ref["outputs"]["scenes"][name]["wgsl"])], name

@@ -111,3 +111,80 @@ def test_oracle_seeding_is_a_pure_function_of_seed_and_index():
     free = b[(b[:, 0] == mn[0])][:, 1:3]  # the -x face: y and z uniform over the box
     lo, hi = np.array([mn[1], mn[2]]), np.array([mx[1], mx[2]])
     assert np.abs(free.mean(axis=0) - (lo + hi) / 2).max() < 0.05 * (hi - lo).max()
+
+
+# ---- pinned to an execution of the reference's own statements (tests/golden/ref_host.json, made by
+# tests/golden/make_ref_host_fixtures.py: getSurfaceArea, calculatePointCount, scaleAABB, initializeDefaults, the scene walk
+# of WGSLCodeGenerator.generateSceneSDF — extracted as text and run under Node) -------------------------------------------
+def _ref_host():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_host.json")) as f:
+        return json.load(f)
+
+
+def _prim_from(d):
+    kw = {k: v for k, v in d.items() if k not in ("prim",)}
+    return {"sphere": sdf.Sphere, "box": sdf.Box, "torus": sdf.Torus, "capsule": sdf.Capsule}[d["prim"]](**kw)
+
+
+def _node_from(d):
+    if "prim" in d:
+        return _prim_from(d)
+    a, b = (_node_from(c) for c in d["children"])
+    if d["op"] == "smooth_union":
+        return sdf.smoothUnion(d["k"], a, b)
+    return {"union": sdf.union, "intersection": sdf.intersection, "subtraction": sdf.subtraction}[d["op"]](a, b)
+
+
+def _emitted(wgsl):
+    """[(kind, id or None)] of the `let result_k = ...` lines, in emission order."""
+    import re
+    out = []
+    for ln in wgsl:
+        m = re.match(r"\s*let result_\d+ = (sdg|op)(\w+)\((.*)\);", ln)
+        if not m:
+            continue
+        kind = {"Sphere": "sphere", "Box": "box", "Torus": "torus", "Capsule": "capsule", "Union": "union", "Intersection": "intersection",
+                "Subtraction": "subtraction", "SmoothUnion": "smooth_union"}[m.group(2)]
+        pid = re.search(r"sceneParams\.(\w+)_center", m.group(3))
+        out.append((kind, pid.group(1) if (pid and m.group(1) == "sdg") else None))
+    return out
+
+
+def test_host_side_formulas_equal_the_reference_own_code():
+    ref = _ref_host()
+    inp, out = ref["inputs"], ref["outputs"]
+    # the four getSurfaceArea() bodies (src/sdf/Primitive.ts), bit for bit (doubles)
+    for d, want in zip(inp["prims"], out["areas"]):
+        assert _prim_from(d).getSurfaceArea() == want, d
+    # scaleAABB as written (centre = min + max / 2)
+    for c, want in zip(inp["boxes"], out["scaleAABB"]):
+        mn, mx = sdf.scaleAABB((np.array(c["min"], np.float64), np.array(c["max"], np.float64)), c["scale"])
+        assert mn.tolist() == want["min"] and mx.tolist() == want["max"], c
+    # PointManager.calculatePointCount incl. both clamps and the empty scene
+    for name, d in inp["scenes"].items():
+        sc = sr.SDFScene()
+        sc.setRoot(_node_from(d))
+        assert sdf.point_count(sc) == out["scenes"][name]["pointCount"], name
+    assert sdf.point_count(sr.SDFScene()) == out["pointCountEmptyScene"] == 50000
+    # SplatPropertyManager.initializeDefaults
+    from splat_renderer_amd.host import default_properties
+    assert np.array_equal(default_properties(3).reshape(-1), np.array(out["defaults"], np.float32))
+
+
+def test_scene_program_order_equals_the_reference_code_generator():
+    """The postfix program the kernels evaluate lists the nodes in the order WGSLCodeGenerator.generateSceneSDF's traverse()
+    emits its `let result_k` lines (src/sdf/CodeGenerator.ts:289-351, executed under Node for the six test scenes)."""
+    from splat_renderer_amd import _lib
+    ref = _ref_host()
+    code = {"sphere": _lib.SDF_SPHERE, "box": _lib.SDF_BOX, "torus": _lib.SDF_TORUS, "capsule": _lib.SDF_CAPSULE, "union": _lib.SDF_UNION,
+            "intersection": _lib.SDF_INTERSECTION, "subtraction": _lib.SDF_SUBTRACTION, "smooth_union": _lib.SDF_SMOOTH_UNION}
+    for name, d in ref["inputs"]["scenes"].items():
+        sc = sr.SDFScene()
+        sc.setRoot(_node_from(d))
+        want = _emitted(ref["outputs"]["scenes"][name]["wgsl"])
+        assert [op for op, _ in sc.program()] == [code[k] for k, _ in want], name
+        # the primitives appear in the walk in the order getPrimitives() lists them (Scene.ts: insertion order of the same walk)
+        assert [p.id for p in sc.getPrimitives()] == [i for _, i in want if i is not None], name
+        assert len(want) >= 1 and ref["outputs"]["scenes"][name]["wgsl"][-2].strip() == f"return result_{len(want) - 1};"
