@@ -40,6 +40,7 @@ struct splat_ctx {
     uint64_t px_key = 0;
     uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps ...
     uint32_t inject_order_position = 0; // ... at entries position, position + 1
+    int tile_sort_digits = 0; // k_tile_sort's in-LDS passes: 0 = not resolved yet, 8 = byte passes (default), 12 = wide passes (SPLAT_TILE_SORT_DIGITS=12)
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars

@@ -61,6 +61,45 @@ struct TileSortShared {
     uint32_t kmin, kmax;
 };
 
+// The WIDE in-LDS path (round 3): digits of up to 12 bits — TWO passes for the 22..24-bit key ranges of the bench sizes'
+// tiles instead of three.  Every wave ranks into its own table of 4096 16-bit counters, two per word (counts and positions
+// of a list that fits LDS stay below 65536, so a half never carries into its neighbour).
+constexpr uint32_t TSW_MAX_BITS = 12, TSW_WORDS = (1u << TSW_MAX_BITS) / 2;
+constexpr uint32_t TSW_LDS_ELEMS = 5888; // 46 KiB + 32 KiB of counters: two workgroups in a CU's 160 KiB
+struct TileSortWide {
+    uint32_t h[TS_WAVES][TSW_WORDS]; // per wave, as the byte passes' tables
+    uint32_t wave_sums[TS_WAVES];
+    uint32_t kmin, kmax;
+};
+union TileSortLds {
+    TileSortShared sh;
+    TileSortWide wd;
+};
+
+// rank of this lane's element among the elements of the same digit seen so far by this wave (wave_rank above, for the
+// packed 16-bit counters and digits of `bits` bits)
+template <bool RANK_ATOMIC>
+__device__ __forceinline__ uint32_t wide_take(uint32_t *h, uint32_t d, uint32_t bits) {
+    const uint32_t sh16 = (d & 1u) << 4;
+    if (RANK_ATOMIC) return (atomicAdd(&h[d >> 1], 1u << sh16) >> sh16) & 0xffffu;
+    const uint64_t active = __ballot(true); // callers take under `if (p < n)`: peers are active lanes only
+    uint32_t plo = (uint32_t)active, phi = (uint32_t)(active >> 32);
+#pragma unroll
+    for (uint32_t b = 0; b < TSW_MAX_BITS; ++b) {
+        if (b < bits) { // (uniform)
+            const uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+            const uint64_t bal = __ballot(m != 0);
+            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);
+            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
+        }
+    }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0));
+    const uint32_t leader = plo ? (uint32_t)__builtin_ctz(plo) : 32u + (uint32_t)__builtin_ctz(phi);
+    uint32_t prev = 0;
+    if (below == 0) prev = atomicAdd(&h[d >> 1], (uint32_t)(__popc(plo) + __popc(phi)) << sh16);
+    return (((uint32_t)__shfl((int)prev, (int)leader) >> sh16) & 0xffffu) + below;
+}
+
 // rank of this lane's element among the elements of the same digit seen so far by this wave
 // (earlier instructions, then lower lanes), adding it to the wave's digit counter
 template <bool RANK_ATOMIC>
@@ -328,16 +367,62 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
     }
 }
 
-template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS>
-__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
+// The end of the in-LDS sort: the tile's index list goes out, and THE ORDER CHECK.  The tile's list must be in strictly
+// increasing (depth key, splat index) order — that IS the contract (TileBinner.binSorted applied to the stable depth
+// order), so verifying it here verifies every pass that led to it, in this kernel and in the two passes of the tile-id
+// sort before it, whichever way they ranked: an unstable rank anywhere leaves equal digits out of their earlier order,
+// i.e. keys or tied indices out of order in the final list.  A violation raises the frame's flag, and the host renders
+// the frame again with ballot ranking (binner_settle).
+// A wave takes 63 elements per step and reads 64: an element's successor sits in the next lane (wave_shl:1 — no LDS
+// instruction: the kernel is bound by those), lane 63 holds the successor of lane 62 and writes nothing — the next step's
+// lane 0 has that element.
+__device__ __forceinline__ void tile_list_out(uint2 *s_el, uint32_t n, uint32_t *__restrict__ out, uint32_t *frame_flags, bool inject,
+                                              uint32_t inject_pos, uint32_t tid) {
+    const uint32_t lane = tid & 63, w = tid >> 6;
+    if (inject) { // test hook (splat_debug_inject_order_fault): the check below must see this
+        if (tid == 0 && n >= inject_pos + 2u) {
+            const uint2 a = s_el[inject_pos];
+            s_el[inject_pos] = s_el[inject_pos + 1];
+            s_el[inject_pos + 1] = a;
+        }
+        __syncthreads();
+    }
+    bool bad = false;
+    for (uint32_t s0 = 0; s0 * 63u < n; s0 += 4 * TS_WAVES) { // (uniform trip count: the lane shifts below want whole waves)
+        uint2 a[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) { // four reads in flight, as in the passes
+            const uint32_t p = (s0 + i * TS_WAVES + w) * 63u + lane;
+            a[i] = s_el[p < n ? p : n - 1];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t p = (s0 + i * TS_WAVES + w) * 63u + lane;
+            if (p < n && lane < 63) out[p] = a[i].y;
+            const uint32_t bx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[i].x, 0x130, 0xf, 0xf, false);
+            const uint32_t by = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[i].y, 0x130, 0xf, 0xf, false);
+#ifndef TS_NO_ORDER_CHECK // (measuring knob of tools/build_variant.sh: what the check costs, profiles/r03_d_order_check_cost.txt)
+            const unsigned long long ka = ((unsigned long long)a[i].x << 32) | a[i].y, kb = ((unsigned long long)bx << 32) | by;
+            if (p + 1 < n && lane < 63) bad |= ka >= kb;
+#endif
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
+}
+
+template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS, bool WIDE>
+__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : (WIDE ? 2 : 3)) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
                                                                                     uint32_t n_above, uint2 *vals, uint2 *scratch,
                                                                                     uint32_t *__restrict__ out_idx,
                                                                                     uint32_t *__restrict__ counts,
                                                                                     uint32_t *__restrict__ frame_flags,
                                                                                     uint32_t inject_tile, uint32_t inject_pos) {
     static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
-    constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_LDS_ELEMS ? TS_MAX_ITEMS * TS_THREADS : TS_LDS_ELEMS;
-    __shared__ TileSortShared sh;
+    constexpr uint32_t TS_FIT = WIDE ? TSW_LDS_ELEMS : TS_LDS_ELEMS;
+    constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_FIT ? TS_MAX_ITEMS * TS_THREADS : TS_FIT;
+    // (the wide path's table and the byte passes' tables are never live together; the byte-pass build holds only its own)
+    __shared__ __align__(16) uint32_t lds_raw[(WIDE ? sizeof(TileSortLds) : sizeof(TileSortShared)) / 4];
+    TileSortShared &sh = *reinterpret_cast<TileSortShared *>(lds_raw);
     __shared__ uint2 s_el[TS_CAP];
     uint32_t *run_base = reinterpret_cast<uint32_t *>(s_el); // long-list path (s_el unused there): start of each digit's run
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -345,13 +430,186 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
     const uint32_t base = offsets[t], n = offsets[t + 1] - base;
     if (counts && tid == 0) counts[t] = n; // (first launch: the tile counts the composite reads)
     if (n <= n_above || (!LAST_CLASS && n > TS_CAP)) return; // empty, or another class's tile
+    uint2 *src = vals + base, *dst = scratch + base;
+    const bool in_lds = !LAST_CLASS || n <= TS_CAP;
+
+    if (WIDE && in_lds) {
+        // ---- the wide path: passes of up to 12 bits ------------------------------------------------------------------
+        // What a pass costs is its returning LDS atomics: the LDS serves them at about one LANE per cycle (a 64-lane
+        // instruction ~64 cycles; a read, a lookup or a scattered 8-byte write 4-8), so an element costs ~64 lane-cycles per
+        // pass whatever else the pass does — measured three ways: the byte passes' time per tile is 3 x n cycles + 30 %;
+        // halving the bytes per element or adding a resident workgroup changed nothing (round 2); a variant of this path
+        // with ONE table shared by the waves (a counting add and a returning add per element and pass: 4 atomics per
+        // element of a 24-bit tile instead of 3) took 106 us where the byte passes take 56 (profiles/r03_f_*).
+        // So: the byte passes' structure — every wave ranks into its own table with ONE returning add per element — with
+        // digits of up to 12 bits: two passes for the 22..24-bit key ranges of the bench sizes' tiles instead of three.  The
+        // first pass ranks straight from the registers the pairs were loaded into.
+        TileSortWide &wd = *reinterpret_cast<TileSortWide *>(lds_raw);
+        if (tid == 0) {
+            wd.kmin = 0xffffffffu;
+            wd.kmax = 0;
+        }
+        const uint32_t items = ((n + TS_THREADS - 1) / TS_THREADS + 3u) & ~3u;
+        const uint32_t wbase = w * items * 64 + lane;
+        uint2 el[TS_MAX_ITEMS];
+#pragma unroll
+        for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+            if (g < items) {
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    const uint32_t p = wbase + i * 64;
+                    el[i] = src[p < n ? p : n - 1]; // (all of a thread's loads in flight at once; padding re-reads the last pair)
+                }
+            }
+        }
+        uint32_t lo = 0xffffffffu, hi = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+            if (g < items) {
+#pragma unroll
+                for (uint32_t i = g; i < g + 4; ++i) {
+                    lo = min(lo, el[i].x);
+                    hi = max(hi, el[i].x);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+        }
+        __syncthreads();
+        if (lane == 0) {
+            atomicMin(&wd.kmin, lo);
+            atomicMax(&wd.kmax, hi);
+        }
+        __syncthreads();
+        const uint32_t kmin = wd.kmin, range = wd.kmax - kmin;
+        const uint32_t bits = range == 0 ? 0u : 32u - (uint32_t)__builtin_clz(range);
+        const uint32_t passes = (bits + TSW_MAX_BITS - 1) / TSW_MAX_BITS;
+        const uint32_t dbits = passes ? (bits + passes - 1) / passes : 0u; // <= 12
+        const uint32_t dmask = (1u << dbits) - 1u;
+        const uint32_t words = dbits ? ((1u << dbits) + 1u) / 2u : 0u; // words of a wave's table in use (two 16-bit counters each)
+        const bool owner = tid * 8u < words;                             // this thread scans digits [16 tid, 16 tid + 16)
+        uint32_t *hw = wd.h[w];
+        if (passes == 0) { // every key equal: the list is in order as it stands
+#pragma unroll
+            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                if (g < items) {
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i)
+                        if (wbase + i * 64 < n) s_el[wbase + i * 64] = el[i];
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t shift = pass * dbits;
+            uint32_t wb = wbase, km = kmin; // (opaque per pass: hoisted out of the loop, every item's digit, address and bound would
+            asm volatile("" : "+v"(wb));    //  live in a register of its own, and a spill in here is a round trip to memory per pass)
+            asm volatile("" : "+s"(km));
+            if (owner) {
+#pragma unroll
+                for (uint32_t v = 0; v < TS_WAVES; ++v) {
+                    uint4 *hv = reinterpret_cast<uint4 *>(wd.h[v]) + tid * 2;
+                    hv[0] = make_uint4(0, 0, 0, 0);
+                    hv[1] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            if (pass > 0) { // (the first pass's elements are in registers already)
+#pragma unroll
+                for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                    if (g < items) {
+#pragma unroll
+                        for (uint32_t i = g; i < g + 4; ++i) {
+                            const uint32_t p = wb + i * 64;
+                            el[i] = s_el[p < n ? p : n - 1];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // rank: the element's number among its wave's earlier elements of the same digit (16-bit counter of the pair in the word)
+            uint32_t rank[TS_MAX_ITEMS];
+#pragma unroll
+            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                if (g < items) {
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i) {
+                        const uint32_t d = ((el[i].x - km) >> shift) & dmask;
+                        rank[i] = 0;
+                        if (wb + i * 64 < n) rank[i] = wide_take<RANK_ATOMIC>(hw, d, dbits);
+                    }
+                }
+            }
+            __syncthreads();
+            // counts -> first positions: digit d's run starts at the exclusive scan of the digit totals, wave v's elements of
+            // digit d follow those of the waves before it; both folded into the wave's own table (one lookup per element)
+            uint32_t tab[TS_WAVES][8]; // packed, relative to this thread's first digit
+            uint32_t total = 0;
+            if (owner) {
+#pragma unroll
+                for (uint32_t half = 0; half < 2; ++half) {
+                    uint4 q[TS_WAVES];
+#pragma unroll
+                    for (uint32_t v = 0; v < TS_WAVES; ++v) q[v] = (reinterpret_cast<const uint4 *>(wd.h[v]) + tid * 2)[half];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        uint32_t cw[TS_WAVES];
+#pragma unroll
+                        for (uint32_t v = 0; v < TS_WAVES; ++v) cw[v] = j == 0 ? q[v].x : j == 1 ? q[v].y : j == 2 ? q[v].z : q[v].w;
+                        uint32_t b0[TS_WAVES], b1[TS_WAVES];
+#pragma unroll
+                        for (uint32_t v = 0; v < TS_WAVES; ++v) { // even digit of the word
+                            b0[v] = total;
+                            total += cw[v] & 0xffffu;
+                        }
+#pragma unroll
+                        for (uint32_t v = 0; v < TS_WAVES; ++v) { // odd digit
+                            b1[v] = total;
+                            total += cw[v] >> 16;
+                        }
+#pragma unroll
+                        for (uint32_t v = 0; v < TS_WAVES; ++v) tab[v][half * 4 + j] = b0[v] | (b1[v] << 16);
+                    }
+                }
+            }
+            const uint32_t excl = ts_scan256(wd.wave_sums, total, tid) * 0x10001u; // (positions stay below 65536: no carry between halves)
+            if (owner) {
+#pragma unroll
+                for (uint32_t v = 0; v < TS_WAVES; ++v) {
+                    uint4 *hv = reinterpret_cast<uint4 *>(wd.h[v]) + tid * 2;
+                    hv[0] = make_uint4(tab[v][0] + excl, tab[v][1] + excl, tab[v][2] + excl, tab[v][3] + excl);
+                    hv[1] = make_uint4(tab[v][4] + excl, tab[v][5] + excl, tab[v][6] + excl, tab[v][7] + excl);
+                }
+            }
+            __syncthreads();
+            // reorder in place (every element is in registers)
+#pragma unroll
+            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                if (g < items) {
+                    uint32_t pos[4];
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i) {
+                        const uint32_t d = ((el[i].x - km) >> shift) & dmask;
+                        pos[i - g] = ((hw[d >> 1] >> ((d & 1u) << 4)) & 0xffffu) + rank[i];
+                    }
+#pragma unroll
+                    for (uint32_t i = g; i < g + 4; ++i)
+                        if (wb + i * 64 < n) s_el[pos[i - g]] = el[i];
+                }
+            }
+            __syncthreads();
+        }
+        tile_list_out(s_el, n, out_idx + base, frame_flags, t == inject_tile, inject_pos, tid);
+        return;
+    }
+
     if (tid == 0) {
         sh.kmin = 0xffffffffu;
         sh.kmax = 0;
     }
     __syncthreads();
-    uint2 *src = vals + base, *dst = scratch + base;
-    const bool in_lds = !LAST_CLASS || n <= TS_CAP;
 
     // load (LDS path) and the tile's key range.  All of a thread's loads are issued before the first
     // is used: one load per loop trip left every workgroup waiting out up to 23 memory latencies in a
@@ -456,49 +714,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : 3) void k_tile_
             }
             __syncthreads();
         }
-        if (t == inject_tile && tid == 0 && n >= inject_pos + 2u) { // test hook (splat_debug_inject_order_fault): the check below must see this
-            const uint2 a = s_el[inject_pos];
-            s_el[inject_pos] = s_el[inject_pos + 1];
-            s_el[inject_pos + 1] = a;
-        }
-        if (t == inject_tile) __syncthreads();
-        // THE ORDER CHECK.  The tile's list must be in strictly increasing (depth key, splat index) order — that IS the
-        // contract (TileBinner.binSorted applied to the stable depth order), so verifying it here verifies every pass
-        // that led to it, in this kernel and in the two passes of the tile-id sort before it, whichever way they ranked:
-        // an unstable rank anywhere leaves equal digits out of their earlier order, i.e. keys or tied indices out of
-        // order in the final list.  One LDS read per element (its successor); a violation raises the frame's flag, and
-        // the host renders the frame again with ballot ranking (binner_settle).
-        bool bad = false;
-        for (uint32_t p0 = 0; p0 < n; p0 += 4 * TS_THREADS) { // (uniform trip count: the lane shifts below want whole waves)
-            uint2 a[4], b63[4];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) { // four reads in flight, as in the passes
-                const uint32_t p = p0 + i * TS_THREADS + tid;
-                a[i] = s_el[p < n ? p : n - 1];
-                b63[i] = a[i];
-            }
-            if (lane == 63) { // the successor of a wave's last lane is another wave's (or another round's) element
-#pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
-                    const uint32_t p = p0 + i * TS_THREADS + tid;
-                    b63[i] = s_el[p + 1 < n ? p + 1 : n - 1];
-                }
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                const uint32_t p = p0 + i * TS_THREADS + tid;
-                if (p < n) out_idx[base + p] = a[i].y;
-                // the successor sits in the next lane (wave_shl:1, no LDS instruction: the kernel is bound by those)
-                uint2 b;
-                b.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[i].x, 0x130, 0xf, 0xf, false);
-                b.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[i].y, 0x130, 0xf, 0xf, false);
-                if (lane == 63) b = b63[i];
-#ifndef TS_NO_ORDER_CHECK // (measuring knob of tools/build_variant.sh: what the check costs, profiles/r03_d_order_check_cost.txt)
-                if (p + 1 < n) bad |= a[i].x > b.x || (a[i].x == b.x && a[i].y >= b.y);
-#endif
-            }
-        }
-        if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
+        tile_list_out(s_el, n, out_idx + base, frame_flags, t == inject_tile, inject_pos, tid);
         return;
     }
 
@@ -576,19 +792,30 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
     // a tenth of a C0 frame).
     const bool one_class = tiles <= 3u * 256u;
-#define SPLAT_TILE_SORT(RA, ITEMS, LAST, ABOVE, COUNTS)                                                                                      \
-    hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, scratch, \
-                       out_idx, COUNTS, frame_flags, inject, inject_pos)
-    if (one_class) {
-        if (ra) SPLAT_TILE_SORT(true, TS_LONG_ITEMS, true, 0u, counts);
-        else SPLAT_TILE_SORT(false, TS_LONG_ITEMS, true, 0u, counts);
-    } else if (ra) {
-        SPLAT_TILE_SORT(true, TS_SHORT_ITEMS, false, 0u, counts);
-        SPLAT_TILE_SORT(true, TS_LONG_ITEMS, true, short_cap, nullptr);
-    } else {
-        SPLAT_TILE_SORT(false, TS_SHORT_ITEMS, false, 0u, counts);
-        SPLAT_TILE_SORT(false, TS_LONG_ITEMS, true, short_cap, nullptr);
+    // SPLAT_TILE_SORT_DIGITS=12: the wide passes (two of up to 12 bits instead of three of 8; built and measured in round 3:
+    // slower — 76 + 33 us against 56 + 23 at C2, profiles/r03_f_tile_sort_wide_digits_C2.txt — kept selectable, and tested)
+    if (ctx->tile_sort_digits == 0) {
+        const char *e = getenv("SPLAT_TILE_SORT_DIGITS");
+        ctx->tile_sort_digits = (e && e[0] == '1' && e[1] == '2' && e[2] == 0) ? 12 : 8;
     }
+    const bool wide = ctx->tile_sort_digits == 12;
+#define SPLAT_TILE_SORT_(RA, ITEMS, LAST, WIDE, ABOVE, COUNTS)                                                                       \
+    hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST, WIDE>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, \
+                       scratch, out_idx, COUNTS, frame_flags, inject, inject_pos)
+#define SPLAT_TILE_SORT(ITEMS, LAST, ABOVE, COUNTS)                          \
+    do {                                                                     \
+        if (ra && wide) SPLAT_TILE_SORT_(true, ITEMS, LAST, true, ABOVE, COUNTS);   \
+        else if (ra) SPLAT_TILE_SORT_(true, ITEMS, LAST, false, ABOVE, COUNTS);     \
+        else if (wide) SPLAT_TILE_SORT_(false, ITEMS, LAST, true, ABOVE, COUNTS);   \
+        else SPLAT_TILE_SORT_(false, ITEMS, LAST, false, ABOVE, COUNTS);            \
+    } while (0)
+    if (one_class) {
+        SPLAT_TILE_SORT(TS_LONG_ITEMS, true, 0u, counts);
+    } else {
+        SPLAT_TILE_SORT(TS_SHORT_ITEMS, false, 0u, counts);
+        SPLAT_TILE_SORT(TS_LONG_ITEMS, true, short_cap, nullptr);
+    }
+#undef SPLAT_TILE_SORT_
 #undef SPLAT_TILE_SORT
     LAUNCH_CHECK(ctx, "k_tile_sort");
     return SPLAT_OK;

@@ -890,6 +890,53 @@ def test_tile_first_with_ballot_ranking(monkeypatch):
         dev.destroy()
 
 
+def test_tile_sort_with_wide_digits(monkeypatch):
+    """SPLAT_TILE_SORT_DIGITS=12: the per-tile sort's two-pass variant (digits of up to 12 bits, 16-bit counters packed two
+    to a word; built and measured in round 3, slower than the byte passes and therefore not the default — DESIGN.md).  Same
+    lists and image as the oracle: both size classes, key ranges that need one, two and three wide passes, a tile of equal
+    keys, the global-memory passes of a list too long for LDS, both rankings."""
+    monkeypatch.setenv("SPLAT_TILE_SORT_DIGITS", "12")
+    for rank in (None, "ballot"):
+        if rank:
+            monkeypatch.setenv("SPLAT_RANK", rank)
+        dev = sr.Device(0)  # (both settings are resolved once per context)
+        try:
+            for n, w, h, seed, rs in [(3000, 128, 96, 41, 1.0), (20000, 640, 360, 42, 1.0), (20000, 64, 64, 43, 6.0), (30000, 48, 32, 44, 8.0),
+                                      (6000, 16, 16, 74, 30.0)]:
+                props, normals, u = make_case(n, w, h, seed, rs)
+                if seed == 43:  # a slab of equal depth keys (equal positions), and keys 2^27 apart in one tile (three wide passes)
+                    props[1000:3000, :3] = props[1000, :3]
+                    eye = np.asarray(u[16:19], np.float32)
+                    toward = -eye / np.linalg.norm(eye)
+                    near = np.random.default_rng(5).choice(n, 40, replace=False)
+                    props[near, :3] = eye + toward * np.random.default_rng(6).uniform(2e-5, 6e-5, size=(40, 1)).astype(np.float32)
+                    props[near, 3] = np.float32(2e-7)
+                if seed == 41:  # every depth within a few hundred ulps: one wide pass (and none for the tiles whose keys are equal)
+                    eye = np.asarray(u[16:19], np.float32)  # (depth = distance from the eye, SplatProjector.ts:77: a thin shell around it)
+                    ray = props[:, :3] - eye
+                    ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+                    props[:, :3] = eye + ray * (3.0 + np.random.default_rng(7).uniform(0, 1e-4, (n, 1))).astype(np.float32)
+                ref = oracle_pipeline(props, normals, u, w, h)
+                pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
+                r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
+                for rep in range(2):  # first and sync-free
+                    r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+                    total = r.finish()
+                    assert not r.previousFrameOverflowed or rep == 0
+                    assert total == ref["indices"].shape[0], (n, w, h)
+                    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("wide digits", rank, n, w, h, rep),
+                                offsets=ref["offsets"], keys=ref["keys"])
+                assert dev.rankStatus()["orderFaults"] == 0
+                got = r.readPixelsFloat()
+                r2 = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="sortFirst")
+                r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
+                assert_same(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32), ("wide digits image", rank, n, w, h))
+                for o in (r, r2, pbuf, nbuf):
+                    o.destroy()
+        finally:
+            dev.destroy()
+
+
 def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
     """The default ranking of the tile-first frame rests on nothing unverified (include/splat.h, NOTE on ranking): the
     per-tile sort checks every finished list for strictly increasing (depth key, splat index) order.  Here a list is

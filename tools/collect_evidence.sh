@@ -20,6 +20,8 @@ for pmc in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $pmc --output-format csv -d "$root/$out/pmc_$pmc" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_$pmc.err"
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d "$root/$out/pmc_SQ" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_SQ.err"
+# the LDS side (which bound holds): instructions, array cycles, bank-conflict cycles, issue stalls
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d "$root/$out/pmc_LDS" -- python3 "$root/bench.py" --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_LDS.err"
 for c in C0 C1 C3; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $pmc --output-format csv -d "$root/$out/pmc_${c}_$pmc" -- python3 "$root/bench.py" --config $c --no-cpu-baseline --no-parity --steps 5 > /dev/null 2> "$root/$out/pmc_${c}_$pmc.err"
@@ -31,6 +33,7 @@ python3 tools/kstats.py $(ls $out/trace/*/*_kernel_trace.csv | head -1) 120 > "$
 cp $(ls $out/trace/*/*_kernel_stats.csv | head -1) "$out/kernel_stats.csv"
 python3 tools/pmc_merge.py $(ls $out/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls $out/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1) > "$out/pmc_fetch_write.csv"
 python3 tools/pmc_avg.py --valu $(ls $out/pmc_SQ/*/*_counter_collection.csv | head -1) $(ls $out/pmc_GRBM_GUI_ACTIVE/*/*_counter_collection.csv | head -1) > "$out/sq_counters.csv"
+python3 tools/pmc_avg.py $(ls $out/pmc_LDS/*/*_counter_collection.csv | head -1) $(ls $out/pmc_GRBM_GUI_ACTIVE/*/*_counter_collection.csv | head -1) > "$out/lds_counters.csv"
 for c in C0 C1 C3; do
   python3 tools/pmc_merge.py $(ls $out/pmc_${c}_FETCH_SIZE/*/*_counter_collection.csv | head -1) $(ls $out/pmc_${c}_WRITE_SIZE/*/*_counter_collection.csv | head -1) > "$out/pmc_fetch_write_$c.csv"
 done
