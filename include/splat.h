@@ -82,7 +82,12 @@ int splat_abi_version(void);
 int splat_set_timing(splat_ctx *ctx, int enabled);
 /* Restrict event recording to the stages whose bit (1 << stage id) is set (default: all).  Each
  * recorded stage costs ~10 us of stream idle per frame, so a throughput measurement that only needs
- * one kernel's duration enables only that stage. */
+ * one kernel's duration enables only that stage.  Bit 31 (SPLAT_TIMING_COUNT_ENTRIES, set by default):
+ * a timed whole-frame call also counts, per tile, the list entries its composite staged and consumed
+ * (splat_timing_consumed) — the counting instantiation of the kernel is a few per cent slower than the
+ * one every other frame runs, so a measurement of the production kernel clears the bit and takes the
+ * counts from a frame outside its timed region (they are a property of the input). */
+#define SPLAT_TIMING_COUNT_ENTRIES 0x80000000u
 int splat_set_timing_stages(splat_ctx *ctx, uint32_t stage_mask);
 /* Duration of the most recent run of `stage`; synchronises on that stage's end event. */
 int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);

@@ -17,6 +17,7 @@ RENDER_AGAIN = (-4, -8)
 
 STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE, STAGE_BIN_SCATTER, STAGE_BIN_PASS2, STAGE_BIN_TILE_SORT = range(8)
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange", "bin_scatter", "bin_second_pass", "bin_tile_sort")
+TIMING_COUNT_ENTRIES = 0x80000000  # splat_set_timing_stages: also count the entries a timed frame's composite staged / consumed
 MODE_FRONT_TO_BACK, MODE_REFERENCE_LITERAL = 0, 1
 RECORDS_PROJECTED, RECORDS_COMPACT, RECORDS_DISC48, RECORDS_LIT32 = 0, 1, 2, 3
 FOOTPRINT_ISOTROPIC, FOOTPRINT_DISC = 0, 1

@@ -511,7 +511,8 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     uint32_t *report = binner->report_for_composite; // (tile-first frames: the frame's last kernel reports it: common.h)
     binner->report_for_composite = nullptr;
     return composite_launch(ctx, cfg, color, color_stride, normals, 1, records, indices, counts, offsets, width, height, out_rgba8,
-                            out_rgba32f, ctx->timing ? (void *)ctx->d_consumed : nullptr, binner->d_total, report, binner->report_seq);
+                            out_rgba32f, (ctx->timing && (ctx->timing_mask & SPLAT_TIMING_COUNT_ENTRIES)) ? (void *)ctx->d_consumed : nullptr, binner->d_total,
+                            report, binner->report_seq);
 }
 
 extern "C" {
