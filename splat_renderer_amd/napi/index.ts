@@ -16,6 +16,20 @@
  * (the hand-written public surface) and have not been through `tsc`; fields and helpers index.d.ts does not list are
  * typed from their use, `any` where that is not a single type.
  */
+declare function require(name: string): any;
+declare const module: { exports: any };
+type TypedArray = Float32Array | Uint32Array | Uint8Array | Int32Array;
+interface CommandEncoder { finish(): null; }
+interface PointerLikeEvent {
+  clientX?: number;
+  clientY?: number;
+  button?: number;
+  deltaY?: number;
+  preventDefault?(): void;
+}
+interface SceneNode { type: "primitive" | "operation"; }
+interface PropertyPlanes { posRadius: Buffer_; colorOpacity: Buffer_; isPlanes: true; prelit?: boolean; }
+type Footprint = "isotropic" | "disc" | 0 | 1;
 const native = require('./splat_napi.node');
 
 const U32_MAX = 0xffffffff;
@@ -25,31 +39,38 @@ const MODE_REFERENCE_LITERAL = 1;
 const RECORDS_PROJECTED = 0, RECORDS_COMPACT = 1, RECORDS_LIT32 = 3;
 
 class Buffer_ {
-  constructor(device, ptr, size, owned = true) {
+  declare device: Device;
+  declare ptr: number;
+  declare size: number;
+  declare owned: boolean;
+  declare hostShadow: Float32Array | null;
+  constructor(device: Device, ptr: number, size: number, owned: boolean = true) {
     this.device = device;
     this.ptr = ptr;
     this.size = size;
     this.owned = owned;
     this.hostShadow = null;
   }
-  destroy() {
+  destroy(): void {
     if (this.owned && this.ptr) native.buf_free(this.device.ctx, this.ptr);
     this.ptr = 0;
   }
-  write(typedArray) {
+  write(typedArray: TypedArray): this {
     native.buf_upload(this.device.ctx, this.ptr, typedArray);
     if (this.size <= 256) this.hostShadow = new Float32Array(typedArray.buffer.slice(typedArray.byteOffset, typedArray.byteOffset + typedArray.byteLength));
     return this;
   }
-  read(typedArray) {
+  read<T extends TypedArray>(typedArray: T): T {
     native.buf_download(this.device.ctx, typedArray, this.ptr);
     return typedArray;
   }
-  zero() { native.buf_zero(this.device.ctx, this.ptr, this.size); }
+  zero(): void { native.buf_zero(this.device.ctx, this.ptr, this.size); }
 }
 
 class Device {
-  constructor(ordinal = 0) {
+  declare ctx: unknown;
+  declare queue: { writeBuffer(buffer: Buffer_, offset: number, data: TypedArray): void; submit(commandBuffers?: unknown[]): void; onSubmittedWorkDone(): Promise<void> };
+  constructor(ordinal: number = 0) {
     this.ctx = native.ctx_create(ordinal);
     const self = this;
     this.queue = {
@@ -64,20 +85,20 @@ class Device {
       },
     };
   }
-  createBuffer(desc) {
+  createBuffer(desc: number | { size: number }): Buffer_ {
     const size = typeof desc === 'number' ? desc : desc.size;
     return new Buffer_(this, native.buf_alloc(this.ctx, size), size);
   }
-  createBufferFrom(typedArray) { return this.createBuffer(Math.max(typedArray.byteLength, 16)).write(typedArray); }
-  createCommandEncoder() { return { finish() { return null; } }; }
-  sync() { native.sync(this.ctx); }
-  destroy() {
+  createBufferFrom(typedArray: TypedArray): Buffer_ { return this.createBuffer(Math.max(typedArray.byteLength, 16)).write(typedArray); }
+  createCommandEncoder(): CommandEncoder { return { finish() { return null; } }; }
+  sync(): void { native.sync(this.ctx); }
+  destroy(): void {
     if (this.ctx) native.ctx_destroy(this.ctx);
     this.ctx = null;
   }
 }
 
-function uniformFloats(u) {
+function uniformFloats(u: Float32Array | Buffer_ | ArrayLike<number>): Float32Array {
   if (u instanceof Buffer_) {
     if (!u.hostShadow) throw new Error('uniform buffer was never written');
     u = u.hostShadow;
@@ -88,14 +109,22 @@ function uniformFloats(u) {
 
 /** src/SplatPropertyManager.ts:13-181 */
 class SplatPropertyManager {
-  constructor(device, numSplats) {
+  declare device: Device;
+  declare numSplats: number;
+  declare propertyBuffer: Buffer_ | null;
+  declare planesValid: boolean;
+  declare litValid: boolean;
+  declare planes: PropertyPlanes | null;
+  declare lit: PropertyPlanes | null;
+  declare litNormals: any;
+  constructor(device: Device, numSplats: number) {
     this.device = device;
     this.numSplats = numSplats;
     this.propertyBuffer = device.createBuffer(numSplats * 32);
     this.propertyBuffer.write(SplatPropertyManager.defaultProperties(numSplats)); // initializeDefaults :33-50
   }
   // :33-50: position 0, radius 0.04, white, opacity 0.7 (held to an execution of the reference's loop: tests/golden/ref_host.json)
-  static defaultProperties(numSplats) {
+  static defaultProperties(numSplats: number): Float32Array {
     const data = new Float32Array(numSplats * 8);
     for (let i = 0; i < numSplats; i++) {
       data[i * 8 + 3] = 0.04;
@@ -106,19 +135,19 @@ class SplatPropertyManager {
     }
     return data;
   }
-  updateFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) { // :153-173
+  updateFromCurvature(commandEncoder: CommandEncoder | null, positionBuffer: Buffer_, curvatureBuffer: Buffer_): void { // :153-173
     native.update_props(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, this.propertyBuffer.ptr);
     this.planesValid = false;
     this.litValid = false;
   }
-  setFromArrays(props) {
+  setFromArrays(props: Float32Array): void {
     this.propertyBuffer.write(props);
     this.planesValid = false;
     this.litValid = false;
   }
-  getPropertyBuffer() { return this.propertyBuffer; } // :175-177
+  getPropertyBuffer(): Buffer_ { return this.propertyBuffer; } // :175-177
   // the MI355X-native layout: two vec4 planes {posRadius, colorOpacity}; Renderer.render takes either
-  getPropertyPlanes() {
+  getPropertyPlanes(): PropertyPlanes {
     if (!this.planes) this.planes = { posRadius: this.device.createBuffer(this.numSplats * 16), colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true };
     if (!this.planesValid) {
       native.props_to_planes(this.device.ctx, this.propertyBuffer.ptr, this.numSplats, this.planes.posRadius.ptr, this.planes.colorOpacity.ptr);
@@ -128,7 +157,7 @@ class SplatPropertyManager {
   }
   // the planes with the colour plane already lit by the given normals (kd = 0.85 + 0.15 max(n.l, 0), once per
   // property update instead of once per staged list entry): the frame then gathers one line less per entry
-  getLitPlanes(normalsBuffer) {
+  getLitPlanes(normalsBuffer: Buffer_): PropertyPlanes {
     const p = this.getPropertyPlanes();
     if (!this.lit) this.lit = { posRadius: p.posRadius, colorOpacity: this.device.createBuffer(this.numSplats * 16), isPlanes: true, prelit: true };
     if (!this.litValid || this.litNormals !== normalsBuffer.ptr) {
@@ -138,12 +167,12 @@ class SplatPropertyManager {
     }
     return this.lit;
   }
-  updatePlanesFromCurvature(commandEncoder, positionBuffer, curvatureBuffer) {
+  updatePlanesFromCurvature(commandEncoder: CommandEncoder | null, positionBuffer: Buffer_, curvatureBuffer: Buffer_): PropertyPlanes {
     const p = this.getPropertyPlanes();
     native.update_props_planes(this.device.ctx, positionBuffer.ptr, curvatureBuffer.ptr, this.numSplats, p.posRadius.ptr, p.colorOpacity.ptr);
     return p;
   }
-  destroy() { // :179-181
+  destroy(): void { // :179-181
     this.propertyBuffer.destroy();
     if (this.planes) {
       this.planes.posRadius.destroy();
@@ -158,7 +187,7 @@ class SplatPropertyManager {
 }
 
 /** src/SplatProjector.ts:5-203 */
-function footprintCode(f) {
+function footprintCode(f: Footprint | undefined): number {
   if (f === undefined || f === null || f === 'isotropic' || f === FOOTPRINT_ISOTROPIC) return FOOTPRINT_ISOTROPIC;
   if (f === 'disc' || f === FOOTPRINT_DISC) return FOOTPRINT_DISC;
   throw new Error(`footprint must be 'isotropic' or 'disc', not ${f}`);
@@ -166,7 +195,13 @@ function footprintCode(f) {
 /** footprint 'disc' (extension): SequentialRenderer's oriented disc — project() then needs normalsBuffer, the bounds are
  * the disc's exact screen extent and getDiscBuffer() holds the 32-byte records the composite evaluates. */
 class SplatProjector {
-  constructor(device, numSplats, footprint = 'isotropic') {
+  declare device: Device;
+  declare numSplats: number;
+  declare footprint: number;
+  declare projectedBuffer: Buffer_ | null;
+  declare contents: "projected" | "lit";
+  declare discBuffer: Buffer_ | null;
+  constructor(device: Device, numSplats: number, footprint: Footprint = 'isotropic') {
     this.device = device;
     this.numSplats = numSplats;
     this.footprint = footprintCode(footprint);
@@ -174,7 +209,7 @@ class SplatProjector {
     this.contents = 'projected';
     this.discBuffer = this.footprint === FOOTPRINT_DISC ? device.createBuffer(numSplats * 32) : null;
   }
-  project(commandEncoder, uniformBuffer, splatPropertyBuffer, keysBuffer = null, payloadBuffer = null, paddedSize = 0, normalsBuffer = null) { // :174-194
+  project(commandEncoder: CommandEncoder | null, uniformBuffer: Buffer_ | Float32Array, splatPropertyBuffer: Buffer_, keysBuffer: Buffer_ | null = null, payloadBuffer: Buffer_ | null = null, paddedSize: number = 0, normalsBuffer: Buffer_ | null = null): void { // :174-194
     const u = uniformFloats(uniformBuffer);
     if (u.length < 22) throw new Error('uniform block needs 22 floats (VP, eye, time, screenW, screenH)');
     const keys = keysBuffer ? keysBuffer.ptr : null, payload = payloadBuffer ? payloadBuffer.ptr : null;
@@ -189,19 +224,19 @@ class SplatProjector {
   // :196-198.  Throws when the last frame left the 32-byte LIT composite records {centre.xy, radius, depth | lit rgb,
   // opacity} here instead of ProjectedSplat records (Renderer records 'lit', the whole-frame facade's default): code
   // written against the reference's layout must not read those by accident — getRecordsBuffer() hands them out.
-  getProjectedBuffer() {
+  getProjectedBuffer(): Buffer_ {
     if (this.contents === 'lit') {
       throw new Error("the projector's buffer holds lit composite records (Renderer records 'lit'), not ProjectedSplat records: " +
         "use getRecordsBuffer() and Renderer.recordFormat, or new Renderer(..., { records: 'projected' })");
     }
     return this.projectedBuffer;
   }
-  getRecordsBuffer() { return this.projectedBuffer; } // whatever the last frame wrote (this.contents: 'projected' | 'lit')
-  getDiscBuffer() {
+  getRecordsBuffer(): Buffer_ { return this.projectedBuffer; } // whatever the last frame wrote (this.contents: 'projected' | 'lit')
+  getDiscBuffer(): Buffer_ {
     if (!this.discBuffer) throw new Error("getDiscBuffer: this projector was not created with footprint 'disc'");
     return this.discBuffer;
   }
-  destroy() {
+  destroy(): void {
     this.projectedBuffer.destroy();
     if (this.discBuffer) this.discBuffer.destroy();
   }          // :200-202
@@ -209,28 +244,33 @@ class SplatProjector {
 
 /** src/DepthKeyExtractor.ts:5-115 */
 class DepthKeyExtractor {
-  constructor(device) { this.device = device; }
-  extract(commandEncoder, projectedBuffer, keysBuffer, payloadBuffer, numSplats, paddedSize) { // :71-109
+  declare device: Device;
+  constructor(device: Device) { this.device = device; }
+  extract(commandEncoder: CommandEncoder | null, projectedBuffer: Buffer_, keysBuffer: Buffer_, payloadBuffer: Buffer_, numSplats: number, paddedSize: number): void { // :71-109
     native.extract_keys(this.device.ctx, projectedBuffer.ptr, numSplats, paddedSize, keysBuffer.ptr, payloadBuffer.ptr);
   }
-  cleanupTempBuffers() {}
+  cleanupTempBuffers(): void {}
 }
 
 /** src/RadixSorter.ts:21-301 */
 class RadixSorter {
-  constructor(device, numSplats) {
+  declare device: Device;
+  declare numSplats: number;
+  declare handle: unknown;
+  declare paddedSize: number;
+  constructor(device: Device, numSplats: number) {
     this.device = device;
     this.numSplats = numSplats;
     this.handle = native.sort_create(device.ctx, numSplats);
     this.paddedSize = native.sort_capacity(this.handle);
     // :46-52
   }
-  sort(numKeys = this.numSplats, bitBegin = 0, bitEnd = 32) { native.sort_run(this.device.ctx, this.handle, numKeys, bitBegin, bitEnd); } // :197-264
-  getSortedIndicesBuffer() { return new Buffer_(this.device, native.sort_sorted_payload(this.handle), this.paddedSize * 4, false); } // :269-271
-  getKeysBuffer() { return new Buffer_(this.device, native.sort_keys(this.handle), this.paddedSize * 4, false); }       // :273-275
-  getPayloadBuffer() { return new Buffer_(this.device, native.sort_payload(this.handle), this.paddedSize * 4, false); } // :277-279
-  cleanupTempBuffers() {}
-  destroy() {
+  sort(numKeys: number = this.numSplats, bitBegin: number = 0, bitEnd: number = 32): void { native.sort_run(this.device.ctx, this.handle, numKeys, bitBegin, bitEnd); } // :197-264
+  getSortedIndicesBuffer(): Buffer_ { return new Buffer_(this.device, native.sort_sorted_payload(this.handle), this.paddedSize * 4, false); } // :269-271
+  getKeysBuffer(): Buffer_ { return new Buffer_(this.device, native.sort_keys(this.handle), this.paddedSize * 4, false); }       // :273-275
+  getPayloadBuffer(): Buffer_ { return new Buffer_(this.device, native.sort_payload(this.handle), this.paddedSize * 4, false); } // :277-279
+  cleanupTempBuffers(): void {}
+  destroy(): void {
     if (this.handle) native.sort_destroy(this.handle);
     this.handle = null;
   }
@@ -238,16 +278,22 @@ class RadixSorter {
 
 /** src/PrefixSumScanner.ts:8-168 */
 class PrefixSumScanner {
-  constructor(device) { this.device = device; }
-  async scan(commandEncoder, inputBuffer, outputBuffer, numElements) { // :74-87 (async in the reference because of its CPU fallback)
+  declare device: Device;
+  constructor(device: Device) { this.device = device; }
+  async scan(commandEncoder: CommandEncoder | null, inputBuffer: Buffer_, outputBuffer: Buffer_, numElements: number): Promise<void> { // :74-87 (async in the reference because of its CPU fallback)
     native.scan_u32(this.device.ctx, inputBuffer.ptr, outputBuffer.ptr, numElements, null);
   }
-  cleanupTempBuffers() {}
+  cleanupTempBuffers(): void {}
 }
 
 /** src/GPUTileBinner.ts:11-378 */
 class GPUTileBinner {
-  constructor(device, tileSize) {
+  declare device: Device;
+  declare tileSize: number;
+  declare handle: unknown;
+  declare prefixSumScanner: PrefixSumScanner;
+  declare numTiles: number;
+  constructor(device: Device, tileSize: number) {
     this.device = device;
     this.tileSize = tileSize;
     this.handle = native.bin_create(device.ctx, tileSize);
@@ -257,22 +303,22 @@ class GPUTileBinner {
   }
   // order of work of the whole-frame call: 'tileFirst' (bin in index order, PerTileSorter-style depth sort per tile;
   // the default), 'sortFirst' (global depth sort, bin in sorted order) or 'default'; same lists either way
-  setFrameOrder(order) { native.bin_set_frame_order(this.device.ctx, this.handle, { default: -1, sortFirst: 0, tileFirst: 1 }[order]); }
-  async binSplats(commandEncoder, projectedBuffer, sortedIndicesBuffer, numSplats, screenWidth, screenHeight) { // :190-338
+  setFrameOrder(order: "default" | "sortFirst" | "tileFirst"): void { native.bin_set_frame_order(this.device.ctx, this.handle, { default: -1, sortFirst: 0, tileFirst: 1 }[order]); }
+  async binSplats(commandEncoder: CommandEncoder | null, projectedBuffer: Buffer_, sortedIndicesBuffer: Buffer_, numSplats: number, screenWidth: number, screenHeight: number): Promise<void> { // :190-338
     native.bin_run(this.device.ctx, this.handle, projectedBuffer.ptr, numSplats, sortedIndicesBuffer.ptr, numSplats, screenWidth, screenHeight, 0, U32_MAX);
     this.numTiles = Math.ceil(screenWidth / this.tileSize) * Math.ceil(screenHeight / this.tileSize);
   }
   // the natives throw Error("... Tile offsets buffer not initialized") etc. before binSplats, as :340-359
-  getTileOffsetsBuffer() { return new Buffer_(this.device, native.bin_offsets(this.device.ctx, this.handle), this.numTiles * 4, false); }
-  getTileIndicesBuffer() {
+  getTileOffsetsBuffer(): Buffer_ { return new Buffer_(this.device, native.bin_offsets(this.device.ctx, this.handle), this.numTiles * 4, false); }
+  getTileIndicesBuffer(): Buffer_ {
     const p = native.bin_indices(this.device.ctx, this.handle);
     return new Buffer_(this.device, p, Math.max(4, this.getTotalIndices() * 4), false);
   }
-  getTileCountsBuffer() { return new Buffer_(this.device, native.bin_counts(this.device.ctx, this.handle), this.numTiles * 4, false); }
-  getTotalIndices() { return native.bin_total(this.device.ctx, this.handle); }
-  getTileSize() { return this.tileSize; } // :361-363
-  cleanupTempBuffers() { this.prefixSumScanner.cleanupTempBuffers(); }
-  destroy() {
+  getTileCountsBuffer(): Buffer_ { return new Buffer_(this.device, native.bin_counts(this.device.ctx, this.handle), this.numTiles * 4, false); }
+  getTotalIndices(): number { return native.bin_total(this.device.ctx, this.handle); }
+  getTileSize(): number { return this.tileSize; } // :361-363
+  cleanupTempBuffers(): void { this.prefixSumScanner.cleanupTempBuffers(); }
+  destroy(): void {
     if (this.handle) native.bin_destroy(this.handle);
     this.handle = null;
   }
@@ -282,24 +328,34 @@ class GPUTileBinner {
  * reorders nothing; with validate=true it runs the order check on the device and returns the number
  * of out-of-order neighbours (0). */
 class PerTileSorter {
-  constructor(device, validate = false) {
+  declare device: Device;
+  declare validate: boolean;
+  declare violations: number;
+  constructor(device: Device, validate: boolean = false) {
     this.device = device;
     this.validate = validate;
     this.violations = 0;
   }
-  sort(commandEncoder, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, splatIndicesBuffer, numTiles, maxSplatsPerTile, totalPairs) { // :174-213
+  sort(commandEncoder: CommandEncoder | null, projectedBuffer: Buffer_, tileListsBuffer: Buffer_, tileOffsetsBuffer: Buffer_, splatIndicesBuffer: Buffer_, numTiles: number, maxSplatsPerTile: number, totalPairs?: number): number | undefined { // :174-213
     if (!this.validate) return undefined;
     const total = totalPairs === undefined ? splatIndicesBuffer.size / 4 : totalPairs;
     this.violations = native.validate_tile_order(this.device.ctx, projectedBuffer.ptr, tileOffsetsBuffer.ptr, numTiles, splatIndicesBuffer.ptr, total);
     return this.violations;
   }
-  cleanupTempBuffers() {}
-  destroy() {}
+  cleanupTempBuffers(): void {}
+  destroy(): void {}
 }
 
 /** src/ComputeShaderRenderer.ts:5-469 (the canvas blit :268-338 is out of scope) */
 class ComputeShaderRenderer {
-  constructor(device, context = null, presentationFormat = 'rgba8unorm', options = {}) {
+  declare device: Device;
+  declare mode: number;
+  declare earlyOut: boolean;
+  declare footprint: number;
+  declare outputTexture: Buffer_ | null;
+  declare width: number;
+  declare height: number;
+  constructor(device: Device, context: unknown = null, presentationFormat: string = 'rgba8unorm', options: { mode?: number; earlyOut?: boolean; footprint?: Footprint } = {}) {
     this.device = device;
     this.mode = options.mode || MODE_FRONT_TO_BACK;
     this.earlyOut = options.earlyOut !== false;
@@ -309,7 +365,7 @@ class ComputeShaderRenderer {
     this.width = 0;
     this.height = 0;
   }
-  ensureOutputTexture(width, height) { // :340-360
+  ensureOutputTexture(width: number, height: number): void { // :340-360
     if (this.width !== width || this.height !== height) {
       if (this.outputTexture) this.outputTexture.destroy();
       this.outputTexture = this.device.createBuffer(width * height * 4);
@@ -317,14 +373,14 @@ class ComputeShaderRenderer {
       this.height = height;
     }
   }
-  render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, tileSize, numTilesX, width, height) { // :362-462
+  render(uniformData: Float32Array, splatPropertyBuffer: Buffer_, splatIndicesBuffer: Buffer_, curvatureBuffer: Buffer_, projectedBuffer: Buffer_, tileListsBuffer: Buffer_, tileOffsetsBuffer: Buffer_, tileSize: number, numTilesX: number, width: number, height: number): void { // :362-462
     if (numTilesX !== Math.ceil(width / tileSize)) throw new Error('numTilesX does not match ceil(width / tileSize)');
     this.ensureOutputTexture(width, height);
     native.composite(this.device.ctx, [this.mode, this.earlyOut ? 1 : 0, tileSize, 0, U32_MAX, 0, 0, this.footprint], splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
       projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr, width, height, this.outputTexture.ptr, null);
   }
-  readPixels() { return this.outputTexture.read(new Uint8Array(this.width * this.height * 4)); }
-  destroy() {
+  readPixels(): Uint8Array { return this.outputTexture.read(new Uint8Array(this.width * this.height * 4)); }
+  destroy(): void {
     if (this.outputTexture) this.outputTexture.destroy();
     this.outputTexture = null;
   } // :464-468
@@ -332,8 +388,9 @@ class ComputeShaderRenderer {
 
 /** src/TileRenderer.ts:5-355 — fronts the same composite; bindTileData supplies what render()'s reference signature lacks */
 class TileRenderer extends ComputeShaderRenderer {
-  bindTileData(projectedBuffer, tileCountsBuffer, tileOffsetsBuffer) { this.bound = [projectedBuffer, tileCountsBuffer, tileOffsetsBuffer]; }
-  async render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, tileCountsData, numTilesX, numTilesY, tileSize, maxSplatsPerTile, width, height) { // :234-348
+  declare bound: boolean;
+  bindTileData(projectedBuffer: Buffer_, tileCountsBuffer: Buffer_, tileOffsetsBuffer: Buffer_): void { this.bound = [projectedBuffer, tileCountsBuffer, tileOffsetsBuffer]; }
+  async render(uniformData: Float32Array, splatPropertyBuffer: Buffer_, splatIndicesBuffer: Buffer_, curvatureBuffer: Buffer_, tileCountsData: Buffer_, numTilesX: Buffer_, numTilesY: Buffer_, tileSize: number, maxSplatsPerTile: number, width: number, height: number): void { // :234-348
     if (!this.bound) throw new Error('TileRenderer.render: call bindTileData(projected, counts, offsets) first');
     super.render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, this.bound[0], this.bound[1], this.bound[2], tileSize, numTilesX, width, height);
   }
@@ -344,7 +401,13 @@ class TileRenderer extends ComputeShaderRenderer {
  * evaluated per pixel through the inverse plane-to-screen homography (footprint 'disc', the default); 'isotropic'
  * composites the same order with ComputeShaderRenderer's screen-space Gaussian. */
 class SequentialRenderer {
-  constructor(device, context = null, presentationFormat = 'rgba8unorm', numSplats = 0, tileSize = 16, footprint = 'disc') {
+  declare device: Device;
+  declare numSplats: number;
+  declare tileSize: number;
+  declare projector: SplatProjector;
+  declare binner: GPUTileBinner;
+  declare compositor: ComputeShaderRenderer;
+  constructor(device: Device, context: unknown = null, presentationFormat: string = 'rgba8unorm', numSplats: number = 0, tileSize: number = 16, footprint: Footprint = 'disc') {
     this.device = device;
     this.numSplats = numSplats;
     this.tileSize = tileSize;
@@ -352,7 +415,7 @@ class SequentialRenderer {
     this.binner = new GPUTileBinner(device, tileSize);
     this.compositor = new ComputeShaderRenderer(device, context, presentationFormat, { footprint });
   }
-  render(uniformData, splatPropertyBuffer, sortedIndexBuffer, curvatureBuffer, width, height) { // :233-314
+  render(uniformData: Float32Array | Buffer_, splatPropertyBuffer: Buffer_, sortedIndexBuffer: Buffer_, curvatureBuffer: Buffer_, width: number, height: number): void { // :233-314
     let u = uniformFloats(uniformData);
     if (u.length < 22) {
       const v = new Float32Array(22);
@@ -368,8 +431,8 @@ class SequentialRenderer {
     this.compositor.render(u, splatPropertyBuffer, this.binner.getTileIndicesBuffer(), curvatureBuffer, disc ? this.projector.getDiscBuffer() : this.projector.getProjectedBuffer(),
       this.binner.getTileCountsBuffer(), this.binner.getTileOffsetsBuffer(), this.tileSize, Math.ceil(width / this.tileSize), width, height);
   }
-  readPixels() { return this.compositor.readPixels(); }
-  destroy() {
+  readPixels(): Uint8Array { return this.compositor.readPixels(); }
+  destroy(): void {
     this.projector.destroy();
     this.binner.destroy();
     this.compositor.destroy();
@@ -378,7 +441,20 @@ class SequentialRenderer {
 
 /** src/Renderer.ts:13,250,311 — name kept as the whole-frame facade (project -> keys -> sort -> bin -> composite) */
 class Renderer {
-  constructor(device, context = null, presentationFormat = 'rgba8unorm', numPoints = 0, tileSize = 16, options = {}) {
+  declare device: Device;
+  declare numPoints: number;
+  declare tileSize: number;
+  declare footprint: number;
+  declare records: string;
+  declare projector: SplatProjector;
+  declare sorter: RadixSorter;
+  declare binner: GPUTileBinner;
+  declare output: Buffer_ | null;
+  declare width: number;
+  declare height: number;
+  declare last: number;
+  declare recordFormat: number;
+  constructor(device: Device, context: unknown = null, presentationFormat: string = 'rgba8unorm', numPoints: number = 0, tileSize: number = 16, options: { footprint?: Footprint; records?: "lit" | "projected" } = {}) {
     this.device = device;
     this.numPoints = numPoints;
     this.tileSize = tileSize;
@@ -395,7 +471,7 @@ class Renderer {
     this.width = 0;
     this.height = 0;
   }
-  render(uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height) {
+  render(uniformData: Float32Array | Buffer_, propertyBuffer: Buffer_ | PropertyPlanes, normalsBuffer: Buffer_, scaleFactorsBuffer: Buffer_ | null, width: number, height: number): Buffer_ {
     this.last = [uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height]; // (finish() may render it again)
     let u = uniformFloats(uniformData);
     if (u.length < 22) {
@@ -428,7 +504,7 @@ class Renderer {
   // Settles a sync-free frame: waits for its report (pair total, overflow and order-check flags: include/splat.h) and, if
   // the frame has to be rendered again — it outgrew the pair limit sized from the frame before it, or its tile lists
   // failed the per-tile sort's order check — does so.  Returns the frame's pair total.  Called before results are read.
-  finish() {
+  finish(): number {
     try {
       return native.bin_total(this.device.ctx, this.binner.handle);
     } catch (e) {
@@ -437,11 +513,11 @@ class Renderer {
       return native.bin_total(this.device.ctx, this.binner.handle);
     }
   }
-  readPixels() {
+  readPixels(): Uint8Array {
     this.finish();
     return this.output.read(new Uint8Array(this.width * this.height * 4));
   }
-  destroy() {
+  destroy(): void {
     this.projector.destroy();
     this.sorter.destroy();
     this.binner.destroy();
@@ -451,6 +527,17 @@ class Renderer {
 
 /** src/Camera.ts:3-139 with gl-matrix 3.4.4 semantics (Float32Array stores, f64 arithmetic) */
 class Camera {
+  declare target: Float32Array;
+  declare distance: number;
+  declare azimuth: number;
+  declare elevation: number;
+  declare fov: number;
+  declare aspect: number;
+  declare near: number;
+  declare far: number;
+  declare viewProjectionMatrix: Float32Array;
+  declare cameraPosition: Float32Array;
+  declare isDirty: boolean;
   constructor() {
     this.target = new Float32Array([0, 0, 0]);
     this.distance = 3.0;
@@ -464,23 +551,23 @@ class Camera {
     this.cameraPosition = new Float32Array(3);
     this.isDirty = true;
   }
-  setAspect(aspect) {
+  setAspect(aspect: number): void {
     this.aspect = aspect;
     this.isDirty = true;
   }
-  rotate(dAz, dEl) {
+  rotate(dAz: number, dEl: number): void {
     this.azimuth += dAz;
     this.elevation += dEl;
     const m = Math.PI / 2 - 0.01;
     this.elevation = Math.max(-m, Math.min(m, this.elevation));
     this.isDirty = true;
   }
-  zoom(d) {
+  zoom(d: number): void {
     this.distance += d;
     this.distance = Math.max(0.5, Math.min(20.0, this.distance));
     this.isDirty = true;
   }
-  pan(deltaX, deltaY) { // :61-83 with gl-matrix's vec3 semantics (every result stored in a Float32Array)
+  pan(deltaX: number, deltaY: number): void { // :61-83 with gl-matrix's vec3 semantics (every result stored in a Float32Array)
     const f32 = (x, y, z) => new Float32Array([x, y, z]);
     const normalize = (a) => {
       let len = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
@@ -499,11 +586,11 @@ class Camera {
     this.target = f32(this.target[0] + offset[0], this.target[1] + offset[1], this.target[2] + offset[2]);
     this.isDirty = true;
   }
-  getCameraPosition() {
+  getCameraPosition(): Float32Array {
     const x = this.distance * Math.cos(this.elevation) * Math.sin(this.azimuth), y = this.distance * Math.sin(this.elevation), z = this.distance * Math.cos(this.elevation) * Math.cos(this.azimuth);
     return new Float32Array([this.target[0] + x, this.target[1] + y, this.target[2] + z]);
   }
-  updateMatrices() {
+  updateMatrices(): void {
     if (!this.isDirty) return;
     const eye = this.getCameraPosition();
     this.cameraPosition = eye;
@@ -533,15 +620,15 @@ class Camera {
     for (let c = 0; c < 4; c++) for (let k = 0; k < 4; k++) out[c * 4 + k] = view[c * 4] * proj[k] + view[c * 4 + 1] * proj[4 + k] + view[c * 4 + 2] * proj[8 + k] + view[c * 4 + 3] * proj[12 + k];
     this.isDirty = false;
   }
-  getViewProjectionMatrix() {
+  getViewProjectionMatrix(): Float32Array {
     this.updateMatrices();
     return this.viewProjectionMatrix;
   }
-  getPosition() {
+  getPosition(): Float32Array {
     this.updateMatrices();
     return this.cameraPosition;
   }
-  uniforms(width, height, time = 0) {
+  uniforms(width: number, height: number, time: number = 0): Float32Array {
     const u = new Float32Array(22);
     u.set(this.getViewProjectionMatrix(), 0);
     u.set(this.getPosition(), 16);
@@ -558,7 +645,7 @@ class Camera {
 // src/sdf/Primitive.ts:283-290 AS WRITTEN: centre = min + max / 2 (vec3.scaleAndAdd(_, min, max, 1 / 2)), not the midpoint — kept, so
 // that seeding boxes equal the reference's; plain arrays, i.e. double precision (held to an execution of the reference's
 // statements: tests/golden/ref_host.json)
-function scaleAABB(aabb, scale) {
+function scaleAABB(aabb: [ArrayLike<number>, ArrayLike<number>], scale: number): [Float32Array, Float32Array] {
   const min = [0, 0, 0];
   const max = [0, 0, 0];
   for (let k = 0; k < 3; k++) {
@@ -571,10 +658,17 @@ function scaleAABB(aabb, scale) {
 }
 
 class PointManager {
+  declare device: Device;
+  declare scene: SDFScene;
+  declare seed: number;
+  declare positions: Float32Array | null;
+  declare numPoints: number;
+  declare buffers: Buffer_[];
+  declare current: number;
   // (device, Float32Array of vec4 positions) | (device, { numPoints, seed }) | (device, SDFScene[, seed]): the reference's constructor —
   // point count from the primitives' surface areas (src/PointManager.ts:22-39), a fresh cloud on the faces of the scene's scaled box
   // at every reinitialize() (:96-189, :220-231), drawn on the device (native.sdf_seed_positions: point i a pure function of (seed, i))
-  constructor(device, scene, seed = 0) {
+  constructor(device: Device, scene: Float32Array | { numPoints: number; seed?: number } | SDFScene, seed: number = 0) {
     this.device = device;
     this.scene = null;
     this.seed = seed;
@@ -614,7 +708,7 @@ class PointManager {
   }
   // the box PointManager seeds on (:96-107): the primitives' AABBs merged, scaled 1.5x by the reference's scaleAABB AS WRITTEN
   // (centre = min + max / 2: src/sdf/Primitive.ts:283-290), in double precision, then rounded to float32
-  seedingBox() {
+  seedingBox(): [Float32Array, Float32Array] {
     const mn = [Infinity, Infinity, Infinity], mx = [-Infinity, -Infinity, -Infinity];
     for (const p of this.scene.getPrimitives()) {
       const [a, b] = p.getAABB();
@@ -627,13 +721,13 @@ class PointManager {
     return [Float32Array.from(scaled.min), Float32Array.from(scaled.max)];
   }
   // :22-39: floor(30000 sqrt(area)) per primitive, clamped to [10000, 200000]; 50000 for a scene without primitives
-  static calculatePointCount(scene) {
+  static calculatePointCount(scene: SDFScene): number {
     const prims = scene.getPrimitives();
     if (prims.length === 0) return 50000;
     const total = prims.reduce((t, p) => t + Math.floor(30000 * Math.sqrt(p.getSurfaceArea())), 0);
     return Math.max(10000, Math.min(total, 200000));
   }
-  reinitialize() { // :220-231
+  reinitialize(): void { // :220-231
     if (this.scene) {
       const [lo, hi] = this.seedingBox();
       native.sdf_seed_positions(this.device.ctx, lo, hi, this.numPoints, this.seed++, this.buffers[this.current].ptr);
@@ -641,11 +735,11 @@ class PointManager {
     }
     this.buffers[this.current].write(this.positions);
   }
-  getCurrentPositionBuffer() { return this.buffers[this.current]; }     // :233-235
-  getNextPositionBuffer() { return this.buffers[1 - this.current]; }    // :236-238
-  swap() { this.current = 1 - this.current; }                           // :240-242
-  getNumPoints() { return this.numPoints; }                             // :244-246
-  destroy() { this.buffers.forEach((b) => b.destroy()); }              // :248-252
+  getCurrentPositionBuffer(): Buffer_ { return this.buffers[this.current]; }     // :233-235
+  getNextPositionBuffer(): Buffer_ { return this.buffers[1 - this.current]; }    // :236-238
+  swap(): void { this.current = 1 - this.current; }                           // :240-242
+  getNumPoints(): number { return this.numPoints; }                             // :244-246
+  destroy(): void { this.buffers.forEach((b) => b.destroy()); }              // :248-252
 }
 
 /** SDF splat generation (src/sdf/{Primitive,Operation,Scene}.ts, src/GradientSampler.ts, src/PositionUpdater.ts,
@@ -657,92 +751,106 @@ let nextPrimId = 0, nextSminId = 0;
 // a primitive's box (src/sdf/Primitive.ts: getAABB): position -/+ extent in double precision, rounded to float32 like the reference's vec3
 const aabb = (p, e) => [Float32Array.from([p[0] - e[0], p[1] - e[1], p[2] - e[2]]), Float32Array.from([p[0] + e[0], p[1] + e[1], p[2] + e[2]])];
 class Primitive {
-  constructor(id, position) {
+  declare id: string;
+  declare position: any;
+  constructor(id: string, position: ArrayLike<number>) {
     this.id = id || `prim_${nextPrimId++}`;
     this.position = Float32Array.from(position || [0, 0, 0]);
   }
 }
 class Sphere extends Primitive {
-  constructor(p = {}) {
+  declare radius: number;
+  constructor(p: { id?: string; position?: ArrayLike<number>; radius?: number } = {}) {
     super(p.id, p.position);
     this.radius = p.radius === undefined ? 0.5 : p.radius;
   }
-  getType() { return 'sphere'; }
-  getParamNames() { return [`${this.id}_center`, `${this.id}_radius`]; }
-  getParamValues() { return [...this.position, this.radius]; }
-  getSurfaceArea() { return 4 * Math.PI * this.radius * this.radius; }
-  instr() { return [SDF.sphere, ...this.position, this.radius]; }
-  getAABB() { return aabb(this.position, [this.radius, this.radius, this.radius]); }
+  getType(): string { return 'sphere'; }
+  getParamNames(): string[] { return [`${this.id}_center`, `${this.id}_radius`]; }
+  getParamValues(): number[] { return [...this.position, this.radius]; }
+  getSurfaceArea(): number { return 4 * Math.PI * this.radius * this.radius; }
+  instr(): number[] { return [SDF.sphere, ...this.position, this.radius]; }
+  getAABB(): [Float32Array, Float32Array] { return aabb(this.position, [this.radius, this.radius, this.radius]); }
 }
 class Box extends Primitive {
-  constructor(p = {}) {
+  declare size: Float32Array;
+  constructor(p: { id?: string; position?: ArrayLike<number>; size?: ArrayLike<number> } = {}) {
     super(p.id, p.position);
     this.size = Float32Array.from(p.size || [0.5, 0.5, 0.5]);
   }
-  getType() { return 'box'; }
-  getParamNames() { return [`${this.id}_center`, `${this.id}_size`]; }
-  getParamValues() { return [...this.position, 0, ...this.size, 0]; }
-  getSurfaceArea() {
+  getType(): string { return 'box'; }
+  getParamNames(): string[] { return [`${this.id}_center`, `${this.id}_size`]; }
+  getParamValues(): number[] { return [...this.position, 0, ...this.size, 0]; }
+  getSurfaceArea(): number {
     const w = this.size[0] * 2, h = this.size[1] * 2, d = this.size[2] * 2;
     return 2 * (w * h + w * d + h * d);
   }
-  instr() { return [SDF.box, ...this.position, ...this.size]; }
-  getAABB() { return aabb(this.position, this.size); }
+  instr(): number[] { return [SDF.box, ...this.position, ...this.size]; }
+  getAABB(): [Float32Array, Float32Array] { return aabb(this.position, this.size); }
 }
 class Torus extends Primitive {
-  constructor(p = {}) {
+  declare majorRadius: number;
+  declare minorRadius: number;
+  constructor(p: { id?: string; position?: ArrayLike<number>; majorRadius?: number; minorRadius?: number } = {}) {
     super(p.id, p.position);
     this.majorRadius = p.majorRadius === undefined ? 0.5 : p.majorRadius;
     this.minorRadius = p.minorRadius === undefined ? 0.2 : p.minorRadius;
   }
-  getType() { return 'torus'; }
-  getParamNames() { return [`${this.id}_center`, `${this.id}_radii`]; }
-  getParamValues() { return [...this.position, 0, this.majorRadius, this.minorRadius, 0, 0]; }
-  getSurfaceArea() { return 4 * Math.PI * Math.PI * this.majorRadius * this.minorRadius; }
-  instr() { return [SDF.torus, ...this.position, this.majorRadius, this.minorRadius]; }
-  getAABB() { return aabb(this.position, [this.majorRadius + this.minorRadius, this.minorRadius, this.majorRadius + this.minorRadius]); }
+  getType(): string { return 'torus'; }
+  getParamNames(): string[] { return [`${this.id}_center`, `${this.id}_radii`]; }
+  getParamValues(): number[] { return [...this.position, 0, this.majorRadius, this.minorRadius, 0, 0]; }
+  getSurfaceArea(): number { return 4 * Math.PI * Math.PI * this.majorRadius * this.minorRadius; }
+  instr(): number[] { return [SDF.torus, ...this.position, this.majorRadius, this.minorRadius]; }
+  getAABB(): [Float32Array, Float32Array] { return aabb(this.position, [this.majorRadius + this.minorRadius, this.minorRadius, this.majorRadius + this.minorRadius]); }
 }
 class Capsule extends Primitive {
-  constructor(p = {}) {
+  declare height: number;
+  declare radius: number;
+  constructor(p: { id?: string; position?: ArrayLike<number>; height?: number; radius?: number } = {}) {
     super(p.id, p.position);
     this.height = p.height === undefined ? 1.0 : p.height;
     this.radius = p.radius === undefined ? 0.3 : p.radius;
   }
-  getType() { return 'capsule'; }
-  getParamNames() { return [`${this.id}_center`, `${this.id}_params`]; }
-  getParamValues() { return [...this.position, 0, this.height, this.radius, 0, 0]; }
-  getSurfaceArea() { return 2 * Math.PI * this.radius * this.height + 4 * Math.PI * this.radius * this.radius; }
-  instr() { return [SDF.capsule, ...this.position, this.height, this.radius]; }
-  getAABB() { return aabb(this.position, [this.radius, this.height / 2 + this.radius, this.radius]); }
+  getType(): string { return 'capsule'; }
+  getParamNames(): string[] { return [`${this.id}_center`, `${this.id}_params`]; }
+  getParamValues(): number[] { return [...this.position, 0, this.height, this.radius, 0, 0]; }
+  getSurfaceArea(): number { return 2 * Math.PI * this.radius * this.height + 4 * Math.PI * this.radius * this.radius; }
+  instr(): number[] { return [SDF.capsule, ...this.position, this.height, this.radius]; }
+  getAABB(): [Float32Array, Float32Array] { return aabb(this.position, [this.radius, this.height / 2 + this.radius, this.radius]); }
 }
 class Operation {
-  constructor(type, params = []) {
+  declare type: string;
+  declare params: number[];
+  constructor(type: string, params: number[] = []) {
     this.type = type;
     this.params = params;
   }
-  getType() { return this.type; }
-  getParamNames() { return []; }
-  getParamValues() { return this.params; }
+  getType(): string { return this.type; }
+  getParamNames(): string[] { return []; }
+  getParamValues(): number[] { return this.params; }
 }
 class SmoothUnion extends Operation {
-  constructor(k = 0.1) {
+  declare k: number;
+  declare id: string;
+  constructor(k: number = 0.1) {
     super('smooth_union', [k]);
     this.k = k;
     this.id = `smin_${nextSminId++}`;
   }
-  getParamNames() { return [`${this.id}_k`]; }
-  getParamValues() { return [this.k]; }
+  getParamNames(): string[] { return [`${this.id}_k`]; }
+  getParamValues(): number[] { return [this.k]; }
 }
 const primitive = (p) => (p && p.type === 'primitive') || (p && p.type === 'operation') ? p : { type: 'primitive', primitive: p };
 const binary = (op, a, b) => ({ type: 'operation', operation: op, children: [primitive(a), primitive(b)] });
 const union = (a, b) => binary(new Operation('union'), a, b), intersection = (a, b) => binary(new Operation('intersection'), a, b);
 const subtraction = (a, b) => binary(new Operation('subtraction'), a, b), smoothUnion = (k, a, b) => binary(new SmoothUnion(k), a, b);
 class SDFScene { // src/sdf/Scene.ts:72-152
+  declare root: SceneNode | null;
+  declare primitiveMap: any;
   constructor() {
     this.root = null;
     this.primitiveMap = new Map();
   }
-  setRoot(node) {
+  setRoot(node: Primitive | SceneNode): void {
     this.root = primitive(node);
     this.primitiveMap.clear();
     const walk = (n) => {
@@ -751,10 +859,10 @@ class SDFScene { // src/sdf/Scene.ts:72-152
     };
     walk(this.root);
   }
-  get(id) { return this.primitiveMap.get(id); }
-  getPrimitives() { return Array.from(this.primitiveMap.values()); }
-  getRoot() { return this.root; }
-  getOperations() {
+  get(id: string): Primitive | undefined { return this.primitiveMap.get(id); }
+  getPrimitives(): Primitive[] { return Array.from(this.primitiveMap.values()); }
+  getRoot(): SceneNode | null { return this.root; }
+  getOperations(): unknown[] {
     const ops = [];
     const walk = (n) => {
       if (n.type === 'operation') {
@@ -765,11 +873,11 @@ class SDFScene { // src/sdf/Scene.ts:72-152
     if (this.root) walk(this.root);
     return ops;
   }
-  getStructureHash() {
+  getStructureHash(): string {
     const walk = (n) => (n.type === 'primitive' ? `P:${n.primitive.getType()}:${n.primitive.id}` : `O:${n.operation.getType()}:(${n.children.map(walk).join(',')})`);
     return this.root ? walk(this.root) : '';
   }
-  program() { // Float32Array, 8 floats per instruction: [op, a0..a6]
+  program(): Float32Array { // Float32Array, 8 floats per instruction: [op, a0..a6]
     const rows = [];
     const walk = (n) => {
       if (n.type === 'primitive') rows.push(n.primitive.instr());
@@ -785,54 +893,64 @@ class SDFScene { // src/sdf/Scene.ts:72-152
   }
 }
 class SceneStage {
-  constructor(device, scene, numPoints) {
+  declare device: Device;
+  declare scene: SDFScene;
+  declare numPoints: number;
+  declare currentStructureHash: any;
+  declare program: Float32Array;
+  constructor(device: Device, scene: SDFScene, numPoints: number) {
     this.device = device;
     this.scene = scene;
     this.numPoints = numPoints;
     this.currentStructureHash = scene.getStructureHash();
     this.updateSceneParameters();
   }
-  updateSceneParameters() { this.program = this.scene.program(); }
-  rebuildIfNeeded() {
+  updateSceneParameters(): void { this.program = this.scene.program(); }
+  rebuildIfNeeded(): void {
     const h = this.scene.getStructureHash();
     if (h !== this.currentStructureHash) {
       this.currentStructureHash = h;
       this.updateSceneParameters();
     }
   }
-  getScene() { return this.scene; }
+  getScene(): SDFScene { return this.scene; }
 }
 class GradientSampler extends SceneStage { // src/GradientSampler.ts
-  constructor(device, scene, numPoints) {
+  declare gradientBuffer: Buffer_ | null;
+  constructor(device: Device, scene: SDFScene, numPoints: number) {
     super(device, scene, numPoints);
     this.gradientBuffer = device.createBuffer(numPoints * 16);
   }
-  evaluateGradients(commandEncoder, uniformBuffer, positionBuffer) { native.sdf_gradients(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.gradientBuffer.ptr); }
-  getGradientBuffer() { return this.gradientBuffer; }
-  destroy() { this.gradientBuffer.destroy(); }
+  evaluateGradients(commandEncoder: CommandEncoder | null, uniformBuffer: Buffer_ | null, positionBuffer: Buffer_): void { native.sdf_gradients(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.gradientBuffer.ptr); }
+  getGradientBuffer(): Buffer_ { return this.gradientBuffer; }
+  destroy(): void { this.gradientBuffer.destroy(); }
 }
 class PositionUpdater { // src/PositionUpdater.ts
-  constructor(device, shaderCode, numPoints) {
+  declare device: Device;
+  declare numPoints: number;
+  constructor(device: Device, shaderCode: string | null, numPoints: number) {
     this.device = device;
     this.numPoints = numPoints;
   }
-  updatePositions(commandEncoder, uniformBuffer, currentPositionBuffer, gradientBuffer, nextPositionBuffer) { native.sdf_update_positions(this.device.ctx, currentPositionBuffer.ptr, gradientBuffer.ptr, this.numPoints, nextPositionBuffer.ptr); }
+  updatePositions(commandEncoder: CommandEncoder | null, uniformBuffer: Buffer_ | null, currentPositionBuffer: Buffer_, gradientBuffer: Buffer_, nextPositionBuffer: Buffer_): void { native.sdf_update_positions(this.device.ctx, currentPositionBuffer.ptr, gradientBuffer.ptr, this.numPoints, nextPositionBuffer.ptr); }
 }
 class CurvatureSampler extends SceneStage { // src/CurvatureSampler.ts
-  constructor(device, scene, numPoints) {
+  declare scaleFactorsBuffer: Buffer_ | null;
+  declare curvatureBuffer: Buffer_ | null;
+  constructor(device: Device, scene: SDFScene, numPoints: number) {
     super(device, scene, numPoints);
     this.scaleFactorsBuffer = device.createBuffer(numPoints * 4);
     this.curvatureBuffer = null;
   }
-  computeScaleFactors(commandEncoder, positionBuffer) { native.sdf_scale_factors(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.scaleFactorsBuffer.ptr); }
-  getScaleFactorsBuffer() { return this.scaleFactorsBuffer; }
+  computeScaleFactors(commandEncoder: CommandEncoder | null, positionBuffer: Buffer_): void { native.sdf_scale_factors(this.device.ctx, this.program, positionBuffer.ptr, this.numPoints, this.scaleFactorsBuffer.ptr); }
+  getScaleFactorsBuffer(): Buffer_ { return this.scaleFactorsBuffer; }
   // vec4(normal, scaleFactor): the curvatureData buffer SplatPropertyManager.updateFromCurvature binds (the reference's samplers write its halves apart)
-  getCurvatureBuffer(gradientBuffer) {
+  getCurvatureBuffer(gradientBuffer: Buffer_): Buffer_ {
     if (!this.curvatureBuffer) this.curvatureBuffer = this.device.createBuffer(this.numPoints * 16);
     native.sdf_curvature(this.device.ctx, gradientBuffer.ptr, this.scaleFactorsBuffer.ptr, this.numPoints, this.curvatureBuffer.ptr);
     return this.curvatureBuffer;
   }
-  destroy() {
+  destroy(): void {
     this.scaleFactorsBuffer.destroy();
     if (this.curvatureBuffer) this.curvatureBuffer.destroy();
   }
@@ -842,7 +960,16 @@ class CurvatureSampler extends SceneStage { // src/CurvatureSampler.ts
  * Camera.rotate / pan / zoom.  `canvas` is anything with addEventListener(type, handler) (a DOM canvas, a Node
  * EventEmitter adapter) or null: without one, feed the handlers synthetic events {clientX, clientY, button, deltaY}. */
 class OrbitCameraController {
-  constructor(camera, canvas = null) {
+  declare camera: Camera;
+  declare canvas: any;
+  declare isDragging: boolean;
+  declare dragButton: any;
+  declare lastMouseX: any;
+  declare lastMouseY: any;
+  declare rotationSpeed: any;
+  declare panSpeed: any;
+  declare zoomSpeed: any;
+  constructor(camera: Camera, canvas: { addEventListener(type: string, handler: (e: PointerLikeEvent) => void, options?: unknown): void } | null = null) {
     this.camera = camera;
     this.canvas = canvas;
     this.isDragging = false; // :7
@@ -854,7 +981,7 @@ class OrbitCameraController {
     this.zoomSpeed = 0.001; // :14
     this.setupEventListeners();
   }
-  setupEventListeners() { // :23-33
+  setupEventListeners(): void { // :23-33
     if (!this.canvas || typeof this.canvas.addEventListener !== 'function') return;
     this.canvas.addEventListener('mousedown', this.onMouseDown.bind(this));
     this.canvas.addEventListener('mousemove', this.onMouseMove.bind(this));
@@ -862,13 +989,13 @@ class OrbitCameraController {
     this.canvas.addEventListener('wheel', this.onWheel.bind(this), { passive: false });
     this.canvas.addEventListener('contextmenu', (e) => e.preventDefault());
   }
-  onMouseDown(event) { // :35-40
+  onMouseDown(event: PointerLikeEvent): void { // :35-40
     this.isDragging = true;
     this.dragButton = event.button;
     this.lastMouseX = event.clientX;
     this.lastMouseY = event.clientY;
   }
-  onMouseMove(event) { // :42-58
+  onMouseMove(event: PointerLikeEvent): void { // :42-58
     if (!this.isDragging) return;
     const dx = event.clientX - this.lastMouseX;
     const dy = event.clientY - this.lastMouseY;
@@ -880,16 +1007,16 @@ class OrbitCameraController {
     this.lastMouseX = event.clientX;
     this.lastMouseY = event.clientY;
   }
-  onMouseUp(_event) { // :60-63
+  onMouseUp(_event?: PointerLikeEvent): void { // :60-63
     this.isDragging = false;
     this.dragButton = -1;
   }
-  onWheel(event) { // :65-70
+  onWheel(event: PointerLikeEvent): void { // :65-70
     if (event.preventDefault) event.preventDefault();
     const delta = event.deltaY * this.zoomSpeed;
     this.camera.zoom(delta);
   }
-  destroy() {} // :72-74
+  destroy(): void {} // :72-74
 }
 
 /** The render loop of src/main.ts:110-193 for the tile-raster path, without a browser: per frame the camera's uniform
@@ -897,7 +1024,13 @@ class OrbitCameraController {
  * (sync-free after the first); a frame's pixels are read only when asked for.  splat_renderer_amd/frameloop.py is the
  * same loop in Python: the two give the same images byte for byte (tests/test_napi.py). */
 class FrameLoop {
-  constructor(device, numPoints, width, height, tileSize = 16, camera = null, rendererOptions = {}) {
+  declare device: Device;
+  declare width: number;
+  declare height: number;
+  declare camera: Camera;
+  declare renderer: Renderer;
+  declare frame: number;
+  constructor(device: Device, numPoints: number, width: number, height: number, tileSize: number = 16, camera: Camera | null = null, rendererOptions: { footprint?: Footprint; records?: "lit" | "projected" } = {}) {
     this.device = device;
     this.width = width;
     this.height = height;
@@ -907,37 +1040,41 @@ class FrameLoop {
     this.frame = 0;
   }
   // one frame with the camera as it stands; returns the output buffer (pixels stay on the device)
-  render(propertyBuffer, normalsBuffer, time) {
+  render(propertyBuffer: Buffer_ | PropertyPlanes, normalsBuffer: Buffer_, time?: number): Buffer_ {
     const t = time === undefined ? this.frame / 60.0 : time;
     const out = this.renderer.render(this.camera.uniforms(this.width, this.height, t), propertyBuffer, normalsBuffer, null, this.width, this.height);
     this.frame += 1;
     return out;
   }
-  readPixels() { return this.renderer.readPixels(); }
+  readPixels(): Uint8Array { return this.renderer.readPixels(); }
   // `frames` frames of a full orbit (Camera.rotate by 2 pi / frames after each); onFrame(k, rgba8) gets every frame's pixels
-  turntable(propertyBuffer, normalsBuffer, frames, onFrame) {
+  turntable(propertyBuffer: Buffer_ | PropertyPlanes, normalsBuffer: Buffer_, frames: number, onFrame?: (k: number, rgba8: Uint8Array) => void): void {
     for (let k = 0; k < frames; k++) {
       this.render(propertyBuffer, normalsBuffer);
       if (onFrame) onFrame(k, this.readPixels());
       this.camera.rotate((2.0 * Math.PI) / frames, 0.0);
     }
   }
-  destroy() { this.renderer.destroy(); }
+  destroy(): void { this.renderer.destroy(); }
 }
 
 /** The multi-GPU frame's exchange (no reference counterpart: the reference is single-device): one process per GPU, an
  * RCCL communicator behind the C ABI.  Rank 0 calls Comm.uniqueId() and hands the 128 bytes to the other ranks by
  * any channel (a file, a socket, an environment variable); every rank then constructs Comm with the same bytes. */
 class Comm {
-  static uniqueId() { return new Uint8Array(native.comm_unique_id()); }
-  constructor(device, rank, world, idBytes) {
+  declare device: Device;
+  declare rank: number;
+  declare world: number;
+  declare handle: unknown;
+  static uniqueId(): Uint8Array { return new Uint8Array(native.comm_unique_id()); }
+  constructor(device: Device, rank: number, world: number, idBytes: Uint8Array) {
     this.device = device;
     this.rank = rank;
     this.world = world;
     this.handle = native.comm_init(device.ctx, rank, world, idBytes);
   }
-  allGather(shardBuffer, gatheredBuffer, bytesPerRank) { native.allgather_records(this.device.ctx, this.handle, shardBuffer.ptr, gatheredBuffer.ptr, bytesPerRank); }
-  destroy() {
+  allGather(shardBuffer: Buffer_, gatheredBuffer: Buffer_, bytesPerRank: number): void { native.allgather_records(this.device.ctx, this.handle, shardBuffer.ptr, gatheredBuffer.ptr, bytesPerRank); }
+  destroy(): void {
     if (this.handle) native.comm_destroy(this.handle);
     this.handle = null;
   }
@@ -948,7 +1085,23 @@ class Comm {
  * gathered records.  render() returns the full-size image buffer of which this rank owns pixel rows pixelRows().
  * Everything is enqueued on the device's stream: no host synchronisation inside a frame. */
 class BandRenderer {
-  constructor(device, comm, numPoints, width, height, tileSize = 16) {
+  declare device: Device;
+  declare comm: Comm | null;
+  declare numPoints: number;
+  declare width: number;
+  declare height: number;
+  declare tileSize: number;
+  declare per: any;
+  declare first: any;
+  declare count: any;
+  declare row0: number;
+  declare row1: number;
+  declare sorter: RadixSorter;
+  declare binner: GPUTileBinner;
+  declare shard: any;
+  declare gathered: any;
+  declare output: Buffer_ | null;
+  constructor(device: Device, comm: Comm | null, numPoints: number, width: number, height: number, tileSize: number = 16) {
     this.device = device;
     this.comm = comm;
     this.numPoints = numPoints;
@@ -971,7 +1124,7 @@ class BandRenderer {
     this.output = device.createBuffer(width * height * 4);
     this.output.zero();
   }
-  render(uniformData, propertyBuffer, normalsBuffer) {
+  render(uniformData: Float32Array | Buffer_, propertyBuffer: Buffer_, normalsBuffer: Buffer_): Buffer_ {
     const u = uniformFloats(uniformData), d = this.device, world = this.comm ? this.comm.world : 1;
     native.project_slice_compact(d.ctx, u, propertyBuffer.ptr, 2, this.first, this.count, this.shard.ptr);
     if (world > 1) this.comm.allGather(this.shard, this.gathered, this.per * 16);
@@ -980,13 +1133,13 @@ class BandRenderer {
       this.width, this.height, this.output.ptr, null);
     return this.output;
   }
-  settle() { return native.band_settle(this.device.ctx, this.sorter.handle, this.binner.handle); }
-  pixelRows() { return [this.row0 * this.tileSize, Math.min(this.row1 * this.tileSize, this.height)]; }
-  readPixels() {
+  settle(): number { return native.band_settle(this.device.ctx, this.sorter.handle, this.binner.handle); }
+  pixelRows(): [number, number] { return [this.row0 * this.tileSize, Math.min(this.row1 * this.tileSize, this.height)]; }
+  readPixels(): Uint8Array {
     this.settle();
     return this.output.read(new Uint8Array(this.width * this.height * 4));
   }
-  destroy() {
+  destroy(): void {
     this.sorter.destroy();
     this.binner.destroy();
     this.shard.destroy();

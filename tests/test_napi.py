@@ -283,3 +283,24 @@ console.log(JSON.stringify({ bad, ops }));
     ref = _ref_host()
     for name, ops in d["ops"].items():
         assert ops == [code[k] for k, _ in _emitted(ref["outputs"]["scenes"][name]["wgsl"])], name
+
+
+def test_index_js_is_the_stripped_twin_of_index_ts():
+    """The host is authored as TypeScript with erasable syntax only (napi/index.ts: `declare` fields, `type` / `interface`
+    statements, annotations in function and member headers — SURVEY §7 step 2); the file Node loads is its mechanical twin.
+    The committed index.js must be exactly `node strip_types.js index.ts`, and the stripped text must be free of the
+    syntax the stripper claims to erase."""
+    r = subprocess.run([NODE, "strip_types.js", "index.ts"], cwd=NAPI, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    with open(os.path.join(NAPI, "index.js")) as f:
+        committed = f.read()
+    assert r.stdout == committed, "index.js is stale: run `node strip_types.js index.ts > index.js` in splat_renderer_amd/napi"
+    ts = open(os.path.join(NAPI, "index.ts")).read()
+    assert ts.count("\n  declare ") > 100 and "interface PropertyPlanes" in ts and "): Buffer_ {" in ts  # (it IS annotated)
+    for line in committed.split("\n"):
+        assert not line.strip().startswith(("declare ", "interface ", "type ")), line
+    # every annotated header of index.ts appears in index.js with the same name and arity
+    import re
+    heads_ts = re.findall(r"^  (?:static |get |set )?(\w+)(?:<[^>]*>)?\(", ts, flags=re.M)
+    heads_js = re.findall(r"^  (?:static |get |set )?(\w+)\(", committed, flags=re.M)
+    assert heads_ts == heads_js
