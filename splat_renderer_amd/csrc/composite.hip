@@ -467,6 +467,7 @@ __device__ __forceinline__ void px_unpack(const CompositeParams &p, const PxRaw 
     }
 }
 
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 constexpr int PXC = 32;     // entries per chunk = bits of a lane's queue
 constexpr int PX_ROW = 35;  // float2 slots per table row: the idle slot, 32 entries, 2 of padding — rows 3 slots apart (mod 32),
                             // so the eight rows a wave reads for ONE entry fall into eight different bank pairs of a ds_read_b64
@@ -641,18 +642,34 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
 #ifdef PX_PROFILE
                 if (__ballot(rad > 1e30f || colr.x > 1e30f) == 0) { pb_fetch += __builtin_amdgcn_s_memtime() - pf0; pb_chunks++; } // (forces the loads' arrival)
 #endif
+#ifdef PX_BOTH_SPANS // (round 3's first form: every lane computes both axes' spans; measuring knob)
                 if (cb0 + e < count && !(rad < 0.5f)) { // :127-129 "too small"
                     const uint32_t xm = span_mask16(b.x, b.z, tile_cx), ym = span_mask16(b.y, b.w, tile_cy);
                     if (xm != 0 && ym != 0) {
-                        // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r
-                        // (:133-140), in tile-local coordinates (as k_composite)
-                        // (v_rcp_f32, 1 ulp: the correctly rounded quotient costs ten instructions on this wave's path)
                         k = 1.6986436005760381f * __builtin_amdgcn_rcpf(rad);
                         const float lx = (b.x + b.z) * 0.5f - tile_x0, ly = (b.y + b.w) * 0.5f - tile_y0; // :124, then exact
                         ck = (h ? ly : lx) * k;
                         m16 = h ? ym : xm;
                     }
                 }
+#else
+                {
+                    // this lane's axis only: its span of covered pixel columns (rows); the other axis's comes from the partner
+                    // lane (e, 1 - h) — v_permlane32_swap, one instruction — because an entry that misses the tile on EITHER
+                    // axis draws nothing in it (ComputeShaderRenderer.ts:118-121)
+                    const float lo = h ? b.y : b.x, hi = h ? b.w : b.z;
+                    uint32_t own = span_mask16(lo, hi, h ? tile_cy : tile_cx);
+                    if (!(cb0 + e < count) || rad < 0.5f) own = 0; // past the list's end; :127-129 "too small"
+                    const v2u sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);
+                    const uint32_t other = h ? sw.x : sw.y;
+                    m16 = other ? own : 0u;
+                    // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r (:133-140), in
+                    // tile-local coordinates (as k_composite); v_rcp_f32, 1 ulp: the correctly rounded quotient costs ten
+                    // instructions on this wave's path.  (An entry that draws nothing has an all-zero mask: its k is never seen.)
+                    k = 1.6986436005760381f * __builtin_amdgcn_rcpf(rad);
+                    ck = ((lo + hi) * 0.5f - (h ? tile_y0 : tile_x0)) * k; // :124, then exact
+                }
+#endif
                 if (h == 0) B.col[1 + e] = make_float4(colr.x, colr.y, colr.z, 1.0f); // (.w = 1: the factor of T's update, see PX_BLEND)
 #pragma unroll
                 for (int c2 = 0; c2 < 8; ++c2) {
@@ -661,8 +678,12 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                     const v2f q = t * t;
                     // (the box test — ComputeShaderRenderer.ts:118-121, exact: span_mask16 — as a bit mask on the value:
                     // v_bfe_i32 spreads the coverage bit over the word)
-                    const uint32_t g0 = __float_as_uint(__builtin_amdgcn_exp2f(-q.x)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2, 1);
-                    const uint32_t g1 = __float_as_uint(__builtin_amdgcn_exp2f(-q.y)) & (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2 + 1, 1);
+                    uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2, 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2 + 1, 1);
+#ifndef PX_MASK_SELECT
+                    asm volatile("" : "+v"(k0), "+v"(k1)); // (kept as v_bfe_i32 + v_and: left alone the compiler makes it and + compare + select)
+#endif
+                    const uint32_t g0 = __float_as_uint(__builtin_amdgcn_exp2f(-q.x)) & k0;
+                    const uint32_t g1 = __float_as_uint(__builtin_amdgcn_exp2f(-q.y)) & k1;
                     B.t[h * 8 + c2][1 + e] = make_float2(__uint_as_float(g0), __uint_as_float(g1));
                 }
                 // queue words: one ballot gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 the y mask)
