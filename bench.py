@@ -52,7 +52,7 @@ def per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, lit, disc):
          (88 if lit else 72 if disc else 56) * n, "B/splat: 16 pos/radius (+ 32 colour, normal) read; 32-byte record + 4 key + 4 range written"),
         ("bin_scatter", "k_tf_scatter (pair expansion fused with the first tile-id sort pass)", 8 * n + 9 * pairs,
          "8 B/splat read (key, range) + 9 B/pair written (1 B high tile digit, 8 B key+index)"),
-        ("bin_second_pass", "k_tf_upsweep2 + k_radix_rowscan + k_tf_downsweep2 + k_tf_offsets", 18 * pairs, "1 + 9 B/pair read, 8 B/pair written"),
+        ("bin_second_pass", "k_tf_upsweep2 + k_radix_rowscan + k_tf_downsweep2 (incl. the tile offsets)", 18 * pairs, "1 + 9 B/pair read, 8 B/pair written"),
         ("bin_tile_sort", "k_tile_sort x2 (PerTileSorter; also checks every list's order)", 12 * pairs, "8 B/pair read, 4 B/pair (index list) written"),
         ("composite", "k_composite_px / k_composite", composite_alg_bytes(p_used, width, height), "SURVEY 8d: 68 B x consumed entry + 4 B x pixel"),
     ]

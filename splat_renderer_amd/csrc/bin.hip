@@ -416,7 +416,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         const bool primary = tf_hi_bits == 0;
         stage_begin(ctx, SPLAT_STAGE_BIN_PASS2);
         rc = tf_second_pass_launch(ctx, b->tf_hi, b->wide_a, b->wide_b, &b->tf_runs, total32, tiles, tf_lo_bits, tf_hi_bits, b->tf2_hist,
-                                   b->offsets, b->d_total, nullptr, 0u);
+                                   b->offsets, b->d_total);
         stage_end(ctx, SPLAT_STAGE_BIN_PASS2);
         if (rc != SPLAT_OK) return rc;
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array

@@ -236,8 +236,7 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
                       uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs,
                       uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq);
 int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in, uint2 *val_out, const TfRuns *runs, uint32_t pairs_bound,
-                          uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total,
-                          uint32_t *report, uint32_t seq);
+                          uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
                      uint32_t *counts, uint32_t *frame_flags); // frame_flags: FRAME_FLAG_ORDER is raised if a list fails the order check

@@ -18,7 +18,8 @@
 //   k_tf_scatter    expansion fused with the first sort pass      N*8 B read, P*9 B written
 //   k_tf_upsweep2 / k_radix_rowscan / k_tf_downsweep2
 //                   second (high digit) pass, 8-byte payload      P*(1 + 9 + 8) B
-//   k_tf_offsets    tile offsets from the second pass's scanned histogram (no search, no sorted tile ids)
+//                   + tile offsets from the second pass's scanned histogram (no search, no sorted tile ids): the
+//                   downsweep launch's last workgroups (tf_offsets_block)
 //   k_tile_sort     per tile: LSD radix on (key - tile min key)    P*8 B read, P*4 B written
 #include "common.h"
 #include "tile_range.h"
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__
                 runs.part_digit[first_part + j] = (uint8_t)tid;
         if (tid == 255) *runs.parts = (align_m1 && fits) ? (run_start + digit_room) / (align_m1 + 1u) : 0u;
         // a screen of at most 256 tiles is sorted by this pass alone and its (dense) runs ARE the tiles: the tile
-        // offsets and the sync-free frame's report go out from here, and no k_tf_offsets is launched for them
+        // offsets go out from here (tf_offsets_block has nothing to read them from)
         if (offsets_out) {
             if (tid < tiles) offsets_out[tid] = fits ? run_start : 0u;
             if (tid == 0) {
@@ -827,7 +828,7 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
 //   * a pair carries one byte of tile id (the high digit) instead of four,
 //   * the pass writes no tile ids at all: with hist[h][p] = pairs of high digit h in partition p, scanned over p by
 //     k_radix_rowscan, tile (h, l) starts at  start(h) + scanned[h][first partition of run l]  — every pair with
-//     high digit h in an earlier run has a smaller tile id, every one in run l or later does not.  k_tf_offsets reads
+//     high digit h in an earlier run has a smaller tile id, every one in run l or later does not.  tf_offsets_block reads
 //     the tile offsets straight out of the scanned histogram; the 65-ary search over the sorted tile ids (10 us at
 //     C2) and the 45 MB of sorted ids it probed are gone, and so are 3 of every 4 key bytes the pass used to move.
 // The price is up to TF2_PART - 1 unused slots at the end of each run of the first pass's output (the second pass's
@@ -885,15 +886,56 @@ struct TfDownsweepShared {
     uint32_t wave_sums[TS_WAVES], wave_gsums[TS_WAVES];
 };
 
+// offsets[t] for t = 0 .. tiles (offsets[tiles] = the pair total): tile (h, l) starts at start(h) + scanned[h][first
+// partition of run l].  It needs the scanned histogram only, not the second pass's output — so it is not a launch of its own
+// (a dependent launch costs ~5 us whatever it does) but the work of k_tf_downsweep2's LAST workgroups, beside the partitions.
+// (A screen of at most 256 tiles has no second pass: its dense runs are the tiles, and k_tf_scatter writes the offsets.)
+struct TfOffsetsArgs {
+    uint32_t tiles, lo_bits;
+    uint32_t *offsets;
+    const uint32_t *d_total;
+};
+__device__ __forceinline__ void tf_offsets_block(uint32_t block, const TfOffsetsArgs &o, const TfRuns &runs, uint32_t num_parts,
+                                                 const uint32_t *__restrict__ scanned, const uint32_t *__restrict__ totals, uint32_t *hstart,
+                                                 uint32_t *wsums) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t t = block * 256u + tid;
+    const uint32_t total = o.d_total[2];
+    // start of every high digit's run in the sorted order: exclusive scan of the second pass's digit totals
+    const uint32_t mine = totals[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t v = __shfl_up(incl, s);
+        if ((int)lane >= s) incl += v;
+    }
+    if (lane == 63) wsums[w] = incl;
+    __syncthreads();
+    hstart[tid] = (w > 0 ? wsums[0] : 0u) + (w > 1 ? wsums[1] : 0u) + (w > 2 ? wsums[2] : 0u) + incl - mine;
+    __syncthreads();
+    if (t > o.tiles) return;
+    if (t == o.tiles) {
+        o.offsets[t] = total;
+        return;
+    }
+    const uint32_t h = t >> o.lo_bits, l = t & ((1u << o.lo_bits) - 1u);
+    const uint32_t first_part = runs.start[l] / TF2_PART; // (an empty run starts where the next one does)
+    o.offsets[t] = hstart[h] + (first_part < num_parts ? scanned[(size_t)h * num_parts + first_part] : totals[h]);
+}
+
 template <bool RANK_ATOMIC>
 __global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *__restrict__ hi_in, const uint2 *__restrict__ val_in,
                                                                 uint2 *__restrict__ val_out, TfRuns runs, uint32_t hmask,
                                                                 uint32_t num_parts, const uint32_t *__restrict__ scanned,
-                                                                const uint32_t *__restrict__ totals) {
+                                                                const uint32_t *__restrict__ totals, TfOffsetsArgs off) {
     __shared__ TfDownsweepShared sh;
     __shared__ uint2 s_val[TF2_PART];
     __shared__ uint8_t s_dig[TF2_PART];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, p = blockIdx.x;
+    if (p >= num_parts) { // (uniform) not a partition: a block of 256 tile offsets
+        tf_offsets_block(p - num_parts, off, runs, num_parts, scanned, totals, sh.global_base, sh.wave_sums);
+        return;
+    }
     const uint32_t valid = tf2_valid(runs, p);
     if (valid == 0) return;
     for (uint32_t i = tid; i < TS_WAVES * 256; i += TF_THREADS) (&sh.wave_hist[0][0])[i] = 0;
@@ -974,45 +1016,10 @@ __global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *
     }
 }
 
-// offsets[t] for t = 0 .. tiles (offsets[tiles] = the pair total), and the sync-free frame's report to the host.
-// (A screen of at most 256 tiles has no second pass: its dense runs are the tiles, and k_tf_scatter writes both.)
-__global__ __launch_bounds__(256) void k_tf_offsets(uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, TfRuns runs,
-                                                    uint32_t num_parts, const uint32_t *__restrict__ scanned,
-                                                    const uint32_t *__restrict__ totals, uint32_t *__restrict__ offsets,
-                                                    const uint32_t *__restrict__ d_total, uint32_t *report, uint32_t seq) {
-    __shared__ uint32_t hstart[256];
-    __shared__ uint32_t wsums[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (report && blockIdx.x == 0 && tid == 0) tile_report(d_total, report, seq);
-    const uint32_t t = blockIdx.x * 256u + tid;
-    const uint32_t total = d_total[2];
-    // start of every high digit's run in the sorted order: exclusive scan of the second pass's digit totals
-    const uint32_t mine = totals[tid];
-    uint32_t incl = mine;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t v = __shfl_up(incl, s);
-        if ((int)lane >= s) incl += v;
-    }
-    if (lane == 63) wsums[w] = incl;
-    __syncthreads();
-    hstart[tid] = (w > 0 ? wsums[0] : 0u) + (w > 1 ? wsums[1] : 0u) + (w > 2 ? wsums[2] : 0u) + incl - mine;
-    __syncthreads();
-    if (t > tiles) return;
-    if (t == tiles) {
-        offsets[t] = total;
-        return;
-    }
-    const uint32_t h = t >> lo_bits, l = t & ((1u << lo_bits) - 1u);
-    const uint32_t first_part = runs.start[l] / TF2_PART; // (an empty run starts where the next one does)
-    offsets[t] = hstart[h] + (first_part < num_parts ? scanned[(size_t)h * num_parts + first_part] : totals[h]);
-}
-
 // The second pass and the tile offsets.  hist: 256 * num_parts + 256 words, num_parts = tf2_parts_bound(pairs bound,
 // low digits).  hi_bits == 0: only the offsets (the first pass's output is final).
 int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in, uint2 *val_out, const TfRuns *runs, uint32_t pairs_bound,
-                          uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total,
-                          uint32_t *report, uint32_t seq) {
+                          uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total) {
     const uint32_t num_parts = tf2_parts_bound(pairs_bound, lo_bits);
     uint32_t *totals = hist + (size_t)256 * num_parts;
     if (hi_bits > 0) {
@@ -1021,19 +1028,17 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
         LAUNCH_CHECK(ctx, "k_tf_upsweep2");
         int rc = radix_rowscan_launch(ctx, hist, num_parts, hmask + 1u);
         if (rc != SPLAT_OK) return rc;
+        const TfOffsetsArgs off = {tiles, lo_bits, offsets, d_total};
+        const dim3 grid(num_parts + div_up(tiles + 1, 256)); // the partitions, then the blocks of tile offsets
         if (rank_atomic_ok(ctx, true)) // (checked: k_tile_sort verifies every list this pass contributes to)
-            hipLaunchKernelGGL(k_tf_downsweep2<true>, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask,
-                               num_parts, hist, totals);
+            hipLaunchKernelGGL(k_tf_downsweep2<true>, grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
+                               totals, off);
         else
-            hipLaunchKernelGGL(k_tf_downsweep2<false>, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask,
-                               num_parts, hist, totals);
+            hipLaunchKernelGGL(k_tf_downsweep2<false>, grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
+                               totals, off);
         LAUNCH_CHECK(ctx, "k_tf_downsweep2");
     }
-    if (hi_bits == 0) return SPLAT_OK; // (k_tf_scatter wrote the offsets and the report itself)
-    hipLaunchKernelGGL(k_tf_offsets, dim3(div_up(tiles + 1, 256)), dim3(256), 0, ctx->stream, tiles, lo_bits, hi_bits, *runs, num_parts, hist,
-                       totals, offsets, d_total, report, seq);
-    LAUNCH_CHECK(ctx, "k_tf_offsets");
-    return SPLAT_OK;
+    return SPLAT_OK; // (hi_bits == 0: k_tf_scatter wrote the offsets itself)
 }
 
 // hist: the digit histogram the projector (k_project_hist) or the band prepare kernel counted, after
