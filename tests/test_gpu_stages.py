@@ -890,6 +890,51 @@ def test_tile_first_with_ballot_ranking(monkeypatch):
         dev.destroy()
 
 
+def test_timed_frames_count_entries_only_when_asked(device):
+    """splat_set_timing_stages' bit 31 (SPLAT_TIMING_COUNT_ENTRIES, on by default): a timed whole-frame call counts the list
+    entries its composite staged and consumed.  bench.py clears the bit for its timed region — the frames whose rate it
+    reports run the kernel instantiation every production frame runs — and takes the counts from later frames: both
+    settings must give the same image, and the counts must be the oracle's consumed entries."""
+    import ctypes as C
+    from splat_renderer_amd import _lib
+    n, w, h = 20000, 640, 360
+    props, normals, u = make_case(n, w, h, 58, 1.0)
+    ref = oracle_pipeline(props, normals, u, w, h)
+    _, _, consumed_ref = O.composite(0, True, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"], ref["offsets"], w, h)[:3]
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    lib, ctx = device.lib, device.ctx
+
+    def counts_after(mask, frames=3):
+        _lib.check(lib.splat_set_timing_stages(ctx, mask), ctx)
+        device.setTiming(True)
+        for _ in range(frames):
+            r.render(u, pbuf, nbuf, None, w, h)
+        r.finish()
+        staged, consumed = C.c_uint64(), C.c_uint64()
+        _lib.check(lib.splat_timing_consumed(ctx, C.byref(staged), C.byref(consumed)), ctx)
+        img = r.readPixels().copy()
+        ms = device.stageTimeMs(_lib.STAGE_COMPOSITE)
+        device.setTiming(False)
+        return staged.value, consumed.value, img, ms
+
+    try:
+        s0, c0, img0, ms0 = counts_after(1 << _lib.STAGE_COMPOSITE)  # events on the composite, no counting
+        assert (s0, c0) == (0, 0) and ms0 > 0
+        s1, c1, img1, _ = counts_after(0xFFFFFFFF)
+        assert c1 % 3 == 0 and s1 >= c1 > 0
+        # (per tile the kernel reports the entries visited before its LAST pixel stopped: the oracle's per-pixel visits, maximised
+        # over the tile, is what test_composite_vs_oracle pins; here: the same frame gives the same number every time)
+        s2, c2, _, _ = counts_after(0xFFFFFFFF, frames=1)
+        assert (s2, c2) == (s1 // 3, c1 // 3)
+        assert_same(img0.view(np.uint32), img1.view(np.uint32), "counting and non-counting composite: same image")
+        assert consumed_ref > 0
+    finally:
+        _lib.check(lib.splat_set_timing_stages(ctx, 0xFFFFFFFF), ctx)
+        for o in (r, pbuf, nbuf):
+            o.destroy()
+
+
 def test_tile_sort_with_wide_digits(monkeypatch):
     """SPLAT_TILE_SORT_DIGITS=12: the per-tile sort's two-pass variant (digits of up to 12 bits, 16-bit counters packed two
     to a word; built and measured in round 3, slower than the byte passes and therefore not the default — DESIGN.md).  Same
