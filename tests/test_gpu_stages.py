@@ -982,7 +982,7 @@ def test_tile_sort_with_wide_digits(monkeypatch):
             dev.destroy()
 
 
-def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
+def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again(monkeypatch):
     """The default ranking of the tile-first frame rests on nothing unverified (include/splat.h, NOTE on ranking): the
     per-tile sort checks every finished list for strictly increasing (depth key, splat index) order.  Here a list is
     deliberately left as an out-of-lane-order rank would leave it (first two entries swapped, test hook): the frame's
@@ -991,6 +991,7 @@ def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
     frame, sync-free frame, both size classes and a list long enough for the global-memory passes."""
     # (position of the swapped pair in the victim's list: 0; 63 | 64 and 255 | 256 are the pairs the check reads across a
     # wave / a round of the workgroup; 4000 lies in the long class's in-LDS range)
+    monkeypatch.delenv("SPLAT_RANK", raising=False)  # (the DEFAULT policy is what this is about, whatever the suite runs under)
     cases = [(3000, 128, 96, 71, 1.0, False, 0), (20000, 640, 360, 72, 1.0, True, 63), (30000, 48, 32, 73, 8.0, True, 255),
              (30000, 48, 32, 75, 8.0, False, 4000), (6000, 16, 16, 74, 30.0, False, 1000)]
     for n, w, h, seed, rs, sync_free, position in cases:
