@@ -792,7 +792,12 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
     // a tenth of a C0 frame).
-    const bool one_class = tiles <= 3u * 256u;
+    // (SPLAT_TILE_SORT_CLASSES=1 / =2 force one launch / two launches: measuring knob, profiles/r03_j_tile_sort_one_launch_C2.txt)
+    static const int force_classes = [] {
+        const char *e = getenv("SPLAT_TILE_SORT_CLASSES");
+        return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
+    }();
+    const bool one_class = force_classes ? force_classes == 1 : tiles <= 3u * 256u;
     // SPLAT_TILE_SORT_DIGITS=12: the wide passes (two of up to 12 bits instead of three of 8; built and measured in round 3:
     // slower — 76 + 33 us against 56 + 23 at C2, profiles/r03_f_tile_sort_wide_digits_C2.txt — kept selectable, and tested)
     if (ctx->tile_sort_digits == 0) {
