@@ -614,31 +614,30 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : (W
 
     // load (LDS path) and the tile's key range.  All of a thread's loads are issued before the first
     // is used: one load per loop trip left every workgroup waiting out up to 23 memory latencies in a
-    // row (48 of the kernel's 76 us at C2 went there).
+    // row (48 of the kernel's 76 us at C2 went there).  The pairs are loaded in the passes' own layout — position =
+    // (wave, item, lane) — and stay in registers: the first pass ranks them from there (no staging write and read).
     uint32_t lo = 0xffffffffu, hi = 0;
+    const uint32_t items = ((n + TS_THREADS - 1) / TS_THREADS + 3u) & ~3u;
+    const uint32_t wbase = w * items * 64 + lane;
+    uint2 el[TS_MAX_ITEMS];
     if (in_lds) {
-        uint2 v[TS_MAX_ITEMS];
 #pragma unroll
         for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-            if (g * TS_THREADS < n) {
+            if (g < items) {
 #pragma unroll
                 for (uint32_t i = g; i < g + 4; ++i) {
-                    const uint32_t p = tid + i * TS_THREADS;
-                    v[i] = src[p < n ? p : n - 1];
+                    const uint32_t p = wbase + i * 64;
+                    el[i] = src[p < n ? p : n - 1]; // (padding re-reads the last pair: harmless for the key range)
                 }
             }
         }
 #pragma unroll
         for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-            if (g * TS_THREADS < n) {
+            if (g < items) {
 #pragma unroll
                 for (uint32_t i = g; i < g + 4; ++i) {
-                    const uint32_t p = tid + i * TS_THREADS;
-                    if (p < n) {
-                        s_el[p] = v[i];
-                        lo = min(lo, v[i].x);
-                        hi = max(hi, v[i].x);
-                    }
+                    lo = min(lo, el[i].x);
+                    hi = max(hi, el[i].x);
                 }
             }
         }
@@ -666,21 +665,31 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : (W
         // per thread, wave-striped: position = (wave, item, lane).  Items go in groups of four so that
         // four LDS reads, then four returning atomics, are in flight together (a branch per item
         // would expose every round trip); positions past n are padding and do nothing.
-        const uint32_t items = ((n + TS_THREADS - 1) / TS_THREADS + 3u) & ~3u;
-        const uint32_t wbase = w * items * 64 + lane;
-        for (uint32_t pass = 0; pass < passes; ++pass) {
-            const uint32_t shift = pass * 8;
-            for (uint32_t i = tid; i < TS_WAVES * 256; i += TS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
-            __syncthreads();
-            uint2 el[TS_MAX_ITEMS];
-            uint32_t rank[TS_MAX_ITEMS];
+        if (passes == 0) { // every key equal: the list is in order as it stands
 #pragma unroll
             for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
                 if (g < items) {
 #pragma unroll
-                    for (uint32_t i = g; i < g + 4; ++i) {
-                        const uint32_t p = wbase + i * 64;
-                        el[i] = s_el[p < n ? p : n - 1];
+                    for (uint32_t i = g; i < g + 4; ++i)
+                        if (wbase + i * 64 < n) s_el[wbase + i * 64] = el[i];
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t shift = pass * 8;
+            for (uint32_t i = tid; i < TS_WAVES * 256; i += TS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+            __syncthreads();
+            uint32_t rank[TS_MAX_ITEMS];
+#pragma unroll
+            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
+                if (g < items) {
+                    if (pass > 0) { // (the first pass's pairs are in registers)
+#pragma unroll
+                        for (uint32_t i = g; i < g + 4; ++i) {
+                            const uint32_t p = wbase + i * 64;
+                            el[i] = s_el[p < n ? p : n - 1];
+                        }
                     }
 #pragma unroll
                     for (uint32_t i = g; i < g + 4; ++i) {
