@@ -112,7 +112,7 @@ def measured_copy_ceiling(dev):
     nbytes = 1 << 30
     a, b = dev.createBuffer(nbytes), dev.createBuffer(nbytes)
     a.zero()
-    for _ in range(2):
+    for _ in range(20):  # (~8 ms: the device's clocks take a few ms of load to reach what they sustain, tools/warm_probe.py)
         _lib.check(dev.lib.splat_buf_copy(dev.ctx, b.ptr, a.ptr, nbytes), dev.ctx)
     dev.sync()
     t0 = time.perf_counter()
@@ -251,6 +251,10 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
         _lib.check(lib.splat_stage_time_stats(ctx, sid, C.byref(cnt), C.byref(tot)), ctx)
         return tot.value / max(cnt.value, 1)
 
+    # the box's copy rate first: a second denominator for the rooflines — and ~12 ms of load, after which the W warm-up frames
+    # and the timed region run at the clocks the device sustains (after idle the first ~50 frames of C2 take 0.345 ms, every
+    # later one 0.3335: tools/warm_probe.py, profiles/r03_l_clock_ramp.txt; host-side scene generation leaves the device idle for seconds)
+    copy_gbs = measured_copy_ceiling(dev)
     for _ in range(args.warmup):
         frame()
     dev.sync()
@@ -282,7 +286,6 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     dev.setTiming(False)
     pairs = r.binner.getTotalIndices()
 
-    copy_gbs = measured_copy_ceiling(dev)
     comp_bytes = composite_alg_bytes(p_used, width, height)
     comp_s = stage_ms["composite"] / 1e3
     achieved = comp_bytes / comp_s / 1e9
