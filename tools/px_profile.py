@@ -47,3 +47,9 @@ for lab, a in (("consumer life", c_life), ("consumer barrier wait", c_wait), ("c
     print(f"  {lab:24s} mean {x.mean():9.0f}  p50 {np.percentile(x, 50):9.0f}  p90 {np.percentile(x, 90):9.0f}  p99 {np.percentile(x, 99):9.0f}  max {x.max():9.0f}  sum {x.sum():.3e}")
 print(f"  cycles per trip {c_trips[nz].sum() / max(c_ntrips[nz].sum(), 1):.0f}; record wait per chunk built {b_fetch[nz].sum() / max(b_chunks[nz].sum(), 1):.0f}; "
       f"builder busy-but-not-waiting per chunk {(b_life[nz].sum() - b_wait[nz].sum() - b_fetch[nz].sum()) / max(b_chunks[nz].sum(), 1):.0f}")
+# by length: do the long tiles — the kernel's duration — run faster than the rest?
+for lo_, hi_ in ((1, 8), (9, 15), (16, 23), (24, 1000)):
+    m = nz & (b_chunks >= lo_) & (b_chunks <= hi_)
+    if m.any():
+        print(f"  tiles of {lo_}..{hi_} chunks: {m.sum():5d}  consumer life mean {c_life[m].mean():8.0f} max {c_life[m].max():8.0f}  cycles per trip "
+              f"{c_trips[m].sum() / max(c_ntrips[m].sum(), 1):5.0f}  life per chunk {c_life[m].sum() / b_chunks[m].sum():6.0f}  barrier wait share {c_wait[m].sum() / c_life[m].sum():.2f}")
