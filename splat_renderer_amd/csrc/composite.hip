@@ -774,6 +774,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             /* COUNT: the last entry a lane takes while one of its pixels still accumulates is the one that stops its last   \
                pixel (if they all stop) */                                                                                    \
             if (COUNT) jlast = __builtin_amdgcn_inverse_ballot_w64((a00 | a01 | a10 | a11) & R) ? J : jlast;                  \
+            all_stopped = (a00 | a01 | a10 | a11) == 0; /* (scalar: the four masks are in SGPRs already) */                    \
         }                                                                                                                     \
         cr[0] += (v2f){C.x, C.x} * w0; cr[1] += (v2f){C.x, C.x} * w1; /* SURVEY §8a contract 3: nearest on top */             \
         cg[0] += (v2f){C.y, C.y} * w0; cg[1] += (v2f){C.y, C.y} * w1;                                                         \
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
             uint32_t ja, jb, jlast = NONE;
+            bool all_stopped = false; // every pixel of the tile had stopped before the entry just blended: the rest of the chunk is zeros
             unsigned long long ra_, rb_;
             float2 gxa, gya, gxb, gyb;
             float4 ca, cb4;
@@ -800,6 +802,9 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 PX_LOAD(jb, gxb, gyb, cb4);
                 __builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads to their use, one trip later: the point is lost)
                 PX_BLEND(ja, ra_, gxa, gya, ca);
+#ifndef PX_NO_STOP_BREAK
+                if (EARLY_OUT && all_stopped) break;
+#endif
                 if (rb_ == 0) break;
 #ifdef PX_PROFILE
                 pc_ntrips++;
@@ -808,6 +813,9 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 PX_LOAD(ja, gxa, gya, ca);
                 __builtin_amdgcn_sched_barrier(0);
                 PX_BLEND(jb, rb_, gxb, gyb, cb4);
+#ifndef PX_NO_STOP_BREAK
+                if (EARLY_OUT && all_stopped) break;
+#endif
             }
 #undef PX_POP
 #undef PX_LOAD
