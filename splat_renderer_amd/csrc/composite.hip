@@ -762,6 +762,12 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
         GY = (&B.t[8 + by][1])[(int)J];  \
         C = (&B.col[1])[(int)J];         \
     } while (0)
+#ifndef PX_KEEP_DEAD_QUEUES // (measuring knob: profiles/r03_h_px_builder_own_axis_span_C2.txt)
+/* a lane whose four pixels have all stopped gives up the rest of its queue at once, not at the next chunk */
+#define PX_DROP_DEAD_LANE(ALIVE) mine = __builtin_amdgcn_inverse_ballot_w64(ALIVE) ? mine : 0u
+#else
+#define PX_DROP_DEAD_LANE(ALIVE) do { } while (0)
+#endif
 #define PX_BLEND(J, R, GX, GY, C)                                                                                             \
     do {                                                                                                                      \
         const v2f gxx = {GX.x, GX.y};                                                                                         \
@@ -775,6 +781,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                pixel (if they all stop) */                                                                                    \
             if (COUNT) jlast = __builtin_amdgcn_inverse_ballot_w64((a00 | a01 | a10 | a11) & R) ? J : jlast;                  \
             all_stopped = (a00 | a01 | a10 | a11) == 0; /* (scalar: the four masks are in SGPRs already) */                    \
+            PX_DROP_DEAD_LANE(a00 | a01 | a10 | a11);                                                                         \
         }                                                                                                                     \
         cr[0] += (v2f){C.x, C.x} * w0; cr[1] += (v2f){C.x, C.x} * w1; /* SURVEY §8a contract 3: nearest on top */             \
         cg[0] += (v2f){C.y, C.y} * w0; cg[1] += (v2f){C.y, C.y} * w1;                                                         \
