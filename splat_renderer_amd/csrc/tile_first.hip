@@ -173,8 +173,11 @@ struct TfScatterShared {
 // later kernels work on: the total, or 0 when it exceeds pair_limit (then nothing is written and
 // the overflow flag is raised: the frame is rendered again with room).
 // TF_PER_THREAD splats per thread: 4 (1024-splat blocks) or 1 (256-splat blocks of small frames, common.h).
+#ifndef TF_SCATTER_WAVES
+#define TF_SCATTER_WAVES 5 // (tuning knob of tools/build_variant.sh: 4 and 6 measured, profiles/r03_q_small_knobs_C2.txt)
+#endif
 template <bool RANK_ATOMIC, uint32_t TF_PER_THREAD>
-__global__ __launch_bounds__(TF_THREADS, 5) void k_tf_scatter(const uint32_t *__restrict__ range32,
+__global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(const uint32_t *__restrict__ range32,
                                                            const uint32_t *__restrict__ depth_keys, uint32_t n, uint32_t ntx,
                                                            uint32_t mask, uint32_t num_parts,
                                                            const uint32_t *__restrict__ scanned_hist,
