@@ -220,7 +220,7 @@ def main():
     u = cam.uniforms(width, height)
     workload = f"{name}: {n} synthetic Gaussians @{width}x{height}, {tile}x{tile} tiles"
 
-    if world == 1 and "RANK" not in os.environ:
+    if world == 1:  # one GPU is one GPU, launched through torchrun or not (the band path is for N > 1)
         result = run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload)
     else:
         result = run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world)
@@ -269,6 +269,8 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     dev.sync()
     dt = time.perf_counter() - t0
     composite_ms = stage_avg(_lib.STAGE_COMPOSITE)
+    r.finish()  # settles the last timed frame's report: a failed order check in ANY timed frame has been counted by now
+    ranking = dict(dev.rankStatus(), framesMisranked=r.framesMisranked, framesOverflowed=int(r.previousFrameOverflowed))
     # per-stage breakdown from a separate short loop with every stage's events on (not part of `value`), and the entries
     # the composite staged / consumed per frame: a property of the input, counted here so that the timed region runs the
     # kernel instantiation every production frame runs (the counting one is ~3 us slower at C2)
@@ -325,7 +327,11 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    "frame_order": os.environ.get("SPLAT_FRAME_ORDER", "tile-first (bin, then depth-sort per tile; library default)"),
                    "footprint": ("oriented disc (SequentialRenderer.ts:91-142), inverse homography per pixel" if disc else
                                  "isotropic screen-space Gaussian (ComputeShaderRenderer.ts:123-147)"),
-                   "composite": "front-to-back, early-out at alpha>=0.99"},
+                   "composite": "front-to-back, early-out at alpha>=0.99",
+                   # how the timed frames ranked equal digits (include/splat.h NOTE on ranking): 'checked' = returning LDS atomics +
+                   # a complete order check of every tile list; orderFaults > 0 would mean frames were re-rendered with ballots and
+                   # the rest of the run took the slower ballot path — asserted zero below
+                   "ranking": ranking},
         "roofline": roofline,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "roofline_per_kernel": per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, args.records == "lit" and not disc, disc),
@@ -334,6 +340,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                            "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                            "frac_of_measured_copy": frame_bytes / (dt / args.steps) / 1e9 / copy_gbs},
     }
+    assert ranking["orderFaults"] == 0 and ranking["framesMisranked"] == 0, f"a timed frame failed the tile-list order check and was rendered again: {ranking}"
     if not disc and not args.no_extras:
         # SURVEY 8d's composite-only figure: early-out OFF, every entry of every list consumed (68 P + 4WH), the same
         # kernel on the same frame's records and lists, outside the timed region
@@ -558,6 +565,7 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     # outside the timed region: proves no sync-free frame overflowed
     (local if local is not None else br).render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
     assert tstages.overflows == 0, "a sync-free frame overflowed its pair limit in a static scene"
+    ranking = dict(tstages.rank_status(), framesMisranked=tstages.misranked)
     tstages.set_timing(False)
     # self-checks of the exchange for the record (outside the timed region): what the communicator says about itself, and
     # every other rank's gathered shard against this rank's own projection of that slice, bit for bit
@@ -566,10 +574,14 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     verified = br.verify_exchange(u, pt.data_ptr(), nt.data_ptr())
     r0, r1 = br.pixel_rows()
     kept = n if local is not None else stages.kept  # (no band filter without an exchange: every rank bins from all n splats)
-    info = torch.tensor([kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6), rccl_view[0], rccl_view[1], verified], dtype=torch.int64, device="cuda")
+    info = torch.tensor([kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6), rccl_view[0], rccl_view[1], verified,
+                         ("checked", "atomic", "ballot").index(ranking["policy"]), int(ranking["atomicsOrdered"]), ranking["orderFaults"]],
+                        dtype=torch.int64, device="cuda")
     infos = [torch.zeros_like(info) for _ in range(world)]
     td.all_gather(infos, info)
     infos = [[int(v) for v in t.tolist()] for t in infos]
+    # (every rank sees every rank's counter: all of them stop together, none is left waiting in a collective)
+    assert all(i[10] == 0 for i in infos), f"a timed frame failed the tile-list order check and was rendered again: orderFaults per rank {[i[10] for i in infos]}"
     # roofline of the dominant kernel on the slowest rank's composite (per launch = per band)
     slow = max(range(world), key=lambda k: infos[k][4])
     rows_px = min(infos[slow][2] * tile, height) - infos[slow][1] * tile
@@ -603,7 +615,9 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                                 "verification": "after the timed region every rank re-projected every other rank's slice from its own copy of "
                                                 "the splats and compared it bit for bit with the block the all-gather delivered",
                                 "in_timed_region": local is None},
-                   "composite": "front-to-back, early-out at alpha>=0.99"},
+                   "composite": "front-to-back, early-out at alpha>=0.99",
+                   "ranking": {"policy": [("checked", "atomic", "ballot")[i[8]] for i in infos], "atomicsOrdered": [bool(i[9]) for i in infos],
+                               "orderFaults": [i[10] for i in infos]}},
         "roofline": {"kernel": "k_composite_px" if (ntx * nty >= 2048 and not stages.disc) else "k_composite", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": comp_bytes,
                      "avg_launch_ms": infos[slow][4] / 1e6, "rank": slow},

@@ -165,6 +165,12 @@ int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches);
  *     overflowed sync-free frame (SPLAT_ERR_RETRY at the next call), the context ranks with ballots from then on, and the
  *     caller renders the frame again.  Every other sort (splat_sort_run, splat_bin_run, the sort-first frame order), whose
  *     result nothing checks, ranks with ballots: lane order by construction (8 ballots + mbcnt per key).
+ *     WHAT IS GUARANTEED, precisely: frame N's image and lists are PROVISIONAL until frame N's report has been examined —
+ *     by the next frame call on the same binner, by splat_bin_total / splat_bin_get_* / splat_band_settle, or by anything the
+ *     host classes read results through (Renderer.finish / readPixels / readPixelsFloat call splat_bin_total first and
+ *     render the frame again on SPLAT_ERR_RETRY / SPLAT_ERR_CAPACITY).  The output buffer of a frame that fails the check
+ *     HAS been written from the wrong lists: a caller that maps it without settling the frame reads that image.  The
+ *     context prints one line to stderr when it switches to ballots, and splat_rank_status counts the frames.
  *   - SPLAT_RANK=atomic: atomics wherever the start-up probe passes (the unchecked sorts too).
  *   - SPLAT_RANK=ballot: ballots everywhere.
  * The price of the guaranteed ranking on the frame path, measured on one MI355X (profiles/r03_a_rank_ab.txt): C0 0.048 ->

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("SPLAT_LIB_PATH") or os.path.join(_HERE, "libsplat_hip
 OK = 0
 ERR_NAMES = {-1: "INVALID", -2: "HIP", -3: "OOM", -4: "CAPACITY", -5: "STATE", -6: "NO_DEVICE", -7: "COMM", -8: "RETRY"}
 # "the previous frame must be rendered again" (its sync-free pair limit overflowed / its lists failed the order check)
-RENDER_AGAIN = (-4, -8)
+ERR_CAPACITY, ERR_RETRY = -4, -8
+RENDER_AGAIN = (ERR_CAPACITY, ERR_RETRY)  # reports about the PREVIOUS sync-free frame: overflowed its pair limit / failed the order check
 
 STAGE_PROJECT, STAGE_SORT, STAGE_BIN, STAGE_COMPOSITE, STAGE_EXCHANGE, STAGE_BIN_SCATTER, STAGE_BIN_PASS2, STAGE_BIN_TILE_SORT = range(8)
 STAGE_NAMES = ("project", "sort", "bin", "composite", "exchange", "bin_scatter", "bin_second_pass", "bin_tile_sort")

@@ -19,6 +19,7 @@
 #include "tile_range.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <sched.h>
 
@@ -501,6 +502,9 @@ int binner_settle(splat_binner *b) {
         // lists (and its image) are wrong; from here on this context ranks with ballots, which assume nothing.
         b->ran = false;
         ctx->order_faults++;
+        if (ctx->rank_policy != RANK_BALLOT) // said ONCE, where an operator sees it: from here on every frame costs the ballot path's +12..19 %
+            fprintf(stderr, "[splat] a frame's tile lists failed the per-tile order check (tile lists are re-rendered): this context ranks with "
+                            "ballots from now on (splat_rank_status: policy ballot, orderFaults %u)\n", ctx->order_faults);
         ctx->rank_policy = RANK_BALLOT;
         return ctx_fail(ctx, SPLAT_ERR_RETRY,
                         "the previous frame's tile lists failed the order check (ranking with returning LDS atomics was not in lane "

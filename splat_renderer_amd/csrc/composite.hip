@@ -1026,7 +1026,6 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     p.tile_cost = nullptr;
     p.order_src = nullptr;
     p.order_dst = nullptr;
-    *launched = true;
     dim3 grid(ntx, r1 - r0), block(256);
     const bool eo = cfg->early_out != 0;
     // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
@@ -1080,6 +1079,7 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
             else    SPLAT_COMPOSITE_PX_LAUNCH(false, false);
         }
 #undef SPLAT_COMPOSITE_PX_LAUNCH
+        *launched = hipPeekAtLastError() == hipSuccess; // (only a launch that went out carries the frame's report: composite_launch sends it otherwise)
         LAUNCH_CHECK(ctx, "k_composite_px");
         return SPLAT_OK;
     }
@@ -1104,6 +1104,7 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
         }
     }
 #undef SPLAT_COMPOSITE_LAUNCH
+    *launched = hipPeekAtLastError() == hipSuccess;
     LAUNCH_CHECK(ctx, "k_composite");
     return SPLAT_OK;
 }

@@ -476,6 +476,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         if (hipMalloc(&binner->discs, (size_t)n * 32 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "disc records hipMalloc");
         binner->discs_cap = n;
     }
+    if (ctx->timing) { // (before binner_run promises a report: nothing that can fail may stand between that promise and the composite_launch that keeps it)
+        rc = ctx_ensure_consumed(ctx, ntx * nty);
+        if (rc != SPLAT_OK) return rc;
+    }
     // (the payload array is not written: payload = splat index)
     const LitIO lio = {(const float4 *)color, (const float4 *)normals, color_stride, 1u, cfg->prelit, lit ? (float4 *)projected : nullptr};
     rc = project_launch(ctx, uniforms, props, pos_stride, n, 0, lit ? nullptr : projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
@@ -502,10 +506,6 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     // (fields, not the public getters: those wait for a sync-free frame's pair total to come back)
     void *counts = binner->counts, *offsets = binner->offsets;
     void *indices = binner->pairs.result_in_primary ? binner->pairs.payload : binner->pairs.payload_b;
-    if (ctx->timing) {
-        rc = ctx_ensure_consumed(ctx, ntx * nty);
-        if (rc != SPLAT_OK) return rc;
-    }
     // (n == 0: every list is empty and no record is read; the composite only wants a non-null pointer)
     const void *records = disc ? (n ? (const void *)binner->discs : (projected ? projected : (const void *)counts)) : projected;
     uint32_t *report = binner->report_for_composite; // (tile-first frames: the frame's last kernel reports it: common.h)

@@ -808,6 +808,7 @@ int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr) {
 int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t position) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, tile != 0xffffffffu);
+    ARG_CHECK(ctx, position < 0x3fffffffu); // (the kernel forms position + 2: no wrap, whatever a test passes)
     ctx->inject_order_fault = tile + 1u;
     ctx->inject_order_position = position;
     return SPLAT_OK;

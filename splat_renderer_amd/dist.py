@@ -120,10 +120,25 @@ class HipStages:
         self.mode, self.early_out = mode, early_out
         self.pairs = 0
         self.overflows = 0
+        self.misranked = 0  # frames whose lists failed the order check and were rendered again with ballots (SPLAT_ERR_RETRY)
         self.consumed = None  # optional torch int64[tiles, 2]: per tile, list entries {staged, consumed} by the composite
         self.lit = None       # optional torch float32[n,4]: lit colour plane (set_lit); band_frame then ignores props/normals
         self.pos_plane = None  # with it: the (pos, radius) plane, for local_frame
         self.local_projected = None  # local_frame: the projector's ProjectedSplat records
+
+    def _again(self, rc):
+        """Books a report about the previous sync-free frame: SPLAT_ERR_CAPACITY (pair limit) or SPLAT_ERR_RETRY (order check)."""
+        if rc == _lib.ERR_RETRY:
+            self.misranked += 1
+        else:
+            self.overflows += 1
+
+    def rank_status(self):
+        """Device.rankStatus() of this rank's context: {policy, atomicsOrdered, orderFaults}."""
+        pol, ordered, faults = C.c_int(), C.c_int(), C.c_uint32()
+        check(self.lib.splat_rank_status(self.ctx, C.byref(pol), C.byref(ordered), C.byref(faults)), self.ctx)
+        return {"policy": ("checked", "atomic", "ballot")[pol.value], "atomicsOrdered": bool(ordered.value == 1),
+                "orderFaults": int(faults.value)}
 
     def set_lit(self, props_ptr, normals_ptr, n):
         """Shade every splat once (kd from its normal) into a colour plane: the composite then gathers two
@@ -182,8 +197,8 @@ class HipStages:
                 self.width, self.height, out_image.data_ptr(), None,
                 self.consumed.data_ptr() if self.consumed is not None else None)
         rc = self.lib.splat_band_frame(*args)
-        if rc in _lib.RENDER_AGAIN:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
-            self.overflows += 1
+        if rc in _lib.RENDER_AGAIN:  # the PREVIOUS frame overflowed its sync-free limit (capacity was raised) or misranked: go again
+            self._again(rc)
             rc = self.lib.splat_band_frame(*args)
         check(rc, self.ctx)
         if settle:
@@ -192,7 +207,7 @@ class HipStages:
                 rc = self.lib.splat_band_settle(self.ctx, self.sorter, self.binner, C.byref(k), C.byref(t))
                 if rc not in _lib.RENDER_AGAIN:
                     break
-                self.overflows += 1
+                self._again(rc)
                 check(self.lib.splat_band_frame(*args), self.ctx)
             check(rc, self.ctx)
             self.pairs = int(t.value)
@@ -217,15 +232,15 @@ class HipStages:
         else:
             fn, args = self.lib.splat_render_frame, head + (props_ptr,) + tail
         rc = fn(*args)
-        if rc in _lib.RENDER_AGAIN:  # the PREVIOUS frame overflowed its sync-free limit; capacity was raised: go again
-            self.overflows += 1
+        if rc in _lib.RENDER_AGAIN:  # the PREVIOUS frame overflowed its sync-free limit (capacity was raised) or misranked: go again
+            self._again(rc)
             rc = fn(*args)
         check(rc, self.ctx)
         if settle:
             t = C.c_uint64()
             rc = self.lib.splat_bin_total(self.binner, C.byref(t))
             if rc in _lib.RENDER_AGAIN:
-                self.overflows += 1
+                self._again(rc)
                 check(fn(*args), self.ctx)
                 rc = self.lib.splat_bin_total(self.binner, C.byref(t))
             check(rc, self.ctx)

@@ -736,6 +736,16 @@ class Renderer:
         self._wh = (0, 0)
         self._last = None
         self.previousFrameOverflowed = False
+        # frames whose tile lists failed the per-tile sort's order check (SPLAT_ERR_RETRY) and were rendered again with
+        # ballots: NOT a capacity event — the context has changed its ranking for good (Device.rankStatus())
+        self.framesMisranked = 0
+
+    def _again(self, rc):
+        """Books a SPLAT_ERR_CAPACITY / SPLAT_ERR_RETRY report about the previous sync-free frame."""
+        if rc == _lib.ERR_RETRY:
+            self.framesMisranked += 1
+        else:
+            self.previousFrameOverflowed = True
 
     def render(self, uniformData, propertyBuffer, normalsBuffer, scaleFactorsBuffer, width, height, tileRows=(0, U32_MAX),
                wantFloat=False):
@@ -770,8 +780,8 @@ class Renderer:
             fn, args = d.lib.splat_render_frame, head + (propertyBuffer.ptr,) + tail
         self._last = (fn, args, u, cfg)  # keeps u/cfg alive; finish() may have to render this frame again
         rc = fn(*args)
-        if rc in _lib.RENDER_AGAIN:  # SPLAT_ERR_CAPACITY: the PREVIOUS (sync-free) frame outgrew its pair limit; room was made
-            self.previousFrameOverflowed = True
+        if rc in _lib.RENDER_AGAIN:  # about the PREVIOUS (sync-free) frame: it outgrew its pair limit (room was made) or misranked
+            self._again(rc)
             rc = fn(*args)
         check(rc, d.ctx)
         self.binner._tiles = -(-width // self.tileSize) * -(-height // self.tileSize)
@@ -785,7 +795,7 @@ class Renderer:
         t = C.c_uint64()
         rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
         if rc in _lib.RENDER_AGAIN and self._last is not None:
-            self.previousFrameOverflowed = True
+            self._again(rc)
             check(self._last[0](*self._last[1]), d.ctx)
             rc = d.lib.splat_bin_total(self.binner._b, C.byref(t))
         check(rc, d.ctx)

@@ -17,6 +17,7 @@ export class Device {
   createBufferFrom(data: TypedArray): Buffer;
   createCommandEncoder(): CommandEncoder;
   sync(): void;
+  rankStatus(): { policy: string; atomicsOrdered: boolean; orderFaults: number };
   destroy(): void;
 }
 export interface CommandEncoder { finish(): null; }

@@ -71,6 +71,13 @@ class Device {
   createBufferFrom(typedArray) { return this.createBuffer(Math.max(typedArray.byteLength, 16)).write(typedArray); }
   createCommandEncoder() { return { finish() { return null; } }; }
   sync() { native.sync(this.ctx); }
+  /** How this context ranks equal digits in its sort kernels (include/splat.h, NOTE on ranking).  orderFaults counts the frames
+   *  whose tile lists failed the per-tile sort's order check and were rendered again: anything but 0 means the context has
+   *  switched to ballot ranking for good (policy 'ballot', the slower path) and is worth a report. */
+  rankStatus() {
+    const s = native.rank_status(this.ctx);
+    return { policy: ['checked', 'atomic', 'ballot'][s[0]], atomicsOrdered: s[1] === 1, orderFaults: s[2] };
+  }
   destroy() {
     if (this.ctx) native.ctx_destroy(this.ctx);
     this.ctx = null;

@@ -20,6 +20,7 @@ declare function require(name: string): any;
 declare const module: { exports: any };
 type TypedArray = Float32Array | Uint32Array | Uint8Array | Int32Array;
 interface CommandEncoder { finish(): null; }
+interface RankStatus { policy: string; atomicsOrdered: boolean; orderFaults: number }
 interface PointerLikeEvent {
   clientX?: number;
   clientY?: number;
@@ -92,6 +93,13 @@ class Device {
   createBufferFrom(typedArray: TypedArray): Buffer_ { return this.createBuffer(Math.max(typedArray.byteLength, 16)).write(typedArray); }
   createCommandEncoder(): CommandEncoder { return { finish() { return null; } }; }
   sync(): void { native.sync(this.ctx); }
+  /** How this context ranks equal digits in its sort kernels (include/splat.h, NOTE on ranking).  orderFaults counts the frames
+   *  whose tile lists failed the per-tile sort's order check and were rendered again: anything but 0 means the context has
+   *  switched to ballot ranking for good (policy 'ballot', the slower path) and is worth a report. */
+  rankStatus(): RankStatus {
+    const s = native.rank_status(this.ctx);
+    return { policy: ['checked', 'atomic', 'ballot'][s[0]], atomicsOrdered: s[1] === 1, orderFaults: s[2] };
+  }
   destroy(): void {
     if (this.ctx) native.ctx_destroy(this.ctx);
     this.ctx = null;

@@ -82,5 +82,5 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     discFramePairs = whole.binner.getTotalIndices();
   }
   console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, seqPairs, discFramePairs, recordFormat, bandEqualsFrame, bandPairs,
-    pointManagerOk, uniforms: Array.from(uniforms) }));
+    pointManagerOk, ranking: device.rankStatus(), uniforms: Array.from(uniforms) }));
 })().catch((e) => { console.error(e); process.exit(1); });

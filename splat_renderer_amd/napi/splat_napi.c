@@ -146,6 +146,18 @@ FN(ctx_create) {
 }
 FN(ctx_destroy) { ARGS(1); splat_ctx_destroy((splat_ctx *)arg_external(&c, 0)); return mk_undefined(env); }
 FN(sync) { ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL; return check(env, x, splat_sync(x), mk_undefined(env)); }
+FN(rank_status) { /* (ctx) -> [policy (0 checked | 1 atomic | 2 ballot), atomicsOrdered (1 | 0 | -1), orderFaults]: splat_rank_status */
+    ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL;
+    int pol = 0, ordered = 0; uint32_t faults = 0;
+    int rc = splat_rank_status(x, &pol, &ordered, &faults);
+    if (rc != SPLAT_OK) return check(env, x, rc, NULL);
+    napi_value arr;
+    if (napi_create_array_with_length(env, 3, &arr) != napi_ok) return NULL;
+    napi_set_element(env, arr, 0, mk_number(env, pol));
+    napi_set_element(env, arr, 1, mk_number(env, ordered));
+    napi_set_element(env, arr, 2, mk_number(env, (double)faults));
+    return arr;
+}
 FN(set_timing) { ARGS(2); splat_ctx *x = arg_external(&c, 0); int e = (int)arg_number(&c, 1); BAIL; return check(env, x, splat_set_timing(x, e), mk_undefined(env)); }
 FN(stage_time_ms) {
     ARGS(2); splat_ctx *x = arg_external(&c, 0); int st = (int)arg_number(&c, 1); BAIL;
@@ -404,7 +416,7 @@ FN(allgather_records) { /* (ctx, comm, shard, gathered, bytesPerRank) */
 static napi_value init(napi_env env, napi_value exports) {
 #define EXPORT(name) { #name, NULL, name, NULL, NULL, NULL, napi_enumerable, NULL }
     napi_property_descriptor d[] = {
-        EXPORT(abi_version), EXPORT(ctx_create), EXPORT(ctx_destroy), EXPORT(sync), EXPORT(set_timing), EXPORT(stage_time_ms),
+        EXPORT(abi_version), EXPORT(ctx_create), EXPORT(ctx_destroy), EXPORT(sync), EXPORT(rank_status), EXPORT(set_timing), EXPORT(stage_time_ms),
         EXPORT(buf_alloc), EXPORT(buf_free), EXPORT(buf_zero), EXPORT(buf_upload), EXPORT(buf_download), EXPORT(update_props), EXPORT(update_props_planes), EXPORT(props_to_planes), EXPORT(lit_colors),
         EXPORT(project), EXPORT(project_disc), EXPORT(extract_keys), EXPORT(sort_create), EXPORT(sort_destroy), EXPORT(sort_capacity), EXPORT(sort_keys),
         EXPORT(sort_payload), EXPORT(sort_sorted_payload), EXPORT(sort_sorted_keys), EXPORT(sort_run), EXPORT(sort_set_mode),

@@ -145,6 +145,8 @@ def test_js_frame_matches_oracle(tmp_path):
     # north_star's multi-GPU frame from JS (one-rank RCCL communicator behind the C ABI) and PointManager
     assert info["bandEqualsFrame"] is True and info["bandPairs"] == ref["indices"].shape[0]
     assert info["pointManagerOk"] is True
+    # Device.rankStatus() from JS: no frame of this script was re-rendered after a failed order check (splat_rank_status)
+    assert info["ranking"] == {"policy": "checked", "atomicsOrdered": True, "orderFaults": 0} or os.environ.get("SPLAT_RANK")
     # SequentialRenderer from JS draws its own footprint (the oriented disc): against the oracle's per-pixel restatement
     # (early-out on, as the class renders) and, off the rims, against the software rasteriser of SequentialRenderer.ts
     dproj, discs = O.project_disc(u, props, normals)

@@ -51,5 +51,7 @@ for case in range(cases):
         o.destroy()
     if case % 50 == 49:
         print(f"{case + 1} cases, {pairs_total} pairs compared so far, {time.time() - t0:.0f} s", flush=True)
+status = dev.rankStatus()
+assert status["orderFaults"] == 0, f"a frame of this sweep was re-rendered after a failed order check: {status}"
 print(f"ok: {cases} random frames (x2: first and sync-free), {with_second_pass} on screens of more than 256 tiles, {pairs_total} pairs in all, "
-      f"largest frame {worst} pairs: counts, offsets and lists identical to the oracle's")
+      f"largest frame {worst} pairs: counts, offsets and lists identical to the oracle's" + f"; ranking {status}")

@@ -64,6 +64,8 @@ for case in range(cases):
         o.destroy()
     if case % 25 == 24:
         print(f"{case + 1} cases, {pixels} pixels, worst off-threshold error {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+status = dev.rankStatus()
+assert status["orderFaults"] == 0, f"a frame of this sweep was re-rendered after a failed order check: {status}"
 print(f"ok: {cases} random frames, {pixels} pixels: largest error off the threshold {worst:.2e} (tolerance {TOL}), "
       f"largest at threshold-grazing pixels, nearest-on-top blending, {worst_near:.2e} (bound {TOL_NEAR}); {grazing_literal} threshold-grazing "
-      f"pixels in frames blended as the reference writes it (not bounded, not compared)")
+      f"pixels in frames blended as the reference writes it (not bounded, not compared)" + f"; ranking {status}")
