@@ -188,6 +188,24 @@ int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t posit
 /* EXPERIMENT HOOK: the order in which the lane-efficient composite's workgroups take the tiles of the rendered band
  * (a permutation of 0 .. tiles - 1 as u32 on the device; NULL = row-major).  Any order gives the same image. */
 int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
+/* The lane-efficient composite keeps, per context and band of tile rows, what its previous launch cost per tile (chunks of
+ * 32 list entries walked): the next launch over the same band takes its tiles longest-first and builds / gathers for each
+ * tile only what that launch needed ahead of need (a tile that needs more pays one exposed gather).  Both are hints — any
+ * history, stale or from another scene, gives the same image.  This forgets the history (the next two launches run
+ * row-major and without a bound, as a context's first do): for measurements and tests that want the kernel's first-frame
+ * behaviour. */
+int splat_composite_forget_history(splat_ctx *ctx);
+/* Per-context choices the environment otherwise makes for the whole process (environment table):
+ *   kernel  -1 default (SPLAT_COMPOSITE: lane-efficient k_composite_px on screens of >= 2048 tiles), 0 k_composite ("quadrant"),
+ *            1 k_composite_px ("pixel") — for isotropic nearest-on-top frames; the disc footprint and the reference-literal
+ *            blend always take k_composite;
+ *   ahead    0 default (SPLAT_PX_AHEAD, 2), 1 or 2: chunks k_composite_px's builder wave stays ahead of its consumer wave
+ *            (2: lanes whose queue for a chunk is empty go on with the next chunk's);
+ *   predict -1 default (SPLAT_PX_PREDICT, on), 0 / 1: bound each tile's look-ahead by what the previous launch walked;
+ *   slack   -1 default (SPLAT_PX_SLACK, 0), else chunks added to that bound.
+ * Every combination gives the same image (tests/test_gpu_stages.py runs the oracle comparisons over them).  Forgets the
+ * composite's history. */
+int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict, int slack);
 /* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
  * (the result is then invalid).  Synchronises. */
 int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag);

@@ -86,6 +86,8 @@ SIGNATURES = {
     "splat_rank_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32)]),
     "splat_debug_inject_order_fault": (_i, [_vp, _u32, _u32]),
     "splat_debug_set_tile_order": (_i, [_vp, _vp]),
+    "splat_composite_forget_history": (_i, [_vp]),
+    "splat_composite_options": (_i, [_vp, _i, _i, _i, _i]),
     "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),
     "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_bin_create": (_i, [_vp, _u32, _pvp]),

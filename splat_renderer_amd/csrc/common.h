@@ -33,6 +33,9 @@ struct splat_ctx {
     int rank_policy = 0;
     uint32_t order_faults = 0;      // frames whose lists failed the order check (each was reported and rendered again)
     const uint32_t *debug_tile_order = nullptr; // experiment hook (splat_debug_set_tile_order)
+    // splat_composite_options (-1 / 0 = the process default, i.e. the environment's): which kernel composites nearest-on-top
+    // isotropic frames (0 quadrant, 1 pixel), and k_composite_px's schedule
+    int opt_composite_kernel = -1, opt_px_ahead = 0, opt_px_predict = -1, opt_px_slack = -1;
     // k_composite_px's dispatch order (composite.hip, px_order_prepare): for the band `px_key` describes, two arrays of
     // per-tile costs and two of tile orders (px_cap entries each), alternating between launches
     uint32_t *px_mem = nullptr;

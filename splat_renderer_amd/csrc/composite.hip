@@ -58,6 +58,11 @@ struct CompositeParams {
     uint32_t *tile_cost;        // k_composite_px: chunks each tile's consumer walked (NULL: not kept)
     const uint32_t *order_src;  // k_composite_px, workgroup 0: the costs the PREVIOUS launch over this band left (NULL: none) ...
     uint32_t *order_dst;        // ... sorted into the order the NEXT launch takes its tiles in
+    const uint32_t *cost_prev;  // k_composite_px: the same costs, read by every tile: how many chunks to build and gather ahead of need (NULL: all)
+    uint32_t cost_slack;        // ... plus this many
+#ifdef PX_PROFILE
+    uint32_t debug_cap;         // (measuring build only, SPLAT_PX_CAP: every list cut after this many entries — a WRONG image: what do the long tiles cost?)
+#endif
 };
 
 __device__ __forceinline__ uint32_t unorm8(float v) {
@@ -471,16 +476,18 @@ typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 constexpr int PXC = 32;     // entries per chunk = bits of a lane's queue
 constexpr int PX_ROW = 35;  // float2 slots per table row: the idle slot, 32 entries, 2 of padding — rows 3 slots apart (mod 32),
                             // so the eight rows a wave reads for ONE entry fall into eight different bank pairs of a ds_read_b64
-// One chunk as the builder wave leaves it for the consumer wave.  Slot 0 of every row and colour 0 are the IDLE entry
-// (zeros): what a lane with an empty queue "takes" — entry j lives at index 1 + j, so ffbl's -1 for an empty queue
-// addresses the idle slot without a select.
+constexpr int PX_TROWS = 18;
+// One chunk as the builder wave leaves it for the consumer wave.  Slot 0 of every row is the IDLE entry (zeros): what a
+// lane with an empty queue "takes" — entry j lives at slot 1 + j, so ffbl's -1 for an empty queue addresses the idle
+// slot without a select.
 struct PxBuf {
-    float2 t[16][PX_ROW];  // t[c][1 + j] = {gx_j(2c), gx_j(2c+1)}: entry j's factor at the tile's pixel columns 2c, 2c+1 (c < 8);
-                           // t[8 + r][1 + j] = {gy_j(2r), gy_j(2r+1)} at its pixel rows
-    float4 col[PXC + 1];   // col[1 + j] = {lit r, g, b, 1}
-    uint2 q[8];            // q[c].x: bit j = entry j's box meets pixel columns 2c, 2c+1; q[r].y: ... pixel rows 2r, 2r+1
+    float2 t[PX_TROWS][PX_ROW]; // t[c][1 + j] = {gx_j(2c), gx_j(2c+1)}: entry j's factor at the tile's pixel columns 2c, 2c+1 (c < 8);
+                                // t[8 + r][1 + j] = {gy_j(2r), gy_j(2r+1)} at its pixel rows; only the pairs entry j's box touches are
+                                // written (no lane is ever sent to another);  t[16][1 + j] = {lit r, g}, t[17][1 + j] = {lit b, 1}:
+                                // every read of a trip is 8 bytes at slot-stride 8 off ONE computed address
+    uint4 q4[4];                // as uint2 q[8]: q[c].x: bit j = entry j's box meets pixel columns 2c, 2c+1; q[r].y: ... pixel rows 2r, 2r+1
 };
-static_assert(sizeof(PxBuf) * 2 * 15 <= 160 * 1024, "fifteen tiles (thirty waves) per CU");
+static_assert(sizeof(PxBuf) * 3 * 10 + 64 <= 160 * 1024, "ten tiles (twenty waves) per CU with three buffers");
 
 // Which tile each workgroup of k_composite_px takes: the tiles that took longest first.
 // The kernel's duration is its longest tile's plus the time that tile spent sharing its SIMD before it was left alone:
@@ -559,18 +566,32 @@ __device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost,
 }
 
 #ifndef PX_WAVES
-#define PX_WAVES 8 // (every instantiation fits 61 registers without scratch; tuning knob of tools/build_variant.sh: minimum waves per SIMD the register allocation must leave room for)
+#define PX_WAVES 5 // (tuning knob of tools/build_variant.sh: minimum waves per SIMD the register allocation must leave room for; LDS allows 5)
 #endif
-// One workgroup of TWO waves per tile.  Wave 1, the BUILDER, gathers the list's entries (two chunks ahead of their use),
-// and per chunk of 32 builds the tables, the colours and the queue words into one of two LDS buffers; wave 0, the
-// CONSUMER, owns the tile's 256 pixels (2x2 per lane) and walks the other buffer.  One s_barrier per chunk hands a buffer
-// over in each direction.  (One wave doing both — the first version — spent as long staging a chunk, ~230 vector
-// instructions, as walking it, one instruction stream after the other: the kernel is bound by each tile's own latency, not
-// by the device's throughput, and a second instruction stream halves it.)
-// The kernel's duration is its LONGEST tile's (every tile is resident from the start: C2 has 4969 tiles with entries, two
-// waves each, on 8192 wave slots), and while the SIMDs are full every wave advances at an eighth of the speed it has
-// alone.  A tile that is still going after a few chunks is one of the long ones: its waves raise their issue priority
-// with their progress, so the tail runs at full speed from early on instead of from the moment the others have left.
+// One workgroup of TWO waves per tile.  Wave 1, the BUILDER, gathers the list's entries (two chunks ahead of their use)
+// and per chunk of 32 builds the tables, the colours and the queue words into one of AH + 1 LDS buffers; wave 0, the
+// CONSUMER, owns the tile's 256 pixels (2x2 per lane) and walks them.  One s_barrier per chunk: at barrier k the consumer
+// has finished chunk k - 1 and the builder chunk k + AH - 1.
+//
+// Round 4, what changed and why (profiles/r04_*; DESIGN.md "k_composite_px"):
+//   * the tables by RECURRENCE.  Along an axis the Gaussian at pixel pairs p0, p0 + 1, ... is G(u + 2k) = G(u) R(u),
+//     R(u + 2k) = R(u) D with R(u) = exp2(-4k(u + k)), D = exp2(-8k^2): five v_exp_f32 seed a lane's table at the FIRST
+//     COVERED pair of its entry (inside the box the Gaussian is >= exp(-4.5): nothing underflows) and every further pair
+//     costs two packed multiplies instead of two exponentials, a packed multiply-add and a packed square; only the covered
+//     pairs are written (the consumer's queues never send a lane to an uncovered pair), and the two half-covered edge
+//     pairs get their zero by a masked 4-byte store instead of an and-mask on all sixteen values.  In binary32 the
+//     recurrence is no less accurate than the direct form it replaces (worst case over 4e5 random entries: 2.1e-6
+//     absolute against 2.6e-6 — the direct form cancels in x k - c k —; tools/px_recurrence_error.py).
+//   * AH = 2: the builder stays TWO chunks ahead and a lane whose queue for chunk k is empty goes on with its queue for
+//     chunk k + 1 (per-pixel order is the list's order either way).  A chunk's trips are its LONGEST queue's length; lanes
+//     that ran ahead shorten the next chunk's.
+//   * nothing is built or gathered that the previous frame did not need: every launch leaves each tile's cost (chunks
+//     walked) behind, and the next launch over the same band builds and gathers only that many chunks ahead of need
+//     (`limit`).  A tile that turns out to need more — the camera moved — pays one exposed gather + build at the first
+//     chunk past the prediction (both waves meet at one extra barrier) and runs eagerly from there.
+//   * both waves execute the same barriers by construction: the consumer's "every pixel has stopped" is latched into
+//     s_done[(k + 1) & 1] BEFORE barrier k + 1 and read by the builder AFTER it — the word the consumer may write while
+//     walking chunk k + 1 is the other one.
 #ifndef PX_PRIO
 #define PX_PRIO 1
 #endif
@@ -584,10 +605,11 @@ __device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost,
 #else
 #define PX_PRIORITY(N) do { } while (0)
 #endif
-template <bool EARLY_OUT, bool LIT32, bool COUNT>
+template <bool EARLY_OUT, bool LIT32, bool COUNT, int AH>
 __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams p, uint32_t band_tiles) {
-    __shared__ PxBuf s_buf[2];
-    __shared__ uint32_t s_done;
+    constexpr uint32_t NB = AH + 1;
+    __shared__ PxBuf s_buf[NB];
+    __shared__ uint32_t s_done[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // 0 = consumer, 1 = builder (wave-uniform)
     if (blockIdx.x == 0) { // not a tile: the frame's report, and the next launch's tile order
@@ -598,94 +620,94 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     const uint32_t t_local = p.tile_order ? p.tile_order[blockIdx.x - 1u] : blockIdx.x - 1u;
     const uint32_t tx = t_local % p.ntx, ty = t_local / p.ntx + p.tile_row0;
     const uint32_t tile_idx = ty * p.ntx + tx; // ComputeShaderRenderer.ts:161-163
+#ifdef PX_PROFILE
+    const uint32_t count = min(p.counts[tile_idx], p.debug_cap), off = p.offsets[tile_idx];
+#else
     const uint32_t count = p.counts[tile_idx], off = p.offsets[tile_idx];
+#endif
     const uint32_t nchunks = (count + PXC - 1) / PXC;
     const float tile_x0 = (float)(tx * CT), tile_y0 = (float)(ty * CT);
+    // chunks built and gathered ahead of need: what the previous launch over this band walked for this tile (+ the slack the
+    // host asks for), at least one, at most all.  Both waves derive the same value: it decides where they meet.
+    uint32_t lim = nchunks;
+    if (p.cost_prev) lim = min(max(p.cost_prev[t_local] + p.cost_slack, 1u), nchunks);
+    lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)lim);
 
     if (role == 1) {
         // ================================================= builder =================================================
         if (count == 0) return; // (the consumer writes the background; no barrier is executed by either wave)
-        const float tile_cx = tile_x0 + 0.5f, tile_cy = tile_y0 + 0.5f; // :169 pixel centres
         const uint32_t e = lane & 31, h = lane >> 5; // lane (e, h) computes entry e's x (h = 0) or y (h = 1) table
-        if (lane < 32) s_buf[lane >> 4].t[lane & 15][0] = make_float2(0.0f, 0.0f); // the idle slots of both buffers
-        if (lane >= 32 && lane < 34) s_buf[lane - 32].col[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        // Entries are fetched two chunks ahead of their use and their indices three (the gather depends on the index).
-        // Every load of this pipeline is UNCONDITIONAL — positions past the list's end re-read its last entry and are
-        // ignored — and nothing is computed from a loaded value before its chunk comes up: a load under a branch, or a use
-        // at issue, would make the compiler wait for everything in flight (s_waitcnt vmcnt(0)) where it can otherwise count.
+        const float tile_c = (h ? tile_y0 : tile_x0) + 0.5f, tile_0 = h ? tile_y0 : tile_x0; // :169 pixel centres, this lane's axis
+        if (lane < PX_TROWS) { // the idle slots of every buffer
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) s_buf[b].t[lane][0] = make_float2(0.0f, 0.0f);
+        }
+        // Entries are fetched two chunks ahead of their build and their indices three (the gather depends on the index).
+        // Every load of this pipeline is UNCONDITIONAL — positions past the last one wanted re-read that one (one line for
+        // the whole wave) and are ignored — and nothing is computed from a loaded value before its chunk comes up: a load
+        // under a branch, or a use at issue, would make the compiler wait for everything in flight (s_waitcnt vmcnt(0))
+        // where it can otherwise count.
         PxRaw ra = {}, rb = {}, rc = {};
-        const uint32_t last = count - 1u;
-        uint32_t idx_c = p.indices[off + min(2 * PXC + e, last)];
-        px_fetch<LIT32>(p, p.indices[off + min(e, last)], ra);
-        px_fetch<LIT32>(p, p.indices[off + min(PXC + e, last)], rb);
-        uint32_t staged = 0;
+        uint32_t fetch_lim = min(count, lim * PXC) - 1u; // last list position gathered without being asked for
+        uint32_t idx_c = p.indices[off + min(2 * PXC + e, fetch_lim)];
+        px_fetch<LIT32>(p, p.indices[off + min(e, fetch_lim)], ra);
+        px_fetch<LIT32>(p, p.indices[off + min(PXC + e, fetch_lim)], rb);
+        uint32_t staged = min(2u * PXC, fetch_lim + 1u);
+        uint32_t built = 0; // chunks built so far = the next one to build
 #ifdef PX_PROFILE
         const unsigned long long pb0 = __builtin_amdgcn_s_memtime();
-        unsigned long long pb_wait = 0, pb_fetch = 0, pb_chunks = 0;
+        unsigned long long pb_wait = 0, pb_chunks = 0;
 #endif
-        for (uint32_t m = 0;; ++m) { // builds chunk m (chunk 0 before the first barrier, chunk n + 1 while the consumer walks n)
-            const uint32_t cb0 = m * PXC;
-            PX_PRIORITY(m);
-            if (m < nchunks) {
-                staged = min(cb0 + 3 * PXC, count); // entries gathered so far: this chunk and the two fetched ahead
-                px_fetch<LIT32>(p, idx_c, rc);
-                idx_c = p.indices[off + min(cb0 + 3 * PXC + e, last)];
-                PxBuf &B = s_buf[m & 1];
-                float k = 0.0f, ck = 0.0f;
-                uint32_t m16 = 0; // this axis's mask of covered pixel columns / rows (zero unless the entry draws something in this tile)
+        for (uint32_t k = 0;;) { // before barrier k: every chunk below min(k + AH, lim) is built
+            const uint32_t due = min(k + (uint32_t)AH, lim);
+            while (built < due) {
+                const uint32_t m = built, cb0 = m * PXC;
+                PX_PRIORITY(m);
+                px_fetch<LIT32>(p, idx_c, rc); // chunk m + 2
+                idx_c = p.indices[off + min(cb0 + 3 * PXC + e, fetch_lim)];
+                if (COUNT) staged = max(staged, min(cb0 + 3 * PXC, fetch_lim + 1u));
+                PxBuf &B = s_buf[m % NB];
                 float4 b, colr;
                 float rad;
-#ifdef PX_PROFILE
-                const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
-#endif
                 px_unpack<LIT32>(p, ra, b, rad, colr);
-#ifdef PX_PROFILE
-                if (__ballot(rad > 1e30f || colr.x > 1e30f) == 0) { pb_fetch += __builtin_amdgcn_s_memtime() - pf0; pb_chunks++; } // (forces the loads' arrival)
-#endif
-#ifdef PX_BOTH_SPANS // (round 3's first form: every lane computes both axes' spans; measuring knob)
-                if (cb0 + e < count && !(rad < 0.5f)) { // :127-129 "too small"
-                    const uint32_t xm = span_mask16(b.x, b.z, tile_cx), ym = span_mask16(b.y, b.w, tile_cy);
-                    if (xm != 0 && ym != 0) {
-                        k = 1.6986436005760381f * __builtin_amdgcn_rcpf(rad);
-                        const float lx = (b.x + b.z) * 0.5f - tile_x0, ly = (b.y + b.w) * 0.5f - tile_y0; // :124, then exact
-                        ck = (h ? ly : lx) * k;
-                        m16 = h ? ym : xm;
-                    }
-                }
-#else
-                {
-                    // this lane's axis only: its span of covered pixel columns (rows); the other axis's comes from the partner
-                    // lane (e, 1 - h) — v_permlane32_swap, one instruction — because an entry that misses the tile on EITHER
-                    // axis draws nothing in it (ComputeShaderRenderer.ts:118-121)
-                    const float lo = h ? b.y : b.x, hi = h ? b.w : b.z;
-                    uint32_t own = span_mask16(lo, hi, h ? tile_cy : tile_cx);
-                    if (!(cb0 + e < count) || rad < 0.5f) own = 0; // past the list's end; :127-129 "too small"
-                    const v2u sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);
-                    const uint32_t other = h ? sw.x : sw.y;
-                    m16 = other ? own : 0u;
-                    // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r (:133-140), in
-                    // tile-local coordinates (as k_composite); v_rcp_f32, 1 ulp: the correctly rounded quotient costs ten
-                    // instructions on this wave's path.  (An entry that draws nothing has an all-zero mask: its k is never seen.)
-                    k = 1.6986436005760381f * __builtin_amdgcn_rcpf(rad);
-                    ck = ((lo + hi) * 0.5f - (h ? tile_y0 : tile_x0)) * k; // :124, then exact
-                }
-#endif
-                if (h == 0) B.col[1 + e] = make_float4(colr.x, colr.y, colr.z, 1.0f); // (.w = 1: the factor of T's update, see PX_BLEND)
-#pragma unroll
-                for (int c2 = 0; c2 < 8; ++c2) {
-                    const v2f pc = {(float)(2 * c2) + 0.5f, (float)(2 * c2) + 1.5f};
-                    const v2f t = pc * (v2f){k, k} - (v2f){ck, ck};
-                    const v2f q = t * t;
-                    // (the box test — ComputeShaderRenderer.ts:118-121, exact: span_mask16 — as a bit mask on the value:
-                    // v_bfe_i32 spreads the coverage bit over the word)
-                    uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2, 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)m16, 2 * c2 + 1, 1);
-#ifndef PX_MASK_SELECT
-                    asm volatile("" : "+v"(k0), "+v"(k1)); // (kept as v_bfe_i32 + v_and: left alone the compiler makes it and + compare + select)
-#endif
-                    const uint32_t g0 = __float_as_uint(__builtin_amdgcn_exp2f(-q.x)) & k0;
-                    const uint32_t g1 = __float_as_uint(__builtin_amdgcn_exp2f(-q.y)) & k1;
-                    B.t[h * 8 + c2][1 + e] = make_float2(__uint_as_float(g0), __uint_as_float(g1));
-                }
+                // this lane's axis only: its span of covered pixel columns (rows), span_mask16's arithmetic; the other axis's
+                // comes from the partner lane (e, 1 - h) — v_permlane32_swap, one instruction — because an entry that misses
+                // the tile on EITHER axis draws nothing in it (ComputeShaderRenderer.ts:118-121)
+                const float lo = h ? b.y : b.x, hi = h ? b.w : b.z;
+                const float fa = fmaxf(ceilf(lo - tile_c), 0.0f), fb = fminf(floorf(hi - tile_c), 15.0f);
+                const uint32_t ia = (uint32_t)fminf(fa, 15.0f), ib = (uint32_t)fmaxf(fb, 0.0f); // (in range whatever the bounds: an empty span is rejected below)
+                uint32_t own = ((2u << ib) - 1u) & ~((1u << ia) - 1u);
+                if (!(fa <= fb) || !(cb0 + e < count) || rad < 0.5f) own = 0; // (NaN bounds;) past the list's end; :127-129 "too small"
+                const v2u sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);
+                const uint32_t m16 = (h ? sw.x : sw.y) ? own : 0u; // covered columns (rows); zero unless the entry draws something in this tile
+                const uint32_t p0 = ia >> 1, npairs = m16 ? (ib >> 1) - p0 + 1u : 0u;
+                // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r (:133-140), one
+                // axis per lane, in tile-local coordinates.  u = (pixel centre - splat centre) k at the first covered pair's two
+                // pixels; v_rcp_f32, 1 ulp: the correctly rounded quotient costs ten instructions on this wave's path.
+                const float k1 = 1.6986436005760381f * __builtin_amdgcn_rcpf(rad);
+                const float cl = (lo + hi) * 0.5f - tile_0; // :124, then exact
+                const float u0 = ((float)(2u * p0) + 0.5f - cl) * k1, u1 = u0 + k1, u2 = u1 + k1, k4 = 4.0f * k1;
+                v2f G = {__builtin_amdgcn_exp2f(-(u0 * u0)), __builtin_amdgcn_exp2f(-(u1 * u1))};
+                v2f R = {__builtin_amdgcn_exp2f(-(k4 * u1)), __builtin_amdgcn_exp2f(-(k4 * u2))}; // G(u + 2k) / G(u)
+                const float Dd = __builtin_amdgcn_exp2f(-2.0f * (k4 * k1));                        // R(u + 2k) / R(u)
+                const v2f D = {Dd, Dd};
+                float2 *row = &B.t[h * 8 + p0][1 + e];
+                // (nested: the set of lanes still writing only shrinks, and the loop ends with the wave's longest span)
+#define PX_PAIR(I, REST)                                        \
+    if (npairs > (I)) {                                         \
+        row[(I) * PX_ROW] = make_float2(G.x, G.y);              \
+        G *= R;                                                 \
+        R *= D;                                                 \
+        REST                                                    \
+    }
+                PX_PAIR(0, PX_PAIR(1, PX_PAIR(2, PX_PAIR(3, PX_PAIR(4, PX_PAIR(5, PX_PAIR(6, PX_PAIR(7, ))))))))
+#undef PX_PAIR
+                // the box test (ComputeShaderRenderer.ts:118-121, exact: span_mask16's set) on the two pairs the span may
+                // cover by half: the uncovered pixel's factor is zero
+                if (m16 && (ia & 1u)) row[0].x = 0.0f;
+                if (m16 && !(ib & 1u)) row[(npairs - 1u) * PX_ROW].y = 0.0f;
+                // the lit colour as two more rows of the table ({r, g}, {b, 1}: the 1 is the factor of T's update, PX_BLEND)
+                B.t[16 + h][1 + e] = h ? make_float2(colr.z, 1.0f) : make_float2(colr.x, colr.y);
                 // queue words: one ballot gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 the y mask)
                 const uint32_t mm = m16 | (m16 >> 1);
                 unsigned long long bal[8];
@@ -693,24 +715,43 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 for (int c2 = 0; c2 < 8; ++c2) bal[c2] = __ballot((mm >> (2 * c2)) & 1u);
                 if (lane == 0) {
 #pragma unroll
-                    for (int c2 = 0; c2 < 8; ++c2) B.q[c2] = make_uint2((uint32_t)bal[c2], (uint32_t)(bal[c2] >> 32));
+                    for (int c2 = 0; c2 < 4; ++c2)
+                        B.q4[c2] = make_uint4((uint32_t)bal[2 * c2], (uint32_t)(bal[2 * c2] >> 32), (uint32_t)bal[2 * c2 + 1], (uint32_t)(bal[2 * c2 + 1] >> 32));
                 }
                 ra = rb;
                 rb = rc;
+                ++built;
+#ifdef PX_PROFILE
+                pb_chunks++;
+#endif
             }
 #ifdef PX_PROFILE
             const unsigned long long pbw = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads(); // chunk m is the consumer's; the buffer of chunk m - 1 is free again
+            __syncthreads(); // barrier k (or the extra one after a misprediction: the consumer waits for chunk k)
 #ifdef PX_PROFILE
             pb_wait += __builtin_amdgcn_s_memtime() - pbw;
 #endif
-            if (m >= nchunks || (EARLY_OUT && s_done)) break;
+            if (EARLY_OUT && __builtin_amdgcn_readfirstlane((int)s_done[k & 1])) break; // latched before this barrier
+            if (k >= nchunks) break;
+            if (k >= lim) {
+                // the tile needs more than was predicted: gather from chunk k on (an exposed round trip, once), build chunk k
+                // (.. k + AH - 1) at the top of the loop, meet the consumer at the extra barrier, eager from here on
+                lim = nchunks;
+                fetch_lim = count - 1u;
+                idx_c = p.indices[off + min((k + 2u) * PXC + e, fetch_lim)];
+                px_fetch<LIT32>(p, p.indices[off + min(k * PXC + e, fetch_lim)], ra);
+                px_fetch<LIT32>(p, p.indices[off + min((k + 1u) * PXC + e, fetch_lim)], rb);
+                if (COUNT) staged = max(staged, min((k + 2u) * PXC, count));
+                built = k;
+                continue; // (k stays)
+            }
+            ++k;
         }
 #ifdef PX_PROFILE
         if (p.consumed && lane == 0)
             p.consumed[(size_t)tile_idx * 2] = (((__builtin_amdgcn_s_memtime() - pb0) >> 4) & 0xffffull) | (((pb_wait >> 4) & 0xffffull) << 16) |
-                                               (((pb_fetch >> 4) & 0xffffull) << 32) | ((pb_chunks & 0xffffull) << 48);
+                                               ((pb_chunks & 0xffffull) << 48);
         return;
 #endif
         if (COUNT && p.consumed && lane == 0) p.consumed[(size_t)tile_idx * 2] += (unsigned long long)staged;
@@ -728,101 +769,149 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     uint32_t stop_pos = 0; // COUNT: list position after the last entry this lane took while one of its pixels still accumulated
     uint32_t walked = 0;   // chunks this tile needed
     constexpr uint32_t NONE = 0xffffffffu;
+    // byte offsets inside a PxBuf of slot 1 (entry 0) of this lane's x row; its y row and the colour rows relative to that
+    const uint32_t lane_x = (bx * PX_ROW + 1u) * 8u;
+    const uint32_t d_xy = ((8u + by - bx) * PX_ROW) * 8u, d_xc = ((16u - bx) * PX_ROW) * 8u;
+    const char *const lds = reinterpret_cast<const char *>(s_buf);
+    v2f k_huge = {0x1p40f, 0x1p40f}, k_stop = {-T_STOP * 0x1p40f, -T_STOP * 0x1p40f}; // PX_BLEND's stop factor
+    asm volatile("" : "+v"(k_huge), "+v"(k_stop)); // (kept in vector registers: as known constants they are moved there from scalar ones every trip)
 #ifdef PX_PROFILE
     const unsigned long long pc0 = __builtin_amdgcn_s_memtime();
     unsigned long long pc_wait = 0, pc_trips = 0, pc_ntrips = 0;
 #endif
     if (count) {
-        if (lane == 0) s_done = 0;
+        if (lane < 2) s_done[lane] = 0;
+        bool finished = false;      // every pixel has stopped (latched in s_done for the builder)
+        bool carried_ok = false;    // `carried` is what is left of this chunk's queues (the lanes ran ahead into it)
+        uint32_t carried = 0;
+        for (uint32_t k = 0;; ++k) {
 #ifdef PX_PROFILE
-        { const unsigned long long w0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); pc_wait += __builtin_amdgcn_s_memtime() - w0_; }
+            { const unsigned long long w0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); pc_wait += __builtin_amdgcn_s_memtime() - w0_; }
 #else
-        __syncthreads(); // chunk 0 is built
+            __syncthreads(); // barrier k: chunks below min(k + AH, lim) are built; the buffer of chunk k - 1 is the builder's again
 #endif
-        for (uint32_t n = 0; n < nchunks; ++n) {
-            const PxBuf &B = s_buf[n & 1];
-            const uint32_t cb0 = n * PXC;
-            walked = n + 1;
-            PX_PRIORITY(n);
+            if (EARLY_OUT && finished) break;
+            if (k >= nchunks) break;
+            if (k >= lim) { // chunk k was not predicted: the builder gathers and builds it now
+                lim = nchunks;
+                __syncthreads();
+            }
+            const uint32_t o0 = (k % NB) * (uint32_t)sizeof(PxBuf), o1 = ((k + 1u) % NB) * (uint32_t)sizeof(PxBuf);
+            const uint32_t cb0 = k * PXC;
+            walked = k + 1;
+            PX_PRIORITY(k);
+            const bool ahead = AH >= 2 && k + 1u < lim; // chunk k + 1 is built: lanes may run ahead into it
             // a lane whose four pixels have all stopped takes no more entries
             const bool lane_live = !EARLY_OUT || fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y)) > T_STOP;
-            uint32_t mine = lane_live ? (B.q[bx].x & B.q[by].y) : 0u;
-            // ---- trips.  Every lane takes its next entry (the idle one when its queue is empty: no divergence, an idle
-            // lane adds exact zeros); the NEXT entry's table and colour reads are issued before the current one is blended,
-            // so a trip costs its arithmetic, not an LDS round trip.
-#define PX_POP(J, R)                                                                        \
-    do {                                                                                    \
-        R = __ballot(mine != 0); /* lanes that take an entry */                              \
-        J = (uint32_t)(int)__builtin_ctz(mine) | (mine ? 0u : NONE); /* v_ffbl_b32: -1 for 0 */ \
-        mine &= mine - 1u;                                                                  \
+            uint32_t mine, nxt = 0;
+            {
+                const uint2 *q0 = reinterpret_cast<const uint2 *>(lds + o0 + offsetof(PxBuf, q4));
+                mine = carried_ok ? carried : (q0[bx].x & q0[by].y);
+                if (ahead) {
+                    const uint2 *q1 = reinterpret_cast<const uint2 *>(lds + o1 + offsetof(PxBuf, q4));
+                    nxt = q1[bx].x & q1[by].y;
+                }
+                if (!lane_live) mine = nxt = 0;
+                carried_ok = ahead;
+            }
+            const uint32_t nxt0 = nxt;
+            const uint32_t ax0 = o0 + lane_x, ax1 = o1 + lane_x;
+            // ---- trips.  Every lane takes its next entry — of chunk k while it has one, then of chunk k + 1, the idle one when
+            // both queues are empty: no divergence, an idle lane adds exact zeros; the NEXT entry's table and colour reads are
+            // issued before the current one is blended, so a trip costs its arithmetic, not an LDS round trip.
+#define PX_POP(J, R, A, S)                                                                       \
+    do {                                                                                         \
+        uint32_t mc_ = mine;                                                                     \
+        asm("" : "+v"(mc_)); /* (an opaque copy: left visible, the compiler derives `mine != 0` from the borrow of mine - 1 below — three instructions for one compare) */ \
+        const bool sel_ = mc_ != 0;                                                              \
+        R = __ballot(sel_); /* lanes that still have an entry of chunk k: none = the chunk is finished, this trip is not made */ \
+        const uint32_t q_ = (AH >= 2) ? (sel_ ? mine : nxt) : mine;                              \
+        asm("v_ffbl_b32 %0, %1" : "=v"(J) : "v"(q_)); /* -1 for 0 (the idle slot): no select; __builtin_ctz(0) is undefined */ \
+        const uint32_t q2_ = q_ & (q_ - 1u);                                                     \
+        if (AH >= 2) {                                                                           \
+            mine = sel_ ? q2_ : 0u;                                                              \
+            /* an entry of chunk k + 1 leaves a lane's queue only in a trip that is made (R != 0) and only while one of the lane's \
+               pixels still accumulates (as of the blend before last: the walk's cost counts the chunks LIVE lanes touched);   \
+               the mask is scalar work */                                                        \
+            nxt = __builtin_amdgcn_inverse_ballot_w64((R ? R : ~0ull) | ~alive_m) ? nxt : q2_;   \
+            A = sel_ ? ax0 : ax1;                                                                \
+            if (COUNT) S = sel_ ? 0u : (uint32_t)PXC;                                            \
+        } else {                                                                                 \
+            mine = q2_;                                                                          \
+            A = ax0;                                                                             \
+        }                                                                                        \
     } while (0)
-#define PX_LOAD(J, GX, GY, C)        \
-    do {                             \
-        GX = (&B.t[bx][1])[(int)J];      \
-        GY = (&B.t[8 + by][1])[(int)J];  \
-        C = (&B.col[1])[(int)J];         \
+#define PX_LOAD(J, A, GX, GY, C0, C1)                                                  \
+    do {                                                                               \
+        const char *a_ = lds + (A + (uint32_t)((int)J * 8));                           \
+        GX = *reinterpret_cast<const float2 *>(a_);                                    \
+        GY = *reinterpret_cast<const float2 *>(a_ + d_xy);                             \
+        C0 = *reinterpret_cast<const float2 *>(a_ + d_xc);                             \
+        C1 = *reinterpret_cast<const float2 *>(a_ + d_xc + PX_ROW * 8);                \
     } while (0)
-#ifndef PX_KEEP_DEAD_QUEUES // (measuring knob: profiles/r03_h_px_builder_own_axis_span_C2.txt)
-/* a lane whose four pixels have all stopped gives up the rest of its queue at once, not at the next chunk */
-#define PX_DROP_DEAD_LANE(ALIVE) mine = __builtin_amdgcn_inverse_ballot_w64(ALIVE) ? mine : 0u
-#else
-#define PX_DROP_DEAD_LANE(ALIVE) do { } while (0)
-#endif
-#define PX_BLEND(J, R, GX, GY, C)                                                                                             \
+// The per-pixel stop (:187-190: a pixel that has reached alpha >= 0.99, i.e. T <= T_STOP, takes nothing more) as a FACTOR:
+// m = clamp((T - T_STOP) 2^40, 0, 1) is exactly 1 while T > T_STOP (the smallest positive difference of two binary32 numbers
+// near T_STOP is 2^-30) and exactly 0 from then on — one v_pk_fma_f32 with the clamp modifier per pixel PAIR and one packed
+// multiply (w = T g m: the same bits as T g where m = 1), where a compare and a select per PIXEL stood before.
+// CHECK (every other trip; every trip when the consumed entries are counted): which lanes still have a pixel accumulating —
+// a lane with none gives up the rest of its queue at once, not at the next chunk, and when there is none at all the chunk's
+// remaining trips are not made.  Neither changes a pixel: the factor does the stopping.
+#define PX_BLEND(J, R, S, GX, GY, C0, C1, CHECK)                                                                              \
     do {                                                                                                                      \
         const v2f gxx = {GX.x, GX.y};                                                                                         \
         v2f w0 = T[0] * (gxx * (v2f){GY.x, GY.x}), w1 = T[1] * (gxx * (v2f){GY.y, GY.y}); /* rows 2by, 2by+1: w = T g */       \
-        if (EARLY_OUT) { /* :187-190 per pixel: a pixel that has reached alpha >= 0.99 takes nothing more */                   \
-            const unsigned long long a00 = __ballot(T[0].x > T_STOP), a01 = __ballot(T[0].y > T_STOP);                        \
-            const unsigned long long a10 = __ballot(T[1].x > T_STOP), a11 = __ballot(T[1].y > T_STOP);                        \
-            w0.x = __builtin_amdgcn_inverse_ballot_w64(a00) ? w0.x : 0.0f; w0.y = __builtin_amdgcn_inverse_ballot_w64(a01) ? w0.y : 0.0f; \
-            w1.x = __builtin_amdgcn_inverse_ballot_w64(a10) ? w1.x : 0.0f; w1.y = __builtin_amdgcn_inverse_ballot_w64(a11) ? w1.y : 0.0f; \
-            /* COUNT: the last entry a lane takes while one of its pixels still accumulates is the one that stops its last   \
-               pixel (if they all stop) */                                                                                    \
-            if (COUNT) jlast = __builtin_amdgcn_inverse_ballot_w64((a00 | a01 | a10 | a11) & R) ? J : jlast;                  \
-            all_stopped = (a00 | a01 | a10 | a11) == 0; /* (scalar: the four masks are in SGPRs already) */                    \
-            PX_DROP_DEAD_LANE(a00 | a01 | a10 | a11);                                                                         \
+        if (EARLY_OUT) {                                                                                                      \
+            v2f m0, m1;                                                                                                       \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m0) : "v"(T[0]), "v"(k_huge), "v"(k_stop));                        \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m1) : "v"(T[1]), "v"(k_huge), "v"(k_stop));                        \
+            if (CHECK) {                                                                                                      \
+                const v2f ms_ = m0 + m1; /* the four factors are 0 or 1: their sum says whether any pixel of the lane still accumulates */ \
+                const unsigned long long al_ = __ballot(ms_.x + ms_.y > 0.0f);                                               \
+                /* COUNT: the last entry a lane takes while one of its pixels still accumulates is the one that stops its    \
+                   last pixel (if they all stop) */                                                                           \
+                if (COUNT) jlast = (__builtin_amdgcn_inverse_ballot_w64(al_) && J != NONE) ? J + S : jlast;                   \
+                all_stopped = al_ == 0;                                                                                       \
+                mine = __builtin_amdgcn_inverse_ballot_w64(al_) ? mine : 0u;                                                  \
+                alive_m = al_;                                                                                                \
+            }                                                                                                                 \
+            w0 *= m0;                                                                                                         \
+            w1 *= m1;                                                                                                         \
         }                                                                                                                     \
-        cr[0] += (v2f){C.x, C.x} * w0; cr[1] += (v2f){C.x, C.x} * w1; /* SURVEY §8a contract 3: nearest on top */             \
-        cg[0] += (v2f){C.y, C.y} * w0; cg[1] += (v2f){C.y, C.y} * w1;                                                         \
-        cb[0] += (v2f){C.z, C.z} * w0; cb[1] += (v2f){C.z, C.z} * w1;                                                         \
-        /* T (1 - g) with the product in hand; C.w is 1.0 for an entry (the same bits as T - w), 0 for the idle one — its    \
-           use keeps the colour read one 16-byte ds_read_b128 (4 LDS cycles; shrunk to a ds_read_b96 it costs 8) */           \
-        T[0] -= (v2f){C.w, C.w} * w0; T[1] -= (v2f){C.w, C.w} * w1;                                                           \
+        cr[0] += (v2f){C0.x, C0.x} * w0; cr[1] += (v2f){C0.x, C0.x} * w1; /* SURVEY §8a contract 3: nearest on top */         \
+        cg[0] += (v2f){C0.y, C0.y} * w0; cg[1] += (v2f){C0.y, C0.y} * w1;                                                     \
+        cb[0] += (v2f){C1.x, C1.x} * w0; cb[1] += (v2f){C1.x, C1.x} * w1;                                                     \
+        /* T (1 - g) with the product in hand; C1.y is 1.0 for an entry (the same bits as T - w), 0 for the idle one */        \
+        T[0] -= (v2f){C1.y, C1.y} * w0; T[1] -= (v2f){C1.y, C1.y} * w1;                                                       \
     } while (0)
 #ifdef PX_PROFILE
             const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
-            uint32_t ja, jb, jlast = NONE;
+            uint32_t ja, jb, jlast = NONE, aa = 0, ab = 0, sa = 0, sb = 0;
+            unsigned long long alive_m = __ballot(lane_live); // lanes with a pixel still accumulating (as of the last blend)
             bool all_stopped = false; // every pixel of the tile had stopped before the entry just blended: the rest of the chunk is zeros
             unsigned long long ra_, rb_;
-            float2 gxa, gya, gxb, gyb;
-            float4 ca, cb4;
-            PX_POP(ja, ra_);
-            PX_LOAD(ja, gxa, gya, ca);
+            float2 gxa, gya, gxb, gyb, ca0, ca1, cb0_, cb1_;
+            PX_POP(ja, ra_, aa, sa);
+            PX_LOAD(ja, aa, gxa, gya, ca0, ca1);
             for (;;) {
                 if (ra_ == 0) break;
 #ifdef PX_PROFILE
                 pc_ntrips++;
 #endif
-                PX_POP(jb, rb_);
-                PX_LOAD(jb, gxb, gyb, cb4);
+                PX_POP(jb, rb_, ab, sb);
+                PX_LOAD(jb, ab, gxb, gyb, cb0_, cb1_);
                 __builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads to their use, one trip later: the point is lost)
-                PX_BLEND(ja, ra_, gxa, gya, ca);
-#ifndef PX_NO_STOP_BREAK
+                PX_BLEND(ja, ra_, sa, gxa, gya, ca0, ca1, true);
                 if (EARLY_OUT && all_stopped) break;
-#endif
                 if (rb_ == 0) break;
 #ifdef PX_PROFILE
                 pc_ntrips++;
 #endif
-                PX_POP(ja, ra_);
-                PX_LOAD(ja, gxa, gya, ca);
+                PX_POP(ja, ra_, aa, sa);
+                PX_LOAD(ja, aa, gxa, gya, ca0, ca1);
                 __builtin_amdgcn_sched_barrier(0);
-                PX_BLEND(jb, rb_, gxb, gyb, cb4);
-#ifndef PX_NO_STOP_BREAK
+                PX_BLEND(jb, rb_, sb, gxb, gyb, cb0_, cb1_, COUNT);
                 if (EARLY_OUT && all_stopped) break;
-#endif
             }
 #undef PX_POP
 #undef PX_LOAD
@@ -830,24 +919,22 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
 #ifdef PX_PROFILE
             if (__ballot(T[0].x > 1e30f) == 0) pc_trips += __builtin_amdgcn_s_memtime() - pt0;
 #endif
-            if (COUNT && EARLY_OUT && jlast != NONE) stop_pos = cb0 + jlast + 1; // (chunks come in order: later ones overwrite)
+            carried = nxt;
+            // the tile's cost = the chunks it touched: if this turns out to be its last chunk and some lane took an entry of the next
+            // one in passing, the next launch must find that one built as well (or the tile would need it and not have it every
+            // other frame)
+            if (AH >= 2) walked += __ballot(nxt != nxt0) != 0 ? 1u : 0u;
+            if (COUNT && EARLY_OUT && jlast != NONE) stop_pos = cb0 + jlast + 1; // (a lane's entries come in list order: later ones overwrite)
             if (EARLY_OUT) {
                 // the tile is finished when every pixel has stopped: both waves leave after the next barrier
                 const bool live = fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y)) > T_STOP;
-                if (__ballot(live) == 0 && lane == 0) s_done = 1;
+                finished = __ballot(live) == 0;
+                if (finished && lane == 0) s_done[(k + 1u) & 1u] = 1;
             }
-#ifdef PX_PROFILE
-            const unsigned long long pcw = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads(); // chunk n + 1 is built; chunk n's buffer is the builder's again
-#ifdef PX_PROFILE
-            pc_wait += __builtin_amdgcn_s_memtime() - pcw;
-#endif
-            if (EARLY_OUT && s_done) break;
         }
     }
 
-    if (p.tile_cost && lane == 0) p.tile_cost[t_local] = walked; // (what the next launch over this band is ordered by)
+    if (p.tile_cost && lane == 0) p.tile_cost[t_local] = walked; // (what the next launch over this band is ordered and sized by)
 #ifdef PX_PROFILE
     if (p.consumed && lane == 0)
         p.consumed[(size_t)tile_idx * 2 + 1] = (((__builtin_amdgcn_s_memtime() - pc0) >> 4) & 0xffffull) | (((pc_wait >> 4) & 0xffffull) << 16) |
@@ -887,17 +974,24 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     }
 }
 
-static bool g_px_order_on = true; // SPLAT_TILE_ORDER=0 switches the ordering off (read once per process)
+static bool g_px_order_on = true;   // SPLAT_TILE_ORDER=0: workgroups take their tiles row-major (read once per process)
+static bool g_px_predict_on = true; // SPLAT_PX_PREDICT=0: every tile builds and gathers ahead of need without a bound
+static uint32_t g_px_slack = 0;     // SPLAT_PX_SLACK=n: chunks built beyond what the previous launch needed
+static int g_px_ahead = 0;          // SPLAT_PX_AHEAD=1 | 2: chunks the builder stays ahead (2: lanes run ahead too); unset: 1 with the early-out, 2 without
 
-// The per-band ordering state of a context (px_make_order): two cost arrays and two order arrays, alternating.  Launch k
-// over a band writes cost[k & 1], takes its tiles in order[k & 1] — which launch k - 1's ordering workgroup derived from
-// cost[k & 1] as launch k - 2 had left it — and derives order[(k + 1) & 1] from cost[(k + 1) & 1] (launch k - 1's).
+// The per-band history of a context: two cost arrays and two order arrays, alternating.  Launch k over a band writes
+// cost[k & 1]; it sizes every tile's look-ahead by cost[(k + 1) & 1] (launch k - 1's), takes its tiles in order[k & 1] —
+// which launch k - 1's ordering workgroup derived from cost[k & 1] as launch k - 2 had left it — and derives
+// order[(k + 1) & 1] from cost[(k + 1) & 1].  All of it is a hint: any order and any bound give the same image.
 static int px_order_prepare(splat_ctx *ctx, uint32_t band_tiles, uint64_t key, CompositeParams &p) {
     p.tile_order = nullptr;
     p.tile_cost = nullptr;
     p.order_src = nullptr;
     p.order_dst = nullptr;
-    if (!g_px_order_on) return SPLAT_OK;
+    p.cost_prev = nullptr;
+    p.cost_slack = ctx->opt_px_slack >= 0 ? (uint32_t)ctx->opt_px_slack : g_px_slack;
+    const bool predict_on = ctx->opt_px_predict >= 0 ? ctx->opt_px_predict != 0 : g_px_predict_on;
+    if (!g_px_order_on && !predict_on) return SPLAT_OK;
     if (band_tiles > ctx->px_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (a launch in flight may still write the old arrays)
         if (ctx->px_mem) (void)hipFree(ctx->px_mem);
@@ -915,13 +1009,27 @@ static int px_order_prepare(splat_ctx *ctx, uint32_t band_tiles, uint64_t key, C
     uint32_t *cost[2] = {ctx->px_mem, ctx->px_mem + ctx->px_cap}, *order[2] = {ctx->px_mem + 2 * (size_t)ctx->px_cap, ctx->px_mem + 3 * (size_t)ctx->px_cap};
     const uint32_t q = ctx->px_parity & 1u;
     p.tile_cost = cost[q];
-    if (ctx->px_streak >= 2) p.tile_order = order[q]; // written by the previous launch from the costs of the one before it
-    if (ctx->px_streak >= 1) {                         // the previous launch left its costs: sort them for the next launch
-        p.order_src = cost[q ^ 1u];
-        p.order_dst = order[q ^ 1u];
+    if (g_px_order_on && ctx->px_streak >= 2) p.tile_order = order[q]; // written by the previous launch from the costs of the one before it
+    if (ctx->px_streak >= 1) {                                          // the previous launch left its costs
+        if (predict_on) p.cost_prev = cost[q ^ 1u];
+        if (g_px_order_on) { // sort them for the next launch
+            p.order_src = cost[q ^ 1u];
+            p.order_dst = order[q ^ 1u];
+        }
     }
     ctx->px_parity ^= 1u;
     if (ctx->px_streak < 2) ctx->px_streak++;
+#ifdef PX_PROFILE
+    { // (measuring build only, SPLAT_PX_FREEZE=1: the order found by the first launches is kept and no launch computes another: is the ordering workgroup free?)
+        static int freeze = -1;
+        static uint32_t *frozen = nullptr;
+        if (freeze < 0) freeze = getenv("SPLAT_PX_FREEZE") ? 1 : 0;
+        if (freeze) {
+            if (frozen && p.tile_order) { p.tile_order = frozen; p.order_src = nullptr; p.order_dst = nullptr; }
+            else if (p.tile_order) frozen = const_cast<uint32_t *>(p.tile_order);
+        }
+    }
+#endif
     return SPLAT_OK;
 }
 
@@ -1026,6 +1134,11 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     p.tile_cost = nullptr;
     p.order_src = nullptr;
     p.order_dst = nullptr;
+    p.cost_prev = nullptr;
+    p.cost_slack = 0;
+#ifdef PX_PROFILE
+    p.debug_cap = getenv("SPLAT_PX_CAP") ? (uint32_t)strtoul(getenv("SPLAT_PX_CAP"), nullptr, 10) : 0xffffffffu;
+#endif
     dim3 grid(ntx, r1 - r0), block(256);
     const bool eo = cfg->early_out != 0;
     // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
@@ -1052,24 +1165,46 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     if (s_px == -2) {
         const char *e = getenv("SPLAT_COMPOSITE");
         s_px = !e ? -1 : (e[0] == 'p' || e[0] == 'P') ? 1 : (e[0] == 'q' || e[0] == 'Q') ? 0 : -1;
-        const char *o = getenv("SPLAT_TILE_ORDER"); // =0: workgroups take tiles row-major (A/B knob for k_tile_order)
+        const char *o = getenv("SPLAT_TILE_ORDER"); // =0: workgroups take tiles row-major
         g_px_order_on = !(o && o[0] == '0');
+        const char *pr = getenv("SPLAT_PX_PREDICT"); // =0: no look-ahead bound from the previous launch's costs
+        g_px_predict_on = !(pr && pr[0] == '0');
+        const char *sl = getenv("SPLAT_PX_SLACK");
+        if (sl) g_px_slack = (uint32_t)strtoul(sl, nullptr, 10);
+        const char *ah = getenv("SPLAT_PX_AHEAD");
+        g_px_ahead = !ah ? 0 : ah[0] == '1' ? 1 : 2;
     }
+    const int opt_kernel = ctx->opt_composite_kernel >= 0 ? ctx->opt_composite_kernel : s_px;
+    // Two chunks ahead with lanes running ahead makes 27 % fewer trips, each four instructions longer, on five waves per
+    // SIMD instead of eight (three table buffers): a gain where every list is walked to its end (early-out off: C2 319 ->
+    // 298 us), a loss where most tiles stop after a few chunks and a tile's life is mostly latency (50.6 -> 52.8 us):
+    // profiles/r04_b_px_ab_C2.txt
+    const int opt_ahead = ctx->opt_px_ahead > 0 ? ctx->opt_px_ahead : g_px_ahead > 0 ? g_px_ahead : (cfg->early_out ? 1 : 2);
     const uint32_t band_tiles = ntx * (r1 - r0);
-    const bool use_px = !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && (s_px == 1 || (s_px == -1 && ntx * nty >= PX_MIN_TILES));
+    const bool use_px = !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && (opt_kernel == 1 || (opt_kernel == -1 && ntx * nty >= PX_MIN_TILES));
     if (use_px) {
-        const uint64_t key = ((uint64_t)ntx << 40) ^ ((uint64_t)r0 << 20) ^ (uint64_t)r1 ^ ((uint64_t)width << 50) ^ 1u;
+        // (the band, the screen, and whose lists these are: two binners on one context do not share a history)
+        const uint64_t key = (((uint64_t)ntx << 40) ^ ((uint64_t)r0 << 20) ^ (uint64_t)r1 ^ ((uint64_t)width << 50) ^
+                              ((uint64_t)(uintptr_t)tile_counts * 0x9E3779B97F4A7C15ull)) | 1u;
         int orc = px_order_prepare(ctx, band_tiles, key, p);
         if (orc != SPLAT_OK) return orc;
         if (ctx->debug_tile_order) p.tile_order = ctx->debug_tile_order;
         // one workgroup of two waves (consumer, builder) per tile, behind workgroup 0 (report, next launch's tile order)
         const dim3 pgrid(band_tiles + 1u), pblock(128);
-#define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT)                                                                                   \
-    do {                                                                                                                     \
-        if (timed && p.consumed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, true>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
-        else if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, false>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles);      \
-        else if (p.consumed) hipLaunchKernelGGL((k_composite_px<EO, LIT, true>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                   \
-        else hipLaunchKernelGGL((k_composite_px<EO, LIT, false>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                                  \
+#define SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, CNT, AH)                                                                             \
+    do {                                                                                                                        \
+        if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, CNT, AH>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
+        else hipLaunchKernelGGL((k_composite_px<EO, LIT, CNT, AH>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                       \
+    } while (0)
+#define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT)                                       \
+    do {                                                                         \
+        if (opt_ahead == 2) {                                                    \
+            if (p.consumed) SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, true, 2);        \
+            else            SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, false, 2);       \
+        } else {                                                                 \
+            if (p.consumed) SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, true, 1);        \
+            else            SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, false, 1);       \
+        }                                                                        \
     } while (0)
         if (lit32) {
             if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, true);
@@ -1078,6 +1213,7 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
             if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, false);
             else    SPLAT_COMPOSITE_PX_LAUNCH(false, false);
         }
+#undef SPLAT_COMPOSITE_PX_LAUNCH2
 #undef SPLAT_COMPOSITE_PX_LAUNCH
         *launched = hipPeekAtLastError() == hipSuccess; // (only a launch that went out carries the frame's report: composite_launch sends it otherwise)
         LAUNCH_CHECK(ctx, "k_composite_px");

@@ -799,6 +799,25 @@ int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_
     return SPLAT_OK;
 }
 
+int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict, int slack) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, kernel >= -1 && kernel <= 1 && ahead >= 0 && ahead <= 2 && predict >= -1 && predict <= 1 && slack >= -1 && slack <= 1024);
+    ctx->opt_composite_kernel = kernel;
+    ctx->opt_px_ahead = ahead;
+    ctx->opt_px_predict = predict;
+    ctx->opt_px_slack = slack;
+    ctx->px_key = 0; // (another schedule: its costs mean something else)
+    ctx->px_streak = 0;
+    return SPLAT_OK;
+}
+
+int splat_composite_forget_history(splat_ctx *ctx) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ctx->px_key = 0;
+    ctx->px_streak = 0;
+    return SPLAT_OK;
+}
+
 int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ctx->debug_tile_order = (const uint32_t *)order_dptr;

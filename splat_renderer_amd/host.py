@@ -140,6 +140,18 @@ class Device:
         return {"policy": ("checked", "atomic", "ballot")[pol.value], "atomicsOrdered": bool(ordered.value == 1),
                 "orderFaults": int(faults.value)}
 
+    def forgetCompositeHistory(self):
+        """splat_composite_forget_history: the lane-efficient composite's next launches run as a context's first do (row-major,
+        no look-ahead bound from an earlier launch's per-tile costs)."""
+        check(self.lib.splat_composite_forget_history(self.ctx), self.ctx)
+
+    def compositeOptions(self, kernel=None, ahead=0, predict=None, slack=None):
+        """splat_composite_options: kernel None (library default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict None |
+        False | True; slack None | chunks.  Every combination gives the same image."""
+        k = -1 if kernel is None else {"quadrant": 0, "pixel": 1}[kernel]
+        check(self.lib.splat_composite_options(self.ctx, k, int(ahead), -1 if predict is None else int(bool(predict)),
+                                               -1 if slack is None else int(slack)), self.ctx)
+
     def injectOrderFault(self, tile, position=0):
         """TEST HOOK (splat_debug_inject_order_fault): the next per-tile sort leaves entries position, position + 1 of tile
         `tile`'s list swapped."""

@@ -270,10 +270,34 @@ def test_bin_empty(device):
     b.destroy()
 
 
+# Which kernel composites, and for k_composite_px on which schedule (Device.compositeOptions; every combination must give the
+# oracle's image and the oracle's per-tile stop positions):
+#   default   the library's choice: k_composite on these screens (fewer than 2048 tiles)
+#   px1       k_composite_px, builder one chunk ahead, no lane runs ahead, first launch (no history)
+#   px2       k_composite_px as frames run it (builder two chunks ahead, lanes run ahead), first launch
+#   px2_warm  the same after two launches over the same lists: every tile's look-ahead is what the launch before walked
+#   px2_under / px1_under  the launch before saw EMPTY lists (costs 0): every tile that needs a second chunk is mispredicted and
+#             takes the on-demand path (exposed gather, extra barrier)
+#   px2_slack the warm launch with two chunks of slack added to every bound
+COMPOSITE_KERNELS = ["default", "px1", "px2", "px2_warm", "px2_under", "px1_under", "px2_slack"]
+
+
 @pytest.mark.parametrize("n,w,h,seed,rs", CASES)
 @pytest.mark.parametrize("mode", [sr.MODE_FRONT_TO_BACK, sr.MODE_REFERENCE_LITERAL])
 @pytest.mark.parametrize("early_out", [False, True])
-def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
+@pytest.mark.parametrize("kernel", COMPOSITE_KERNELS)
+def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel):
+    if kernel != "default" and mode != sr.MODE_FRONT_TO_BACK:
+        pytest.skip("k_composite_px composites nearest-on-top only")
+    try:
+        if kernel != "default":
+            device.compositeOptions("pixel", ahead=1 if kernel.startswith("px1") else 2, predict=True, slack=2 if kernel == "px2_slack" else 0)
+        composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel)
+    finally:
+        device.compositeOptions()  # the library's defaults again (the context is shared)
+
+
+def composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel):
     props, normals, u = make_case(n, w, h, seed, rs)
     ref = oracle_pipeline(props, normals, u, w, h)
     want, want8, _, stop, near = O.composite(mode, early_out, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
@@ -285,11 +309,23 @@ def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
         r = sr.ComputeShaderRenderer(device, None, "rgba8unorm", mode=mode, earlyOut=early_out, recordFormat=fmt)
         r.consumedBuffer = device.createBuffer(ntx * nty * 16)
         r.consumedBuffer.zero()
+        device.forgetCompositeHistory()  # (the shared context may hold another scene's per-tile costs for this screen size)
         records = g["proj"].getProjectedBuffer()
         if fmt == _lib.RECORDS_LIT32:  # the frame's lit composite records, built here from the oracle's stages
             records = device.createBufferFrom(lit_records(u, props, normals))
-        r.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], records,
-                 b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h, wantFloat=True)
+        render = lambda: r.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], records,
+                                  b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h, wantFloat=True)
+        if kernel in ("px2_warm", "px2_slack"):  # two launches leave costs and an order behind for the third
+            render()
+            render()
+        elif kernel.endswith("_under"):  # a launch over empty lists leaves cost 0 for every tile
+            cbuf = b.getTileCountsBuffer()
+            saved = cbuf.read(np.uint32).copy()
+            cbuf.write(np.zeros_like(saved))
+            render()
+            cbuf.write(saved)
+        r.consumedBuffer.zero()
+        render()
         got = r.readPixelsFloat()
         got8 = r.readPixels()
         check_image_against_oracle(got, got8, want, want8, near if early_out else None)
@@ -301,17 +337,23 @@ def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out):
         ok = ~tile_near.reshape(-1)
         assert_same(cons[ok, 1], tile_stop.reshape(-1)[ok].astype(np.uint64), "L301")
         # entries gathered: k_composite_px (nearest-on-top on screens of at least 2048 tiles, or SPLAT_COMPOSITE=pixel) works in
-        # chunks of 32, builds one chunk ahead of the one being walked and fetches two further ahead; k_composite (smaller
-        # screens, the reference-literal blend, SPLAT_COMPOSITE=quadrant) stages batches of 256
+        # chunks of 32; its builder stays two chunks ahead of the chunk being walked and fetches two further ahead — unless
+        # the previous launch over the same band left costs behind, in which case it gathers what THAT launch walked and
+        # anything beyond only when it is needed (the shared test context may hold such a history, from another scene:
+        # any bound gives the same image).  k_composite (smaller screens, the reference-literal blend,
+        # SPLAT_COMPOSITE=quadrant) stages batches of 256
         counts64 = ref["counts"].astype(np.uint64)
-        forced = os.environ.get("SPLAT_COMPOSITE", "")[:1].lower()
+        forced = "p" if kernel != "default" else os.environ.get("SPLAT_COMPOSITE", "")[:1].lower()
         px = mode == sr.MODE_FRONT_TO_BACK and (forced == "p" or (forced != "q" and ntx * nty >= 2048))
-        if px and early_out:  # walked chunks = ceil(consumed / 32); the builder was building the next and had fetched two more
-            staged_want = np.minimum(counts64, (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32) + np.uint64(96))
-            # (a tile whose builder had not yet started the chunk after the last walked one when the consumer finished has
-            # fetched one chunk less: both are what the kernel does, depending on which wave reached the barrier first)
-            alt = np.minimum(counts64, (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32) + np.uint64(64))
-            assert np.all((cons[:, 0] == staged_want) | (cons[:, 0] == alt)), "entries staged per tile (k_composite_px)"
+        if px and early_out:
+            walked = (cons[:, 1] + np.uint64(31)) // np.uint64(32) * np.uint64(32)
+            # at least every walked chunk, at most the look-ahead beyond them (2 built + 2 fetched); a tile is done when all
+            # its pixels have stopped at a chunk's END, so one whose last pixel stops on a chunk's last entry walks no more
+            assert np.all(cons[:, 0] >= np.minimum(counts64, cons[:, 1])), "entries staged per tile (k_composite_px): fewer than consumed"
+            slack = np.uint64(64 if kernel == "px2_slack" else 0)
+            assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(128) + slack)), "entries staged per tile (k_composite_px): beyond the look-ahead"
+            if kernel == "px2_warm":  # nothing gathered beyond the chunks the tile touches (the last walked, or the one after it)
+                assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(32))), "a warm launch gathers only what the one before needed"
             staged_want = cons[:, 0]
         elif px:
             staged_want = counts64
@@ -1010,7 +1052,8 @@ def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again(mo
             dev.injectOrderFault(victim, position)
             r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
             total = r.finish()  # learns of the failed check, renders the frame again (with ballots)
-            assert r.previousFrameOverflowed  # (the facade's "a frame had to be rendered again" flag)
+            # the facade books it as a MISRANKED frame, apart from capacity events (one flag for both hid it)
+            assert r.framesMisranked == 1 and not r.previousFrameOverflowed
             st = dev.rankStatus()
             assert st["policy"] == "ballot" and st["orderFaults"] == 1, st
             assert total == ref["indices"].shape[0]

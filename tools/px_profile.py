@@ -40,7 +40,14 @@ f = lambda x, k: ((x >> np.uint64(16 * k)) & np.uint64(0xffff)).astype(np.float6
 nz = counts > 0
 b_life, b_wait, b_fetch, b_chunks = f(v[:, 0], 0) * 16, f(v[:, 0], 1) * 16, f(v[:, 0], 2) * 16, f(v[:, 0], 3)
 c_life, c_wait, c_trips, c_ntrips = f(v[:, 1], 0) * 16, f(v[:, 1], 1) * 16, f(v[:, 1], 2) * 16, f(v[:, 1], 3)
+if len(sys.argv) > 3:  # per-tile arrays for offline analysis
+    np.savez_compressed(sys.argv[3], counts=counts, b_life=b_life, b_wait=b_wait, b_chunks=b_chunks, c_life=c_life, c_wait=c_wait,
+                        c_trips=c_trips, c_ntrips=c_ntrips)
 print(f"{name} early_out={eo}: tiles with entries {nz.sum()} (cycles; a life beyond 1.05M cycles wraps)")
+top = np.argsort(-c_life)[:12]
+print("  the longest-lived tiles: tile count chunks | consumer life, barrier wait, in trips, trips | builder life, barrier wait")
+for t in top:
+    print(f"    {t:5d} {counts[t]:5d} {b_chunks[t]:3.0f} | {c_life[t]:7.0f} {c_wait[t]:7.0f} {c_trips[t]:7.0f} {c_ntrips[t]:4.0f} | {b_life[t]:7.0f} {b_wait[t]:7.0f}")
 for lab, a in (("consumer life", c_life), ("consumer barrier wait", c_wait), ("consumer in trip loops", c_trips), ("consumer trips", c_ntrips),
                ("builder life", b_life), ("builder barrier wait", b_wait), ("builder record wait", b_fetch), ("builder chunks built", b_chunks)):
     x = a[nz]
