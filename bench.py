@@ -169,6 +169,60 @@ def time_composite_alone(dev, r, u, pbuf, nbuf, width, height, tile, early_out, 
     return {"ms": tot.value / max(cnt.value, 1), "staged": float(cons[0]), "consumed": float(cons[1])}
 
 
+def orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, static_ms, static_composite_ms, frames=60, degrees=0.5):
+    """K frames of an orbit, the camera turned by `degrees` of azimuth between frames by OrbitCameraController (a drag of
+    degrees / 0.005 rad-per-pixel pixels: OrbitCameraController.ts:12,47-49), through FrameLoop; ms/frame, the composite's own
+    duration, frames that had to be rendered again.  Then the same orbit with the composite's two history-fed mechanisms
+    switched, to say which one a slowdown comes from."""
+    lib, ctx = dev.lib, dev.ctx
+    loop = sr.FrameLoop(dev, n, width, height, tile, records=args.records)
+    ctrl = sr.OrbitCameraController(loop.camera)
+    dx = np.radians(degrees) / ctrl.rotationSpeed
+    ctrl.onMouseDown(sr.MouseEvent(0.0, 0.0, 0))
+
+    def run(k_frames, x0):
+        uniforms = []
+        for k in range(k_frames):  # the camera path first: the host's matrix arithmetic is not what is measured
+            ctrl.onMouseMove(sr.MouseEvent(x0 + (k + 1) * dx, 0.0, 0))
+            uniforms.append(loop.camera.uniforms(width, height, time=k / 60.0).copy())
+        again = 0
+        dev.sync()
+        t0 = time.perf_counter()
+        for uk in uniforms:
+            loop.renderer.previousFrameOverflowed = False
+            loop.renderer.render(uk, pbuf, nbuf, None, width, height)
+            again += int(loop.renderer.previousFrameOverflowed)
+        dev.sync()
+        return (time.perf_counter() - t0) / k_frames * 1e3, again, x0 + k_frames * dx
+
+    def leg(label, **opts):
+        dev.compositeOptions(**opts)
+        _, _, x = run(12, leg.x)  # the history re-learns under the moving camera
+        _lib.check(lib.splat_set_timing_stages(ctx, 1 << _lib.STAGE_COMPOSITE), ctx)
+        dev.setTiming(True)
+        ms, again, leg.x = run(frames, x)
+        cnt, tot = C.c_uint32(), C.c_double()
+        _lib.check(lib.splat_stage_time_stats(ctx, _lib.STAGE_COMPOSITE, C.byref(cnt), C.byref(tot)), ctx)
+        dev.setTiming(False)
+        loop.renderer.finish()
+        return {"ms_per_step": round(ms, 4), "composite_ms": round(tot.value / max(cnt.value, 1), 4), "frames_rendered_again": again}
+    leg.x = 0.0
+    out = leg("default")
+    out.update({"frames": frames, "degrees_per_frame": degrees, "value": n / out["ms_per_step"] / 1e3, "unit": "Msplats/s",
+                "static_ms_per_step": round(static_ms, 4), "static_composite_ms": round(static_composite_ms, 4),
+                "over_static": round(out["ms_per_step"] / static_ms, 4),
+                "frames_misranked": loop.renderer.framesMisranked,
+                "note": "FrameLoop + OrbitCameraController, frames enqueued back to back (no host sync between frames); the static figures are "
+                        "the timed region's"})
+    # which mechanism: the same orbit without the look-ahead bound, and with one chunk of slack on it
+    out["without_lookahead_bound"] = leg("nopredict", predict=False)
+    out["with_one_chunk_of_slack"] = leg("slack1", slack=1)
+    dev.compositeOptions()
+    ctrl.onMouseUp()
+    loop.destroy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,6 +429,15 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                         "a frame's latency is unchanged"}
         except Exception as e:  # (an extra: never costs the run its headline)
             result.setdefault("extra", {})["two_frames_in_flight"] = {"error": repr(e)}
+    if not disc and not args.no_extras:
+        # The camera MOVES in the reference's loop (src/main.ts:110-193, OrbitCameraController.ts:42-58): the timed region
+        # above renders one view K times, which is the best case of everything the frame learns from the frame before it
+        # (the composite's tile order and per-tile look-ahead, the sync-free pair limit).  Here: a left-button drag of
+        # 0.5 degrees of azimuth per frame through the controller, frames enqueued back to back, nothing read in between.
+        try:
+            result.setdefault("extra", {})["orbit"] = orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, dt / args.steps * 1e3, composite_ms)
+        except Exception as e:  # (an extra: never costs the run its headline)
+            result.setdefault("extra", {})["orbit"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         cb = cpu_baseline(name, props, normals, u, width, height)
         ref8 = cb.pop("frame_u8")

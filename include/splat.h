@@ -381,7 +381,12 @@ int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected,
  * filter (kept count on the device) -> depth sort -> bin.  records: n_records records in
  * cfg->record_format whose position is the global splat index (the all-gathered shards);
  * props/normals: the full scene in the reference's layouts (props = interleaved records); with
- * cfg->prelit, props is the plane of lit colours (splat_lit_colors) and normals may be NULL. */
+ * cfg->prelit, props is the plane of lit colours (splat_lit_colors) and normals may be NULL.
+ * cfg->record_format = SPLAT_RECORDS_LIT32 (tile-first order, 16-byte exchange records in `records` all the same): the call
+ * also writes the frame's 32-byte lit composite record for every splat the band KEEPS and composites from those — one
+ * gathered line per staged list entry, as the single-GPU frame — instead of exchange record + colour (+ normal).  Same
+ * image.  Not the default: on eight virtual ranks of C2 the composite gains 2-4 us per rank and writing the records costs
+ * 21 us (profiles/r04_c_band_lit_records_C2.txt). */
 int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                      const splat_composite_cfg *cfg, const void *props, const void *normals,
                      const void *records, uint32_t n_records, uint32_t width, uint32_t height,

@@ -558,6 +558,7 @@ void splat_bin_destroy(splat_binner *b) {
     binner_free_wide(b);
     if (b->expanded) (void)hipFree(b->expanded);
     if (b->discs) (void)hipFree(b->discs);
+    if (b->band_lit) (void)hipFree(b->band_lit);
     if (b->pinned) (void)hipHostFree(b->pinned);
     if (b->readback_done) (void)hipEventDestroy(b->readback_done);
     delete b;

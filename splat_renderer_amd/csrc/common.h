@@ -165,6 +165,8 @@ struct splat_binner {
     uint32_t expanded_cap = 0;
     void *discs = nullptr;                          // frame path, oriented-disc footprint: the projector's 32-byte disc records
     uint32_t discs_cap = 0;
+    void *band_lit = nullptr;                       // multi-GPU band frame: 32-byte lit composite records of the splats the band keeps (shade.h)
+    uint32_t band_lit_cap = 0;
     bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
     uint32_t tf_block = 1024;                       // splats per block of that histogram (TF_BLOCK_SMALL for small frames)
     uint64_t total = 0;

@@ -691,7 +691,8 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 v2f R = {__builtin_amdgcn_exp2f(-(k4 * u1)), __builtin_amdgcn_exp2f(-(k4 * u2))}; // G(u + 2k) / G(u)
                 const float Dd = __builtin_amdgcn_exp2f(-2.0f * (k4 * k1));                        // R(u + 2k) / R(u)
                 const v2f D = {Dd, Dd};
-                float2 *row = &B.t[h * 8 + p0][1 + e];
+                // (24-bit multiply: v_mul_lo_u32 is a quarter-rate instruction)
+                float2 *row = reinterpret_cast<float2 *>(reinterpret_cast<char *>(&B.t[h * 8][1 + e]) + __umul24(p0, PX_ROW * 8u));
                 // (nested: the set of lanes still writing only shrinks, and the loop ends with the wave's longest span)
 #define PX_PAIR(I, REST)                                        \
     if (npairs > (I)) {                                         \
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 // the box test (ComputeShaderRenderer.ts:118-121, exact: span_mask16's set) on the two pairs the span may
                 // cover by half: the uncovered pixel's factor is zero
                 if (m16 && (ia & 1u)) row[0].x = 0.0f;
-                if (m16 && !(ib & 1u)) row[(npairs - 1u) * PX_ROW].y = 0.0f;
+                if (m16 && !(ib & 1u)) reinterpret_cast<float2 *>(reinterpret_cast<char *>(row) + __umul24(npairs - 1u, PX_ROW * 8u))->y = 0.0f;
                 // the lit colour as two more rows of the table ({r, g}, {b, 1}: the 1 is the factor of T's update, PX_BLEND)
                 B.t[16 + h][1 + e] = h ? make_float2(colr.z, 1.0f) : make_float2(colr.x, colr.y);
                 // queue words: one ballot gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 the y mask)

@@ -183,13 +183,15 @@ class HipStages:
     def project_slice(self, uniforms, props_ptr, first, count, out_records, normals_ptr=None):
         _project_slice(self.lib, self.ctx, self.disc, uniforms, props_ptr, normals_ptr, first, count, out_records)
 
-    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False):
+    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False, lit_records=False):
         """settle=False (frame loops): sync-free; a frame whose pairs outgrew 1.5x the previous frame's
         is only noticed at the next call (which then has room).  settle=True: wait for this frame's pair
         total and render it again if it overflowed — results are final on return."""
         prelit = self.lit is not None
+        # lit_records: the band builds 32-byte lit composite records for the splats it keeps and composites from those (one
+        # gathered line per staged entry instead of two or three; same image; measured slower on eight ranks — splat.h)
         cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1,
-                           _lib.RECORDS_DISC48 if self.disc else _lib.RECORDS_COMPACT, int(prelit),
+                           _lib.RECORDS_DISC48 if self.disc else _lib.RECORDS_LIT32 if lit_records else _lib.RECORDS_COMPACT, int(prelit),
                            _lib.FOOTPRINT_DISC if self.disc else _lib.FOOTPRINT_ISOTROPIC)
         if prelit:
             props_ptr, normals_ptr = self.lit.data_ptr(), None
@@ -307,7 +309,8 @@ class BandRenderer:
     """One rank of a multi-GPU frame.  `all_gather(out, shard)` is AbiAllGather (the C ABI's RCCL communicator) or
     torch.distributed.all_gather_into_tensor (RCCL on GPUs; gloo in the CPU tests)."""
 
-    def __init__(self, stages, n, width, height, rank, world, all_gather, tile=TILE):
+    def __init__(self, stages, n, width, height, rank, world, all_gather, tile=TILE, gathered=None):
+        # gathered: a records tensor to gather into instead of one of this renderer's own (virtual ranks on one device share it)
         self.stages, self.n, self.rank, self.world = stages, n, rank, world
         self.width, self.height, self.tile = width, height, tile
         self.per = shard_size(n, world)
@@ -317,7 +320,7 @@ class BandRenderer:
         self.all_gather = all_gather
         # shard padding (indices >= n) is all-NaN once: NaN bins nowhere and never changes
         self.shard = stages.new_records(self.per, fill_nan=True)
-        self.gathered = stages.new_records(self.per * world) if world > 1 else self.shard
+        self.gathered = gathered if gathered is not None else stages.new_records(self.per * world) if world > 1 else self.shard
         self.image = stages.new_image()
 
     def render(self, uniforms, props_ptr, normals_ptr, settle=False):

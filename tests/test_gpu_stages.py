@@ -527,7 +527,9 @@ def test_virtual_ranks_band_frame_matches_single_gpu(device, world):
     got = np.zeros_like(want)
     kept = []
     for br in renderers:  # phase 2: every rank renders its band from the gathered records
-        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=True)
+        # (every other rank with the band's own lit composite records for the splats it keeps: splat_band_frame, SPLAT_RECORDS_LIT32)
+        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=True,
+                          lit_records=bool(br.rank & 1))
         torch.cuda.synchronize()
         r0, r1 = br.pixel_rows()
         got[r0:r1] = br.image.cpu().numpy()[r0:r1]
@@ -1687,3 +1689,63 @@ def test_pipelined_renderer_keeps_frames_identical(device):
     assert len({w_.tobytes() for w_ in want}) == len(want)
     for o in (pr, one, pbuf, nbuf):
         o.destroy()
+
+
+def test_C4_workload_eight_virtual_ranks_through_the_all_gather_cut(device):
+    """BASELINE.json configs[4] — 10M Gaussians @3840x2160 sharded by tile rows over 8 ranks with ONE all-gather of projected
+    splats — as far as one GPU can run it: the eight ranks' device work runs in turn on the one device.  Every rank projects
+    its slice of the splats into 16-byte exchange records (splat_project_slice_compact), every shard travels through the C
+    ABI's own RCCL communicator (a one-rank communicator: the collective is real, its peers are not), and every rank renders
+    its band — cut so that the bands carry equal pairs, as bench.py cuts them — from the gathered records (splat_band_frame:
+    band filter + tile-first binning + lit composite records for the kept splats + composite).  The stitched rgba8 image
+    must be the single-GPU C3 frame byte for byte, the bands' pair totals must add up to the frame's 29 483 686, and every
+    rank's gathered blocks must be what a local projection of the other ranks' slices gives."""
+    import torch
+    from splat_renderer_amd import dist
+    name, world = "C3", 8
+    n, w, h = sr.scene.CONFIGS[name]
+    props, normals, u = make_case(n, w, h)
+    pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)
+    full = sr.Renderer(device, None, "rgba8unorm", n)
+    full.render(u, pbuf, nbuf, None, w, h)
+    assert full.finish() == FULL_SIZE_PAIRS[name]
+    want = full.readPixels().copy()
+    for o in (full, pbuf, nbuf):
+        o.destroy()
+    pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
+    per = dist.shard_size(n, world)
+    stages = dist.HipStages(torch, 0, per * world, w, h)
+    gather = dist.AbiAllGather(torch, stages, 0, 1, lambda ident: ident)
+    gathered = stages.new_records(per * world)
+    ranks = []
+    for r in range(world):  # phase 1: every rank projects its slice; the communicator delivers it into its block
+        br = dist.BandRenderer(stages, n, w, h, r, world, None, gathered=gathered)  # (the virtual ranks share the gathered records)
+        stages.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard)
+        gather(gathered[r * per:(r + 1) * per], br.shard)
+        ranks.append(br)
+    torch.cuda.synchronize()
+    # the bands: equal pairs per band from the rows' pair counts (one calibration frame over all rows, as bench.py's first frame)
+    nty = -(-h // 16)
+    stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), 0, nty, ranks[0].image, settle=True)
+    rows = stages.row_pairs()
+    assert int(rows.sum()) == FULL_SIZE_PAIRS[name] == stages.pairs
+    bands = dist.balanced_rows(rows, world)
+    assert bands[0][0] == 0 and bands[-1][1] == nty and all(bands[r][1] == bands[r + 1][0] for r in range(world - 1))
+    got = np.zeros_like(want)
+    pairs, kept = [], []
+    for r, br in enumerate(ranks):  # phase 2: every rank renders its band from the gathered records, twice (the second sync-free)
+        br.row0, br.row1 = bands[r]
+        for settle in (False, True):
+            stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=settle)
+        pairs.append(stages.pairs)
+        kept.append(stages.kept)
+        assert br.verify_exchange(u, pt.data_ptr()) == world - 1, f"rank {r}: a gathered block differs from a local projection of that slice"
+        r0, r1 = br.pixel_rows()
+        got[r0:r1] = br.image.cpu().numpy()[r0:r1]
+    assert_same(got, want, "C4: the eight bands do not stitch into the single-GPU frame")
+    assert sum(pairs) == FULL_SIZE_PAIRS[name], pairs
+    assert max(pairs) <= 1.2 * min(pairs), f"bands are cut for equal pairs: {pairs}"
+    assert all(0 < k < n for k in kept) and sum(kept) >= n * 0.9, kept
+    assert stages.overflows == 0 and stages.misranked == 0 and stages.rank_status()["orderFaults"] == 0
+    gather.destroy()
+    stages.destroy()

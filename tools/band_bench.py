@@ -25,7 +25,8 @@ pt, nt = torch.from_numpy(props).cuda(), torch.from_numpy(normals).cuda()
 for world in worlds:
     per = dist.shard_size(n, world)
     st = dist.HipStages(torch, 0, per * world, w, h, footprint=footprint)
-    st.set_lit(pt.data_ptr(), nt.data_ptr(), n)  # shading once per property update (as bench.py does)
+    if os.environ.get("BAND_LAYOUT", "planes") != "interleaved":  # (bench.py's --layout: interleaved is its default, planes = lit once per property update)
+        st.set_lit(pt.data_ptr(), nt.data_ptr(), n)
     brs = [dist.BandRenderer(st, n, w, h, r, world, None) for r in range(world)]
     for br in brs:
         st.project_slice(u, pt.data_ptr(), br.first, br.count, br.shard, nt.data_ptr())
@@ -49,6 +50,14 @@ for world in worlds:
             st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), r0, r1, br.image)
         torch.cuda.synchronize()
         out.append(((time.perf_counter() - t0) / K * 1e3, r1 - r0, st.kept))
+        if os.environ.get("BAND_STAGES"):  # per-stage HIP-event intervals of this rank's band frame (every stage's events on: ~5 us of idle each)
+            from splat_renderer_amd import _lib
+            st.set_timing(True)
+            for _ in range(5):
+                st.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), r0, r1, br.image)
+            torch.cuda.synchronize()
+            print(f"   rank {r}: " + "  ".join(f"{nm} {st.stage_avg_ms(i) * 1e3:.1f}" for i, nm in enumerate(_lib.STAGE_NAMES) if st.stage_avg_ms(i) > 0) + " us")
+            st.set_timing(False)
     print(f"{name} {footprint} G={world}: per-rank ms (rows, kept): " + "  ".join(f"{t:.3f} ({rr},{k})" for t, rr, k in out)
           + f"   max {max(t for t, _, _ in out):.3f} ms  [+ all-gather of {per * st.rec_floats * 4 / 1e6:.0f} MB shards]")
     st.destroy()
