@@ -351,7 +351,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     key = name + (("_disc" if prelit else "_unmeasured") if disc else "" if (args.records == "lit" and not prelit) else
                   "_projected_records_prelit_planes" if (args.records == "projected" and prelit) else "_unmeasured")
     pmc = load_traffic(key)
-    px = (not disc) and ntx * nty >= 2048 and os.environ.get("SPLAT_COMPOSITE", "")[:1].lower() != "q" or os.environ.get("SPLAT_COMPOSITE", "")[:1].lower() == "p"
+    px = ntx * nty >= 2048 and os.environ.get("SPLAT_COMPOSITE", "")[:1].lower() != "q" or os.environ.get("SPLAT_COMPOSITE", "")[:1].lower() == "p"
     roofline = {"kernel": "k_composite_px" if px else "k_composite", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"],
@@ -681,7 +681,7 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    "composite": "front-to-back, early-out at alpha>=0.99",
                    "ranking": {"policy": [("checked", "atomic", "ballot")[i[8]] for i in infos], "atomicsOrdered": [bool(i[9]) for i in infos],
                                "orderFaults": [i[10] for i in infos]}},
-        "roofline": {"kernel": "k_composite_px" if (ntx * nty >= 2048 and not stages.disc) else "k_composite", "bound": "hbm", "achieved": achieved,
+        "roofline": {"kernel": "k_composite_px" if ntx * nty >= 2048 else "k_composite", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": comp_bytes,
                      "avg_launch_ms": infos[slow][4] / 1e6, "rank": slow},
         "cpu_baseline": None,  # reported at N=1 only

@@ -42,7 +42,8 @@ struct CompositeParams {
     uint32_t compact;
     uint32_t lit32;                                // projected holds lit composite records (shade.h): colour and normals are not read
     uint32_t disc;                                 // projected holds disc records (disc.h): the oriented-disc footprint
-    uint32_t disc_stride;                          // float4s between disc records: 2 (projector's) or 3 (48-byte exchange records)
+    uint32_t disc_stride;                          // float4s between disc records: 2 (projector's) or 3 (48-byte exchange records, lit disc records)
+    uint32_t disc_lit;                             // the third float4 of a disc record is the splat's lit colour: colour and normals are not read
     uint32_t prelit;                               // color holds lit colours (k_lit_colors): normals are not read
     const uint32_t *indices, *counts, *offsets;
     uint32_t width, height, ntx, tile_row0;
@@ -145,6 +146,10 @@ __device__ __forceinline__ void fetch_entry(const CompositeParams &p, uint32_t i
     if constexpr (DISC) {
         f_b = p.projected[(size_t)idx * p.disc_stride];
         f_b2 = p.projected[(size_t)idx * p.disc_stride + 1];
+        if (p.disc_lit) {
+            f_c = p.projected[(size_t)idx * p.disc_stride + 2];
+            return;
+        }
     } else if constexpr (LIT32) {
         const float4 c = p.projected[(size_t)idx * 2];
         f_c = p.projected[(size_t)idx * 2 + 1];
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
                 const DiscRecord rec = {f_b, f_b2};
                 float4 bnd;
                 if (disc_bounds(rec, bnd)) { // (a culled splat's record is all zeros and is in no list anyway)
-                    const float4 c = p.prelit ? f_c : lit_color(f_c, f_n);
+                    const float4 c = (p.prelit || p.disc_lit) ? f_c : lit_color(f_c, f_n);
                     col = make_float2(c.x, c.y);
                     col_b = c.z;
                     geo = make_float4(f_b.x, f_b.y, -f_b2.z, -f_b2.w);
@@ -436,7 +441,19 @@ __global__ __launch_bounds__(256) void k_composite(CompositeParams p) {
 struct PxRaw {
     float4 a, c, n;
     float r;
+    float4 a2; // DISC: the disc record's second half
 };
+// DISC (the oriented-disc footprint): a, a2 = the 32-byte disc record (disc.h), c = colour, n = normal
+__device__ __forceinline__ void px_fetch_disc(const CompositeParams &p, uint32_t idx, PxRaw &o) {
+    o.a = p.projected[(size_t)idx * p.disc_stride];
+    o.a2 = p.projected[(size_t)idx * p.disc_stride + 1];
+    if (p.disc_lit) { // (lit disc records: one 48-byte gather is all)
+        o.c = p.projected[(size_t)idx * p.disc_stride + 2];
+        return;
+    }
+    o.c = p.color[(size_t)idx * p.color_stride];
+    if (!p.prelit) o.n = p.normals[(size_t)idx * p.normal_stride];
+}
 template <bool LIT32>
 __device__ __forceinline__ void px_fetch(const CompositeParams &p, uint32_t idx, PxRaw &o) {
     if constexpr (LIT32) {
@@ -488,6 +505,15 @@ struct PxBuf {
     uint4 q4[4];                // as uint2 q[8]: q[c].x: bit j = entry j's box meets pixel columns 2c, 2c+1; q[r].y: ... pixel rows 2r, 2r+1
 };
 static_assert(sizeof(PxBuf) * 3 * 10 + 64 <= 160 * 1024, "ten tiles (twenty waves) per CU with three buffers");
+// The same for the oriented-disc footprint (SequentialRenderer.ts:91-142; disc.h), which is not separable: no tables — per
+// entry the inverse homography's eleven numbers, evaluated by the consumer for the four pixels of every lane the entry's
+// box touches (k_composite evaluates it for all 64 pixels of every quadrant the box touches).
+struct PxBufDisc {
+    float4 par[PXC + 1][3]; // par[1 + j] = {c.x, c.y, -q0, -q1}, {B00, B10, B01, B11}, {lit r, g, b, 1}; par[0]: zeros (the idle entry)
+    uint4 q4[4];            // the queue words, as PxBuf's
+};
+template <bool DISC> struct PxBufOf { typedef PxBuf type; };
+template <> struct PxBufOf<true> { typedef PxBufDisc type; };
 
 // Which tile each workgroup of k_composite_px takes: the tiles that took longest first.
 // The kernel's duration is its longest tile's plus the time that tile spent sharing its SIMD before it was left alone:
@@ -500,6 +526,7 @@ static_assert(sizeof(PxBuf) * 3 * 10 + 64 <= 160 * 1024, "ten tiles (twenty wave
 // sorts them into nine classes, longest first, empty tiles last, for the launch after.  The order only says who goes
 // first: any order (a stale one, one from another scene) gives the same image.
 constexpr uint32_t PX_CLASSES = 9;
+constexpr uint32_t PX_ORDER_SCRATCH = (PX_CLASSES * 128 + 2 * PX_CLASSES) * 4; // px_make_order's LDS, carved out of the table buffers
 __device__ __forceinline__ uint32_t px_cost_class(uint32_t c) { // 0 = longest ... 8 = no entries
     return 8u - ((c >= 1) + (c >= 3) + (c >= 5) + (c >= 7) + (c >= 9) + (c >= 12) + (c >= 16) + (c >= 24));
 }
@@ -585,10 +612,11 @@ __device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost,
 //   * AH = 2: the builder stays TWO chunks ahead and a lane whose queue for chunk k is empty goes on with its queue for
 //     chunk k + 1 (per-pixel order is the list's order either way).  A chunk's trips are its LONGEST queue's length; lanes
 //     that ran ahead shorten the next chunk's.
-//   * nothing is built or gathered that the previous frame did not need: every launch leaves each tile's cost (chunks
-//     walked) behind, and the next launch over the same band builds and gathers only that many chunks ahead of need
-//     (`limit`).  A tile that turns out to need more — the camera moved — pays one exposed gather + build at the first
-//     chunk past the prediction (both waves meet at one extra barrier) and runs eagerly from there.
+//   * nothing is built that the previous frame did not need, and one chunk more than that is gathered: every launch
+//     leaves each tile's cost (chunks touched) behind, and the next launch over the same band builds only that many chunks
+//     ahead of need (`lim`).  A tile that turns out to need more — the camera moved — finds the next chunk's records in
+//     registers, pays its build at the first chunk past the prediction (both waves meet at one extra barrier) and runs
+//     eagerly from there.
 //   * both waves execute the same barriers by construction: the consumer's "every pixel has stopped" is latched into
 //     s_done[(k + 1) & 1] BEFORE barrier k + 1 and read by the builder AFTER it — the word the consumer may write while
 //     walking chunk k + 1 is the other one.
@@ -605,10 +633,13 @@ __device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost,
 #else
 #define PX_PRIORITY(N) do { } while (0)
 #endif
-template <bool EARLY_OUT, bool LIT32, bool COUNT, int AH>
+template <bool EARLY_OUT, bool LIT32, bool COUNT, int AH, bool DISC>
 __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams p, uint32_t band_tiles) {
     constexpr uint32_t NB = AH + 1;
-    __shared__ PxBuf s_buf[NB];
+    typedef typename PxBufOf<DISC>::type Buf;
+    constexpr uint32_t BUF_BYTES = NB * sizeof(Buf) > PX_ORDER_SCRATCH ? NB * sizeof(Buf) : PX_ORDER_SCRATCH;
+    __shared__ __attribute__((aligned(16))) char s_raw[BUF_BYTES];
+    Buf *const s_buf = reinterpret_cast<Buf *>(s_raw);
     __shared__ uint32_t s_done[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // 0 = consumer, 1 = builder (wave-uniform)
@@ -638,7 +669,9 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
         if (count == 0) return; // (the consumer writes the background; no barrier is executed by either wave)
         const uint32_t e = lane & 31, h = lane >> 5; // lane (e, h) computes entry e's x (h = 0) or y (h = 1) table
         const float tile_c = (h ? tile_y0 : tile_x0) + 0.5f, tile_0 = h ? tile_y0 : tile_x0; // :169 pixel centres, this lane's axis
-        if (lane < PX_TROWS) { // the idle slots of every buffer
+        if constexpr (DISC) {
+            if (lane < 3 * NB) s_buf[lane / 3].par[0][lane % 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // the idle entry of every buffer
+        } else if (lane < PX_TROWS) { // the idle slots of every buffer
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) s_buf[b].t[lane][0] = make_float2(0.0f, 0.0f);
         }
@@ -648,10 +681,14 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
         // under a branch, or a use at issue, would make the compiler wait for everything in flight (s_waitcnt vmcnt(0))
         // where it can otherwise count.
         PxRaw ra = {}, rb = {}, rc = {};
-        uint32_t fetch_lim = min(count, lim * PXC) - 1u; // last list position gathered without being asked for
+        // last list position gathered without being asked for: one chunk beyond the last one BUILT ahead of need, so that a tile
+        // which turns out to need one more chunk than the previous frame (the camera moved) finds its records in registers
+        // already and pays a build, not a gather
+        uint32_t fetch_lim = min(count, (lim + 1u) * PXC) - 1u;
         uint32_t idx_c = p.indices[off + min(2 * PXC + e, fetch_lim)];
-        px_fetch<LIT32>(p, p.indices[off + min(e, fetch_lim)], ra);
-        px_fetch<LIT32>(p, p.indices[off + min(PXC + e, fetch_lim)], rb);
+#define PX_FETCH(IDX, DST) do { if constexpr (DISC) px_fetch_disc(p, IDX, DST); else px_fetch<LIT32>(p, IDX, DST); } while (0)
+        PX_FETCH(p.indices[off + min(e, fetch_lim)], ra);
+        PX_FETCH(p.indices[off + min(PXC + e, fetch_lim)], rb);
         uint32_t staged = min(2u * PXC, fetch_lim + 1u);
         uint32_t built = 0; // chunks built so far = the next one to build
 #ifdef PX_PROFILE
@@ -663,13 +700,19 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             while (built < due) {
                 const uint32_t m = built, cb0 = m * PXC;
                 PX_PRIORITY(m);
-                px_fetch<LIT32>(p, idx_c, rc); // chunk m + 2
+                PX_FETCH(idx_c, rc); // chunk m + 2
                 idx_c = p.indices[off + min(cb0 + 3 * PXC + e, fetch_lim)];
                 if (COUNT) staged = max(staged, min(cb0 + 3 * PXC, fetch_lim + 1u));
-                PxBuf &B = s_buf[m % NB];
+                Buf &B = s_buf[m % NB];
                 float4 b, colr;
                 float rad;
-                px_unpack<LIT32>(p, ra, b, rad, colr);
+                if constexpr (DISC) { // the disc's exact screen bounds (what the binner's tile ranges came from); a culled or degenerate record has none
+                    const DiscRecord drec = {ra.a, ra.a2};
+                    rad = disc_bounds(drec, b) ? 1.0f : 0.0f;
+                    colr = (p.prelit || p.disc_lit) ? ra.c : lit_color(ra.c, ra.n);
+                } else {
+                    px_unpack<LIT32>(p, ra, b, rad, colr);
+                }
                 // this lane's axis only: its span of covered pixel columns (rows), span_mask16's arithmetic; the other axis's
                 // comes from the partner lane (e, 1 - h) — v_permlane32_swap, one instruction — because an entry that misses
                 // the tile on EITHER axis draws nothing in it (ComputeShaderRenderer.ts:118-121)
@@ -680,6 +723,15 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 if (!(fa <= fb) || !(cb0 + e < count) || rad < 0.5f) own = 0; // (NaN bounds;) past the list's end; :127-129 "too small"
                 const v2u sw = __builtin_amdgcn_permlane32_swap(own, own, false, false);
                 const uint32_t m16 = (h ? sw.x : sw.y) ? own : 0u; // covered columns (rows); zero unless the entry draws something in this tile
+                if constexpr (DISC) {
+                    // the inverse homography of the entry (disc.h: (u, v) = B d / (1 - q.d)) and its lit colour, as the consumer reads them
+                    if (h == 0) {
+                        B.par[1 + e][0] = make_float4(ra.a.x, ra.a.y, -ra.a2.z, -ra.a2.w);
+                        B.par[1 + e][1] = make_float4(ra.a.z, ra.a2.x, ra.a.w, ra.a2.y); // B by columns
+                    } else {
+                        B.par[1 + e][2] = make_float4(colr.x, colr.y, colr.z, 1.0f);
+                    }
+                } else {
                 const uint32_t p0 = ia >> 1, npairs = m16 ? (ib >> 1) - p0 + 1u : 0u;
                 // gaussian = exp(-0.5 (dist / r)^2 / 0.25) = exp2(-((dx k)^2 + (dy k)^2)), k = sqrt(2 log2 e) / r (:133-140), one
                 // axis per lane, in tile-local coordinates.  u = (pixel centre - splat centre) k at the first covered pair's two
@@ -709,6 +761,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 if (m16 && !(ib & 1u)) reinterpret_cast<float2 *>(reinterpret_cast<char *>(row) + __umul24(npairs - 1u, PX_ROW * 8u))->y = 0.0f;
                 // the lit colour as two more rows of the table ({r, g}, {b, 1}: the 1 is the factor of T's update, PX_BLEND)
                 B.t[16 + h][1 + e] = h ? make_float2(colr.z, 1.0f) : make_float2(colr.x, colr.y);
+                }
                 // queue words: one ballot gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 the y mask)
                 const uint32_t mm = m16 | (m16 >> 1);
                 unsigned long long bal[8];
@@ -736,13 +789,13 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             if (EARLY_OUT && __builtin_amdgcn_readfirstlane((int)s_done[k & 1])) break; // latched before this barrier
             if (k >= nchunks) break;
             if (k >= lim) {
-                // the tile needs more than was predicted: gather from chunk k on (an exposed round trip, once), build chunk k
-                // (.. k + AH - 1) at the top of the loop, meet the consumer at the extra barrier, eager from here on
+                // the tile needs more than was predicted: chunk k's records are here (ra: gathered one chunk beyond the bound);
+                // chunk k + 1's gather goes out now, chunk k (.. k + AH - 1) is built at the top of the loop, the consumer is
+                // met at the extra barrier, and the tile runs eagerly from here on
                 lim = nchunks;
                 fetch_lim = count - 1u;
                 idx_c = p.indices[off + min((k + 2u) * PXC + e, fetch_lim)];
-                px_fetch<LIT32>(p, p.indices[off + min(k * PXC + e, fetch_lim)], ra);
-                px_fetch<LIT32>(p, p.indices[off + min((k + 1u) * PXC + e, fetch_lim)], rb);
+                PX_FETCH(p.indices[off + min((k + 1u) * PXC + e, fetch_lim)], rb);
                 if (COUNT) staged = max(staged, min((k + 2u) * PXC, count));
                 built = k;
                 continue; // (k stays)
@@ -771,11 +824,19 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     uint32_t walked = 0;   // chunks this tile needed
     constexpr uint32_t NONE = 0xffffffffu;
     // byte offsets inside a PxBuf of slot 1 (entry 0) of this lane's x row; its y row and the colour rows relative to that
-    const uint32_t lane_x = (bx * PX_ROW + 1u) * 8u;
+    // (DISC: slot 1 of the parameter array, the same for every lane)
+    const uint32_t lane_x = DISC ? 48u : (bx * PX_ROW + 1u) * 8u;
     const uint32_t d_xy = ((8u + by - bx) * PX_ROW) * 8u, d_xc = ((16u - bx) * PX_ROW) * 8u;
+    // DISC: this lane's pixel centres (:169; global coordinates, as the disc records' centres are)
+    const v2f pxc = {(float)px0 + 0.5f, (float)px0 + 1.5f}, pyc = {(float)py0 + 0.5f, (float)py0 + 1.5f};
     const char *const lds = reinterpret_cast<const char *>(s_buf);
     v2f k_huge = {0x1p40f, 0x1p40f}, k_stop = {-T_STOP * 0x1p40f, -T_STOP * 0x1p40f}; // PX_BLEND's stop factor
     asm volatile("" : "+v"(k_huge), "+v"(k_stop)); // (kept in vector registers: as known constants they are moved there from scalar ones every trip)
+    // PX_DISC_ROW's inside factor, (1 - d2) 2^23 + 1: 1 at d2 = 1, 0 at the next binary32 number above it, exact in one fused
+    // operation (2^23 + 1 is the largest odd number a binary32 holds next to 2^23)
+    v2f k_in_a = {-0x1p23f, -0x1p23f}, k_in_b = {0x1p23f + 1.0f, 0x1p23f + 1.0f};
+    static_assert(0x1p23f + 1.0f == 8388609.0f, "2^23 + 1 is a binary32 number");
+    if (DISC) asm volatile("" : "+v"(k_in_a), "+v"(k_in_b));
 #ifdef PX_PROFILE
     const unsigned long long pc0 = __builtin_amdgcn_s_memtime();
     unsigned long long pc_wait = 0, pc_trips = 0, pc_ntrips = 0;
@@ -797,7 +858,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 lim = nchunks;
                 __syncthreads();
             }
-            const uint32_t o0 = (k % NB) * (uint32_t)sizeof(PxBuf), o1 = ((k + 1u) % NB) * (uint32_t)sizeof(PxBuf);
+            const uint32_t o0 = (k % NB) * (uint32_t)sizeof(Buf), o1 = ((k + 1u) % NB) * (uint32_t)sizeof(Buf);
             const uint32_t cb0 = k * PXC;
             walked = k + 1;
             PX_PRIORITY(k);
@@ -806,10 +867,10 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             const bool lane_live = !EARLY_OUT || fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y)) > T_STOP;
             uint32_t mine, nxt = 0;
             {
-                const uint2 *q0 = reinterpret_cast<const uint2 *>(lds + o0 + offsetof(PxBuf, q4));
+                const uint2 *q0 = reinterpret_cast<const uint2 *>(lds + o0 + offsetof(Buf, q4));
                 mine = carried_ok ? carried : (q0[bx].x & q0[by].y);
                 if (ahead) {
-                    const uint2 *q1 = reinterpret_cast<const uint2 *>(lds + o1 + offsetof(PxBuf, q4));
+                    const uint2 *q1 = reinterpret_cast<const uint2 *>(lds + o1 + offsetof(Buf, q4));
                     nxt = q1[bx].x & q1[by].y;
                 }
                 if (!lane_live) mine = nxt = 0;
@@ -842,13 +903,20 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             A = ax0;                                                                             \
         }                                                                                        \
     } while (0)
-#define PX_LOAD(J, A, GX, GY, C0, C1)                                                  \
+#define PX_LOAD(J, A, E)                                                               \
     do {                                                                               \
-        const char *a_ = lds + (A + (uint32_t)((int)J * 8));                           \
-        GX = *reinterpret_cast<const float2 *>(a_);                                    \
-        GY = *reinterpret_cast<const float2 *>(a_ + d_xy);                             \
-        C0 = *reinterpret_cast<const float2 *>(a_ + d_xc);                             \
-        C1 = *reinterpret_cast<const float2 *>(a_ + d_xc + PX_ROW * 8);                \
+        if constexpr (DISC) {                                                          \
+            const float4 *a_ = reinterpret_cast<const float4 *>(lds + (A + (uint32_t)((int)J * 48))); \
+            E.p0 = a_[0];                                                              \
+            E.p1 = a_[1];                                                              \
+            E.p2 = a_[2];                                                              \
+        } else {                                                                       \
+            const char *a_ = lds + (A + (uint32_t)((int)J * 8));                       \
+            E.gx = *reinterpret_cast<const float2 *>(a_);                              \
+            E.gy = *reinterpret_cast<const float2 *>(a_ + d_xy);                       \
+            E.c0 = *reinterpret_cast<const float2 *>(a_ + d_xc);                       \
+            E.c1 = *reinterpret_cast<const float2 *>(a_ + d_xc + PX_ROW * 8);          \
+        }                                                                              \
     } while (0)
 // The per-pixel stop (:187-190: a pixel that has reached alpha >= 0.99, i.e. T <= T_STOP, takes nothing more) as a FACTOR:
 // m = clamp((T - T_STOP) 2^40, 0, 1) is exactly 1 while T > T_STOP (the smallest positive difference of two binary32 numbers
@@ -857,10 +925,48 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
 // CHECK (every other trip; every trip when the consumed entries are counted): which lanes still have a pixel accumulating —
 // a lane with none gives up the rest of its queue at once, not at the next chunk, and when there is none at all the chunk's
 // remaining trips are not made.  Neither changes a pixel: the factor does the stopping.
-#define PX_BLEND(J, R, S, GX, GY, C0, C1, CHECK)                                                                              \
+// DISC: the footprint of SequentialRenderer.ts:91-142 per pixel (disc.h): (u, v) = B d / (1 - q.d) with d = pixel centre -
+// disc centre, inside when u^2 + v^2 <= 1 (:128-130), gaussian exp(-0.5 d2 / 0.16) (:132-133).  Per row of the lane's 2x2
+// block the two columns go through packed arithmetic; the row's own terms (q1 dy, B01 dy, B11 dy) are scalars of it.
+#define PX_DISC_ROW(DY, G)                                                                                                    \
     do {                                                                                                                      \
-        const v2f gxx = {GX.x, GX.y};                                                                                         \
-        v2f w0 = T[0] * (gxx * (v2f){GY.x, GY.x}), w1 = T[1] * (gxx * (v2f){GY.y, GY.y}); /* rows 2by, 2by+1: w = T g */       \
+        const float s_ = __builtin_fmaf(E_.p0.w, DY, 1.0f);                         /* 1 - q1 dy */                            \
+        const v2f den_ = (v2f){E_.p0.z, E_.p0.z} * dx_ + (v2f){s_, s_};             /* 1 - q.d   */                            \
+        const v2f rd_ = {__builtin_amdgcn_rcpf(den_.x), __builtin_amdgcn_rcpf(den_.y)};                                       \
+        const v2f by_ = (v2f){E_.p1.z, E_.p1.w} * (v2f){DY, DY};                    /* B01 dy, B11 dy */                       \
+        const v2f nu_ = (v2f){E_.p1.x, E_.p1.x} * dx_ + (v2f){by_.x, by_.x};        /* (B d) */                                \
+        const v2f nv_ = (v2f){E_.p1.y, E_.p1.y} * dx_ + (v2f){by_.y, by_.y};                                                  \
+        /* :126 u^2 + v^2 = |B d|^2 / (1 - q.d)^2 — in this form no 0 * inf can arise (|B d| = 0 only at the centre, where    \
+           1 - q.d = 1): a pixel on the disc plane's horizon line gets inf (outside), never NaN */                            \
+        const v2f d2_ = (nu_ * nu_ + nv_ * nv_) * (rd_ * rd_);                                                                \
+        const v2f ar_ = d2_ * (v2f){DISC_EXP2_SCALE, DISC_EXP2_SCALE};                                                        \
+        /* :128-133 discard outside the unit circle, as a factor: clamp((1 - d2) 2^23 + 1, 0, 1) is exactly 1 for d2 <= 1 and  \
+           exactly 0 from the next binary32 number above 1 on (and for NaN): one packed multiply-add for two compares + selects */ \
+        v2f in_;                                                                                                              \
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(in_) : "v"(d2_), "v"(k_in_a), "v"(k_in_b));                             \
+        G = (v2f){__builtin_amdgcn_exp2f(ar_.x), __builtin_amdgcn_exp2f(ar_.y)} * in_;                                        \
+    } while (0)
+#define PX_BLEND(J, R, S, E, CHECK)                                                                                           \
+    do {                                                                                                                      \
+        const auto &E_ = E;                                                                                                   \
+        v2f w0, w1;                                                                                                           \
+        float2 C0, C1;                                                                                                        \
+        if constexpr (DISC) {                                                                                                 \
+            const v2f dx_ = pxc - (v2f){E_.p0.x, E_.p0.x};                                                                    \
+            v2f g0_, g1_;                                                                                                     \
+            PX_DISC_ROW(pyc.x - E_.p0.y, g0_);                                                                                \
+            PX_DISC_ROW(pyc.y - E_.p0.y, g1_);                                                                                \
+            w0 = T[0] * g0_;                                                                                                  \
+            w1 = T[1] * g1_;                                                                                                  \
+            C0 = make_float2(E_.p2.x, E_.p2.y);                                                                               \
+            C1 = make_float2(E_.p2.z, E_.p2.w);                                                                               \
+        } else {                                                                                                              \
+            const v2f gxx = {E_.gx.x, E_.gx.y};                                                                               \
+            w0 = T[0] * (gxx * (v2f){E_.gy.x, E_.gy.x});                            /* rows 2by, 2by+1: w = T g */             \
+            w1 = T[1] * (gxx * (v2f){E_.gy.y, E_.gy.y});                                                                      \
+            C0 = E_.c0;                                                                                                       \
+            C1 = E_.c1;                                                                                                       \
+        }                                                                                                                     \
         if (EARLY_OUT) {                                                                                                      \
             v2f m0, m1;                                                                                                       \
             asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m0) : "v"(T[0]), "v"(k_huge), "v"(k_stop));                        \
@@ -891,32 +997,36 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             unsigned long long alive_m = __ballot(lane_live); // lanes with a pixel still accumulating (as of the last blend)
             bool all_stopped = false; // every pixel of the tile had stopped before the entry just blended: the rest of the chunk is zeros
             unsigned long long ra_, rb_;
-            float2 gxa, gya, gxb, gyb, ca0, ca1, cb0_, cb1_;
+            struct PxEnt { // what a trip reads of its entry: table values and colour, or (DISC) the three parameter vectors
+                float2 gx, gy, c0, c1;
+                float4 p0, p1, p2;
+            } ea, eb;
             PX_POP(ja, ra_, aa, sa);
-            PX_LOAD(ja, aa, gxa, gya, ca0, ca1);
+            PX_LOAD(ja, aa, ea);
             for (;;) {
                 if (ra_ == 0) break;
 #ifdef PX_PROFILE
                 pc_ntrips++;
 #endif
                 PX_POP(jb, rb_, ab, sb);
-                PX_LOAD(jb, ab, gxb, gyb, cb0_, cb1_);
+                PX_LOAD(jb, ab, eb);
                 __builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads to their use, one trip later: the point is lost)
-                PX_BLEND(ja, ra_, sa, gxa, gya, ca0, ca1, true);
+                PX_BLEND(ja, ra_, sa, ea, true);
                 if (EARLY_OUT && all_stopped) break;
                 if (rb_ == 0) break;
 #ifdef PX_PROFILE
                 pc_ntrips++;
 #endif
                 PX_POP(ja, ra_, aa, sa);
-                PX_LOAD(ja, aa, gxa, gya, ca0, ca1);
+                PX_LOAD(ja, aa, ea);
                 __builtin_amdgcn_sched_barrier(0);
-                PX_BLEND(jb, rb_, sb, gxb, gyb, cb0_, cb1_, COUNT);
+                PX_BLEND(jb, rb_, sb, eb, COUNT);
                 if (EARLY_OUT && all_stopped) break;
             }
 #undef PX_POP
 #undef PX_LOAD
 #undef PX_BLEND
+#undef PX_DISC_ROW
 #ifdef PX_PROFILE
             if (__ballot(T[0].x > 1e30f) == 0) pc_trips += __builtin_amdgcn_s_memtime() - pt0;
 #endif
@@ -1092,7 +1202,8 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     ARG_CHECK(ctx, cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK || cfg->mode == SPLAT_COMPOSITE_REFERENCE_LITERAL);
     ARG_CHECK(ctx, cfg->record_format <= SPLAT_RECORDS_LIT32);
     ARG_CHECK(ctx, width >= 1 && height >= 1 && width <= 65535u * CT && height <= 65535u * CT);
-    const bool lit32 = cfg->record_format == SPLAT_RECORDS_LIT32; // the records carry the lit colour: no colour / normal arrays
+    // the records carry the lit colour (isotropic: 32-byte lit composite records; disc: the colour behind each disc record): no colour / normal arrays
+    const bool lit32 = cfg->record_format == SPLAT_RECORDS_LIT32;
     ARG_CHECK(ctx, lit32 || (color_opacity && (normals || cfg->prelit)));
     ARG_CHECK(ctx, projected && tile_indices && tile_counts && tile_offsets);
     ARG_CHECK(ctx, color_stride_vec4 >= 1 && normal_stride_vec4 >= 1);
@@ -1102,7 +1213,7 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     // the oriented disc is SequentialRenderer's footprint: nearest-on-top "over" is its only blend, and its
     // records are the projector's 32-byte disc records
     ARG_CHECK(ctx, cfg->footprint != SPLAT_FOOTPRINT_DISC ||
-                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format != SPLAT_RECORDS_COMPACT && !lit32));
+                       (cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && cfg->record_format != SPLAT_RECORDS_COMPACT));
     ARG_CHECK(ctx, cfg->record_format != SPLAT_RECORDS_DISC48 || cfg->footprint == SPLAT_FOOTPRINT_DISC);
     const uint32_t ntx = div_up(width, CT), nty = div_up(height, CT);
     uint32_t r0 = cfg->tile_row0, r1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
@@ -1117,7 +1228,8 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     p.lit32 = cfg->record_format == SPLAT_RECORDS_LIT32;
     p.prelit = cfg->prelit != 0;
     p.disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
-    p.disc_stride = cfg->record_format == SPLAT_RECORDS_DISC48 ? 3u : 2u;
+    p.disc_stride = (cfg->record_format == SPLAT_RECORDS_DISC48 || (p.disc && lit32)) ? 3u : 2u;
+    p.disc_lit = p.disc && lit32;
     p.indices = (const uint32_t *)tile_indices;
     p.counts = (const uint32_t *)tile_counts;
     p.offsets = (const uint32_t *)tile_offsets;
@@ -1180,9 +1292,10 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     // SIMD instead of eight (three table buffers): a gain where every list is walked to its end (early-out off: C2 319 ->
     // 298 us), a loss where most tiles stop after a few chunks and a tile's life is mostly latency (50.6 -> 52.8 us):
     // profiles/r04_b_px_ab_C2.txt
-    const int opt_ahead = ctx->opt_px_ahead > 0 ? ctx->opt_px_ahead : g_px_ahead > 0 ? g_px_ahead : (cfg->early_out ? 1 : 2);
+    // (the oriented disc keeps eleven numbers per entry instead of tables: a third buffer costs it no resident workgroup)
+    const int opt_ahead = ctx->opt_px_ahead > 0 ? ctx->opt_px_ahead : g_px_ahead > 0 ? g_px_ahead : ((cfg->early_out && !p.disc) ? 1 : 2);
     const uint32_t band_tiles = ntx * (r1 - r0);
-    const bool use_px = !p.disc && cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && (opt_kernel == 1 || (opt_kernel == -1 && ntx * nty >= PX_MIN_TILES));
+    const bool use_px = cfg->mode == SPLAT_COMPOSITE_FRONT_TO_BACK && (opt_kernel == 1 || (opt_kernel == -1 && ntx * nty >= PX_MIN_TILES));
     if (use_px) {
         // (the band, the screen, and whose lists these are: two binners on one context do not share a history)
         const uint64_t key = (((uint64_t)ntx << 40) ^ ((uint64_t)r0 << 20) ^ (uint64_t)r1 ^ ((uint64_t)width << 50) ^
@@ -1192,27 +1305,30 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
         if (ctx->debug_tile_order) p.tile_order = ctx->debug_tile_order;
         // one workgroup of two waves (consumer, builder) per tile, behind workgroup 0 (report, next launch's tile order)
         const dim3 pgrid(band_tiles + 1u), pblock(128);
-#define SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, CNT, AH)                                                                             \
+#define SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, CNT, AH, DISC)                                                                       \
     do {                                                                                                                        \
-        if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, CNT, AH>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
-        else hipLaunchKernelGGL((k_composite_px<EO, LIT, CNT, AH>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                       \
+        if (timed) hipExtLaunchKernelGGL((k_composite_px<EO, LIT, CNT, AH, DISC>), pgrid, pblock, 0, ctx->stream, ev0, ev1, 0, p, band_tiles); \
+        else hipLaunchKernelGGL((k_composite_px<EO, LIT, CNT, AH, DISC>), pgrid, pblock, 0, ctx->stream, p, band_tiles);                       \
     } while (0)
-#define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT)                                       \
-    do {                                                                         \
-        if (opt_ahead == 2) {                                                    \
-            if (p.consumed) SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, true, 2);        \
-            else            SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, false, 2);       \
-        } else {                                                                 \
-            if (p.consumed) SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, true, 1);        \
-            else            SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, false, 1);       \
-        }                                                                        \
+#define SPLAT_COMPOSITE_PX_LAUNCH(EO, LIT, DISC)                                       \
+    do {                                                                               \
+        if (opt_ahead == 2) {                                                          \
+            if (p.consumed) SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, true, 2, DISC);        \
+            else            SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, false, 2, DISC);       \
+        } else {                                                                       \
+            if (p.consumed) SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, true, 1, DISC);        \
+            else            SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, false, 1, DISC);       \
+        }                                                                              \
     } while (0)
-        if (lit32) {
-            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, true);
-            else    SPLAT_COMPOSITE_PX_LAUNCH(false, true);
+        if (p.disc) { // the oriented disc: per-lane queues as well, the footprint evaluated per queued pixel
+            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, false, true);
+            else    SPLAT_COMPOSITE_PX_LAUNCH(false, false, true);
+        } else if (lit32) {
+            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, true, false);
+            else    SPLAT_COMPOSITE_PX_LAUNCH(false, true, false);
         } else {
-            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, false);
-            else    SPLAT_COMPOSITE_PX_LAUNCH(false, false);
+            if (eo) SPLAT_COMPOSITE_PX_LAUNCH(true, false, false);
+            else    SPLAT_COMPOSITE_PX_LAUNCH(false, false, false);
         }
 #undef SPLAT_COMPOSITE_PX_LAUNCH2
 #undef SPLAT_COMPOSITE_PX_LAUNCH

@@ -271,7 +271,7 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, sorter && binner && cfg && props && (normals || cfg->prelit) && (n_records == 0 || records));
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner) && width >= 1 && height >= 1);
-    ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC && cfg->record_format <= SPLAT_RECORDS_DISC48);
+    ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC && cfg->record_format <= SPLAT_RECORDS_LIT32);
     // the oriented disc travels as its own 48-byte records, and only those carry it
     ARG_CHECK(ctx, (cfg->footprint == SPLAT_FOOTPRINT_DISC) == (cfg->record_format == SPLAT_RECORDS_DISC48));
     // colours: the second vec4 of the reference's interleaved records, or (cfg->prelit) `props` IS the plane of lit colours
@@ -492,8 +492,10 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     const bool disc = cfg->footprint == SPLAT_FOOTPRINT_DISC;
     // cfg->record_format says what the frame leaves in `projected` and composites from: the reference's ProjectedSplat
     // records, or the lit composite records (shade.h) — one gathered line per staged list entry instead of three
-    ARG_CHECK(ctx, cfg->record_format == SPLAT_RECORDS_PROJECTED || (cfg->record_format == SPLAT_RECORDS_LIT32 && !disc));
-    const bool lit = cfg->record_format == SPLAT_RECORDS_LIT32;
+    // (a disc frame with SPLAT_RECORDS_LIT32: the lit colour rides behind each 32-byte disc record — 48-byte records, owned by the
+    // binner like the plain disc records — and the composite gathers that one record per staged entry)
+    ARG_CHECK(ctx, cfg->record_format == SPLAT_RECORDS_PROJECTED || cfg->record_format == SPLAT_RECORDS_LIT32);
+    const bool lit = cfg->record_format == SPLAT_RECORDS_LIT32 && !disc, disc_lit = cfg->record_format == SPLAT_RECORDS_LIT32 && disc;
     ARG_CHECK(ctx, !disc || (normals && (((uintptr_t)normals) & 15) == 0));
     if (n > splat_sort_capacity(sorter)) return ctx_fail(ctx, SPLAT_ERR_CAPACITY, "splat_render_frame: n exceeds the sorter's capacity");
     ARG_CHECK(ctx, width >= 1 && height >= 1);
@@ -505,7 +507,7 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     uint32_t row0 = cfg->tile_row0, row1 = cfg->tile_row1 > nty ? nty : cfg->tile_row1;
     if (row0 > row1) row0 = row1;
     const bool fast = ntx <= 256 && nty <= 256 && n > 0;
-    if ((!projected || lit) && n > 0 && !fast)
+    if ((!projected || lit || disc_lit) && n > 0 && !fast)
         return ctx_fail(ctx, SPLAT_ERR_INVALID, "splat_render_frame: screens beyond 256 x 256 tiles bin from ProjectedSplat records: pass a "
                                                 "buffer and cfg->record_format = SPLAT_RECORDS_PROJECTED");
     int rc = SPLAT_OK;
@@ -528,12 +530,12 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, block), block};
         binner->tf_block = block;
     }
-    if (disc && n > binner->discs_cap) {
+    if (disc && n > binner->discs_cap) { // (48 bytes per splat: room for the lit records)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (binner->discs) (void)hipFree(binner->discs);
         binner->discs = nullptr;
         binner->discs_cap = 0;
-        if (hipMalloc(&binner->discs, (size_t)n * 32 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "disc records hipMalloc");
+        if (hipMalloc(&binner->discs, (size_t)n * 48 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "disc records hipMalloc");
         binner->discs_cap = n;
     }
     if (ctx->timing) { // (before binner_run promises a report: nothing that can fail may stand between that promise and the composite_launch that keeps it)
@@ -541,7 +543,8 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
         if (rc != SPLAT_OK) return rc;
     }
     // (the payload array is not written: payload = splat index)
-    const LitIO lio = {(const float4 *)color, (const float4 *)normals, color_stride, 1u, cfg->prelit, lit ? (float4 *)projected : nullptr};
+    const LitIO lio = {(const float4 *)color, (const float4 *)normals, color_stride, 1u, cfg->prelit,
+                       lit ? (float4 *)projected : disc_lit ? (float4 *)binner->discs : nullptr};
     rc = project_launch(ctx, uniforms, props, pos_stride, n, 0, lit ? nullptr : projected, splat_sort_keys(sorter), nullptr, n, range32, &bp,
                         tile_first ? &ho : nullptr, normals, 1, disc ? binner->discs : nullptr, &lio);
     if (rc != SPLAT_OK) return rc;

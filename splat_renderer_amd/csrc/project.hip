@@ -66,6 +66,7 @@ struct DiscIO {
     const float4 *normals;
     uint32_t normal_stride;
     float4 *discs;
+    uint32_t disc_stride; // float4s per record: 2, or 3 when the frame asks for LIT disc records (the splat's lit colour behind the record)
 };
 
 // Band frames without an exchange (every rank projects all splats): most splats cannot reach the rank's
@@ -141,8 +142,12 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const Sp
     if (DISC) {
         const float4 pr = in.pr;
         const DiscRecord d = disc_record(u.m, u.w, u.h, pr, in.nrm);
-        dio.discs[(size_t)i * 2] = d.a;
-        dio.discs[(size_t)i * 2 + 1] = d.b;
+        dio.discs[(size_t)i * dio.disc_stride] = d.a;
+        dio.discs[(size_t)i * dio.disc_stride + 1] = d.b;
+        // LIT: the lit colour rides behind the record (48 bytes per splat): the disc frame's composite then gathers this one
+        // record per staged list entry instead of record + colour + normal — the gathers are what a staged entry costs
+        // (C2: 168 -> 124 us for one line less, profiles/r04_d_disc_composite_C2.txt)
+        if (LIT) dio.discs[(size_t)i * dio.disc_stride + 2] = lio.prelit ? in.col : lit_color(in.col, in.nrm);
         disc_bounds(d, a);
         const float dx = pr.x - u.eye[0], dy = pr.y - u.eye[1], dz = pr.z - u.eye[2];
         depth = sqrtf((dx * dx + dy * dy) + dz * dz); // SplatProjector.ts:77: the sort key does not depend on the footprint
@@ -402,13 +407,14 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
     BinParams none = {0, 0, 1, 0, 0, 0, 0};
     const float4 *src = (const float4 *)pos_radius + (size_t)index_base * pr_stride_vec4;
     const bool disc = discs != nullptr; // the oriented-disc footprint (disc.h): normals in, disc records out
-    const DiscIO dio = {disc ? (const float4 *)normals + (size_t)index_base * normal_stride_vec4 : nullptr, normal_stride_vec4,
-                        (float4 *)discs};
-    // lit composite records (shade.h): isotropic frames only, written next to the keys and tile ranges
-    const bool with_lit = lit && lit->records && !disc;
-    if (with_lit && !(keys && range32 && !payload && index_base == 0))
+    // lit composite records (shade.h) of an isotropic frame, written next to the keys and tile ranges; a disc frame's lit
+    // colours go behind its disc records (lit->records = discs there: 48-byte records)
+    const bool with_lit = lit && lit->records && !disc, disc_lit = lit && lit->records && disc;
+    if ((with_lit || disc_lit) && !(keys && range32 && !payload && index_base == 0))
         return ctx_fail(ctx, SPLAT_ERR_INVALID, "project_launch: lit records are written by the frame's projector only");
-    const LitIO lio = with_lit ? *lit : LitIO{};
+    const DiscIO dio = {disc ? (const float4 *)normals + (size_t)index_base * normal_stride_vec4 : nullptr, normal_stride_vec4,
+                        (float4 *)discs, disc_lit ? 3u : 2u};
+    const LitIO lio = (with_lit || disc_lit) ? *lit : LitIO{};
     stage_begin(ctx, SPLAT_STAGE_PROJECT);
     dim3 grid(div_up(work, 256)), block(256);
 #define SPLAT_PROJECT_LAUNCH(K, R, D, L, RANGE, BP)                                                                                \
@@ -428,14 +434,17 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
     } while (0)
     if (hist_out && keys && range32 && !payload && index_base == 0) {
         // (a strict band's kernel works in 1024-splat blocks only: the caller keeps hist_out->block at TF_BLOCK_LARGE for it)
-        if (disc && bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, true, false);
+        if (disc_lit && bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, true, true);
+        else if (disc_lit) SPLAT_PROJECT_HIST_LAUNCH_PER(true, true);
+        else if (disc && bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, true, false);
         else if (disc) SPLAT_PROJECT_HIST_LAUNCH_PER(true, false);
         else if (bp->skip_outside && with_lit) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, false, true);
         else if (bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, false, false);
         else if (with_lit) SPLAT_PROJECT_HIST_LAUNCH_PER(false, true);
         else SPLAT_PROJECT_HIST_LAUNCH_PER(false, false);
     } else if (keys && range32) {
-        if (disc) SPLAT_PROJECT_LAUNCH(true, true, true, false, range32, *bp);
+        if (disc_lit) SPLAT_PROJECT_LAUNCH(true, true, true, true, range32, *bp);
+        else if (disc) SPLAT_PROJECT_LAUNCH(true, true, true, false, range32, *bp);
         else if (with_lit) SPLAT_PROJECT_LAUNCH(true, true, false, true, range32, *bp);
         else SPLAT_PROJECT_LAUNCH(true, true, false, false, range32, *bp);
     } else if (keys) {

@@ -734,7 +734,9 @@ class Renderer:
             raise SplatError(-1, "writeProjected=False: the isotropic composite reads the records the projector writes")
         if records not in ("lit", "projected"):
             raise SplatError(-1, f"records must be 'lit' or 'projected', not {records!r}")
-        self.records = records if self.footprint == _lib.FOOTPRINT_ISOTROPIC else "projected"
+        # (disc frames, "lit": the lit colour rides behind each disc record — 48-byte records inside the binner, one gathered
+        # record per staged entry instead of disc record + colour + normal; the ProjectedSplat buffer is what it always was)
+        self.records = records
         self.writeProjected = writeProjected
         self.device, self.numPoints, self.tileSize = device, numPoints, tileSize
         self.projector = SplatProjector(device, numPoints)
@@ -779,7 +781,7 @@ class Renderer:
         ts = self.tileSize
         lit = self.records == "lit" and -(-width // ts) <= 256 and -(-height // ts) <= 256
         self.recordFormat = _lib.RECORDS_LIT32 if lit else _lib.RECORDS_PROJECTED  # of projector.getRecordsBuffer() after this frame
-        self.projector.contents = "lit" if lit else "projected"
+        self.projector.contents = "lit" if (lit and self.footprint == _lib.FOOTPRINT_ISOTROPIC) else "projected"
         cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], self.recordFormat, int(prelit),
                            self.footprint)
         tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height,

@@ -394,7 +394,8 @@ class Renderer {
     // records 'lit' (default, isotropic frames): the projector leaves 32-byte lit composite records (centre, radius, depth |
     // lit colour) in projector.getProjectedBuffer() and the composite gathers ONE line per staged list entry;
     // 'projected': the reference's ProjectedSplat records, colour and normal gathered per entry.  Same image.
-    this.records = options.records === 'projected' || this.footprint === FOOTPRINT_DISC ? 'projected' : 'lit';
+    // (disc frames, 'lit': the lit colour rides behind each disc record inside the binner — one gathered record per staged entry)
+    this.records = options.records === 'projected' ? 'projected' : 'lit';
     this.projector = new SplatProjector(device, numPoints);
     this.sorter = new RadixSorter(device, numPoints);
     this.binner = new GPUTileBinner(device, tileSize);
@@ -420,7 +421,7 @@ class Renderer {
     }
     const small = Math.ceil(width / this.tileSize) <= 256 && Math.ceil(height / this.tileSize) <= 256;
     this.recordFormat = this.records === 'lit' && small ? RECORDS_LIT32 : RECORDS_PROJECTED; // of projector.getRecordsBuffer() after this frame
-    this.projector.contents = this.recordFormat === RECORDS_LIT32 ? 'lit' : 'projected';
+    this.projector.contents = this.recordFormat === RECORDS_LIT32 && this.footprint !== FOOTPRINT_DISC ? 'lit' : 'projected';
     const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, this.recordFormat, propertyBuffer.prelit ? 1 : 0, this.footprint];
     if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
       native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,

@@ -98,9 +98,29 @@ def test_disc_projector_bit_exact(device, n, w, h, seed, rs):
         o.destroy()
 
 
+# Which kernel composites the disc frames (Device.compositeOptions): the library's choice on these screens of fewer than 2048
+# tiles — k_composite, a wave per 8x8 quadrant evaluating every entry that touches it — or k_composite_px (per-lane entry
+# queues, the footprint evaluated for the four pixels of every lane an entry's box touches) on its two schedules.
+DISC_KERNELS = ["default", "px1", "px2"]
+
+
+def force_kernel(device, kernel):
+    if kernel != "default":
+        device.compositeOptions("pixel", ahead=1 if kernel == "px1" else 2)
+
+
 @pytest.mark.parametrize("n,w,h,seed,rs", CASES)
 @pytest.mark.parametrize("early_out", [False, True])
-def test_disc_staged_pipeline_vs_oracle(device, n, w, h, seed, rs, early_out):
+@pytest.mark.parametrize("kernel", DISC_KERNELS)
+def test_disc_staged_pipeline_vs_oracle(device, n, w, h, seed, rs, early_out, kernel):
+    try:
+        force_kernel(device, kernel)
+        disc_staged_pipeline_vs_oracle(device, n, w, h, seed, rs, early_out)
+    finally:
+        device.compositeOptions()
+
+
+def disc_staged_pipeline_vs_oracle(device, n, w, h, seed, rs, early_out):
     props, normals, u = disc_case(n, w, h, seed, rs)
     ref = oracle_disc(props, normals, u, w, h, early_out)
     pm = sr.SplatPropertyManager(device, n)
@@ -182,10 +202,14 @@ def test_disc_whole_frame(device, order, layout):
         with pytest.raises(sr.SplatError):  # the disc projector needs the normals even when the colours are pre-lit
             r.render(u, src, None, None, w, h)
     # without the ProjectedSplat by-product (nothing in a disc frame reads it): same lists, same image bits
-    r2 = sr.Renderer(device, None, "rgba8unorm", n, earlyOut=False, frameOrder=order, footprint="disc", writeProjected=False)
+    # (and with plain 32-byte disc records — colour and normal gathered per staged entry, as the staged API does — instead of
+    # the frame's default, the lit colour behind each disc record: the same arithmetic on the same numbers)
+    assert r.recordFormat == _lib.RECORDS_LIT32
+    r2 = sr.Renderer(device, None, "rgba8unorm", n, earlyOut=False, frameOrder=order, footprint="disc", writeProjected=False,
+                     records="projected")
     r2.projector.getProjectedBuffer().zero()
     r2.render(u, src, nbuf, None, w, h, wantFloat=True)
-    assert r2.finish() == total
+    assert r2.finish() == total and r2.recordFormat == _lib.RECORDS_PROJECTED
     assert_same(r2.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "disc L189")
     assert_same(r2.readPixelsFloat().view(np.uint32), r.readPixelsFloat().view(np.uint32), "disc L190")
     assert not r2.projector.getProjectedBuffer().read(np.uint32).any()
@@ -480,7 +504,16 @@ def test_frame_of_no_splats_is_the_background(device, footprint):
         o.destroy()
 
 
-def test_disc_random_scenes(device):
+@pytest.mark.parametrize("kernel", DISC_KERNELS)
+def test_disc_random_scenes(device, kernel):
+    try:
+        force_kernel(device, kernel)
+        disc_random_scenes(device)
+    finally:
+        device.compositeOptions()
+
+
+def disc_random_scenes(device):
     """Seeded sweep over sizes, aspect ratios, splat scales, camera distances (inside the cube too: splats behind the
     eye and discs crossing w = 0 are culled) and normal distributions (unit, scaled, near the |n.y| = 0.9 switch, zero):
     records and lists against the oracle bit for bit, the image within the stated tolerance."""

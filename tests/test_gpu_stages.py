@@ -352,8 +352,8 @@ def composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel):
             assert np.all(cons[:, 0] >= np.minimum(counts64, cons[:, 1])), "entries staged per tile (k_composite_px): fewer than consumed"
             slack = np.uint64(64 if kernel == "px2_slack" else 0)
             assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(128) + slack)), "entries staged per tile (k_composite_px): beyond the look-ahead"
-            if kernel == "px2_warm":  # nothing gathered beyond the chunks the tile touches (the last walked, or the one after it)
-                assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(32))), "a warm launch gathers only what the one before needed"
+            if kernel == "px2_warm":  # gathered: the chunks the tile touched in the launch before (the last walked, or the one after it) + one
+                assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(64))), "a warm launch gathers what the one before needed and one chunk more"
             staged_want = cons[:, 0]
         elif px:
             staged_want = counts64
