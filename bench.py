@@ -42,7 +42,7 @@ def composite_traffic_model(p_staged, width, height, records, prelit, disc=False
     return per * p_staged + 4 * width * height
 
 
-def per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, lit, disc):
+def per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, lit, disc, pmc=None):
     """every kernel group of the tile-first frame against the 8 TB/s HBM roof, from the bytes each is
     built to move (the tile-first frame's own byte table, which replaces SURVEY §8d's sort / count / fill
     rows — the composite row IS SURVEY §8d's) and its HIP-event interval in the all-stages loop (each interval carries
@@ -64,6 +64,16 @@ def per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, lit, disc):
         gbs = nbytes / (ms / 1e3) / 1e9
         out[key] = {"kernels": kernels, "bytes_per_frame": int(nbytes), "bytes_model": what, "ms": round(ms, 4), "achieved_GBps": round(gbs, 1),
                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    # The per-tile sort moves its bytes once and spends its time in LDS: its own roof is the LDS pipe.  From
+    # committed rocprofv3 counters (profiles/traffic.json names the csv), not measured in this run: the fraction of the kernel's
+    # duration during which the CUs' LDS arrays were busy, and how much of that was bank conflicts.
+    if pmc and pmc.get("k_tile_sort_lds") and "bin_tile_sort" in out:
+        t = pmc["k_tile_sort_lds"]
+        out["bin_tile_sort"]["lds"] = {"bound": "lds", "frac": t["lds_pipe_frac"], "conflict_share_of_array_cycles": t["conflict_share_of_array_cycles"],
+                                       "lds_array_cycles_per_frame": t["lds_array_cycles_per_frame"],
+                                       "lds_instructions_per_frame": t["lds_instructions_per_frame"], "source": t["source"],
+                                       "reading": "well below the pipe's capacity with half of the busy cycles lost to conflicts: the kernel waits on its "
+                                                  "chain of barriers and LDS round trips (SQ_WAIT_ANY 0.53 of its wave cycles), not on LDS bandwidth"}
     return out
 
 
@@ -388,7 +398,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    "ranking": ranking},
         "roofline": roofline,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-        "roofline_per_kernel": per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, args.records == "lit" and not disc, disc),
+        "roofline_per_kernel": per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, args.records == "lit" and not disc, disc, pmc),
         "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                            "achieved_GBps": frame_bytes / (dt / args.steps) / 1e9,
                            "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -188,6 +188,8 @@ int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t posit
 /* EXPERIMENT HOOK: the order in which the lane-efficient composite's workgroups take the tiles of the rendered band
  * (a permutation of 0 .. tiles - 1 as u32 on the device; NULL = row-major).  Any order gives the same image. */
 int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
+/* EXPERIMENT HOOK: the same for the per-tile sort's workgroups (a permutation of ALL the screen's tiles; NULL = row-major). */
+int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr);
 /* The lane-efficient composite keeps, per context and band of tile rows, what its previous launch cost per tile (chunks of
  * 32 list entries walked): the next launch over the same band takes its tiles longest-first and builds / gathers for each
  * tile only what that launch needed ahead of need (a tile that needs more pays one exposed gather).  Both are hints — any

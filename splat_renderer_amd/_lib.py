@@ -86,6 +86,7 @@ SIGNATURES = {
     "splat_rank_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32)]),
     "splat_debug_inject_order_fault": (_i, [_vp, _u32, _u32]),
     "splat_debug_set_tile_order": (_i, [_vp, _vp]),
+    "splat_debug_set_tile_sort_order": (_i, [_vp, _vp]),
     "splat_composite_forget_history": (_i, [_vp]),
     "splat_composite_options": (_i, [_vp, _i, _i, _i, _i]),
     "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),

@@ -33,6 +33,7 @@ struct splat_ctx {
     int rank_policy = 0;
     uint32_t order_faults = 0;      // frames whose lists failed the order check (each was reported and rendered again)
     const uint32_t *debug_tile_order = nullptr; // experiment hook (splat_debug_set_tile_order)
+    const uint32_t *debug_sort_order = nullptr; // experiment hook (splat_debug_set_tile_sort_order)
     // splat_composite_options (-1 / 0 = the process default, i.e. the environment's): which kernel composites nearest-on-top
     // isotropic frames (0 quadrant, 1 pixel), and k_composite_px's schedule
     int opt_composite_kernel = -1, opt_px_ahead = 0, opt_px_predict = -1, opt_px_slack = -1;

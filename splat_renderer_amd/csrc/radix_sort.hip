@@ -818,6 +818,12 @@ int splat_composite_forget_history(splat_ctx *ctx) {
     return SPLAT_OK;
 }
 
+int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ctx->debug_sort_order = (const uint32_t *)order_dptr;
+    return SPLAT_OK;
+}
+
 int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ctx->debug_tile_order = (const uint32_t *)order_dptr;

@@ -420,7 +420,8 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : (W
                                                                                     uint32_t *__restrict__ out_idx,
                                                                                     uint32_t *__restrict__ counts,
                                                                                     uint32_t *__restrict__ frame_flags,
-                                                                                    uint32_t inject_tile, uint32_t inject_pos) {
+                                                                                    uint32_t inject_tile, uint32_t inject_pos,
+                                                                                    const uint32_t *__restrict__ order) {
     static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
     constexpr uint32_t TS_FIT = WIDE ? TSW_LDS_ELEMS : TS_LDS_ELEMS;
     constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_FIT ? TS_MAX_ITEMS * TS_THREADS : TS_FIT;
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : (W
     __shared__ uint2 s_el[TS_CAP];
     uint32_t *run_base = reinterpret_cast<uint32_t *>(s_el); // long-list path (s_el unused there): start of each digit's run
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = order ? order[blockIdx.x] : blockIdx.x; // (experiment hook splat_debug_set_tile_sort_order: any permutation gives the same lists)
     const uint32_t base = offsets[t], n = offsets[t + 1] - base;
     if (counts && tid == 0) counts[t] = n; // (first launch: the tile counts the composite reads)
     if (n <= n_above || (!LAST_CLASS && n > TS_CAP)) return; // empty, or another class's tile
@@ -819,7 +820,7 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     const bool wide = ctx->tile_sort_digits == 12;
 #define SPLAT_TILE_SORT_(RA, ITEMS, LAST, WIDE, ABOVE, COUNTS)                                                                       \
     hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST, WIDE>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, \
-                       scratch, out_idx, COUNTS, frame_flags, inject, inject_pos)
+                       scratch, out_idx, COUNTS, frame_flags, inject, inject_pos, ctx->debug_sort_order)
 #define SPLAT_TILE_SORT(ITEMS, LAST, ABOVE, COUNTS)                          \
     do {                                                                     \
         if (ra && wide) SPLAT_TILE_SORT_(true, ITEMS, LAST, true, ABOVE, COUNTS);   \
