@@ -319,20 +319,40 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     # and the timed region run at the clocks the device sustains (after idle the first ~50 frames of C2 take 0.345 ms, every
     # later one 0.3335: tools/warm_probe.py, profiles/r03_l_clock_ramp.txt; host-side scene generation leaves the device idle for seconds)
     copy_gbs = measured_copy_ceiling(dev)
+    # ... and ~40 ms more of the frame itself, untimed and before the W warm-up frames the contract asks for: the ramp is ~50
+    # frames long, the driver's W is a handful, and its K is twenty — a timed region of 7 ms would otherwise sit on it
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.04:
+        for _ in range(10):
+            frame()
+        dev.sync()
     for _ in range(args.warmup):
         frame()
     dev.sync()
     # timed region: exactly K frames; HIP events bracket ONLY the roofline kernel (k_composite) on
     # the ctx stream, because every recorded stage costs ~10 us of stream idle per frame
+    # ... on every TIMED_EVERY-th frame of the timed region: a timed launch costs the stream ~5 us even with the event pair on the
+    # launch itself (0.326 against 0.321 ms per frame at C2 with a pair on every frame, profiles/r04_f_event_cost_C2.txt)
+    TIMED_EVERY = int(os.environ.get("SPLAT_BENCH_EVENT_STRIDE", "4"))
     _lib.check(lib.splat_set_timing_stages(ctx, 1 << _lib.STAGE_COMPOSITE), ctx)
-    dev.setTiming(True)
+    _lib.check(lib.splat_set_timing_sampling(ctx, max(TIMED_EVERY, 1)), ctx)
+    dev.setTiming(os.environ.get("SPLAT_BENCH_EVENTS", "1") != "0")  # (=0: what the event pairs cost the frame — a measuring knob)
     dev.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
     dev.sync()
     dt = time.perf_counter() - t0
+    if os.environ.get("SPLAT_BENCH_EVENTS", "1") == "0":  # (the kernel's duration then comes from a few launches after the timed region)
+        dev.setTiming(True)
+        for _ in range(5):
+            frame()
+        dev.sync()
     composite_ms = stage_avg(_lib.STAGE_COMPOSITE)
+    cnt_, tot_ = C.c_uint32(), C.c_double()
+    _lib.check(lib.splat_stage_time_stats(ctx, _lib.STAGE_COMPOSITE, C.byref(cnt_), C.byref(tot_)), ctx)
+    launches_timed = int(cnt_.value)
+    _lib.check(lib.splat_set_timing_sampling(ctx, 1), ctx)
     r.finish()  # settles the last timed frame's report: a failed order check in ANY timed frame has been counted by now
     ranking = dict(dev.rankStatus(), framesMisranked=r.framesMisranked, framesOverflowed=int(r.previousFrameOverflowed))
     # per-stage breakdown from a separate short loop with every stage's events on (not part of `value`), and the entries
@@ -366,6 +386,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": comp_bytes, "avg_launch_ms": stage_ms["composite"],
                 "formula": "SURVEY 8d: 68 B x pairs_consumed + 4 B x W x H, / avg launch (HIP events on the ctx stream inside the timed region)",
+                "launches_timed": launches_timed, "launches_in_timed_region": args.steps,
                 "pairs_consumed": round(p_used), "pairs_staged": round(p_staged),
                 "traffic_model": composite_traffic_model(p_staged, width, height, args.records, prelit, disc),
                 "traffic_model_note": "bytes the kernel as built is expected to move: per STAGED entry (k_composite_px: chunks of 32, fetched ahead; "

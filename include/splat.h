@@ -89,6 +89,10 @@ int splat_set_timing(splat_ctx *ctx, int enabled);
  * counts from a frame outside its timed region (they are a property of the input). */
 #define SPLAT_TIMING_COUNT_ENTRIES 0x80000000u
 int splat_set_timing_stages(splat_ctx *ctx, uint32_t stage_mask);
+/* A stage that is ONE kernel (the composite) carries its event pair on the launch itself; even so a timed launch costs the
+ * stream ~5 us (C2: 0.326 ms per frame with a pair on every composite, 0.321 with none).  every = n: only every n-th such
+ * launch while timing is on is timed (the first one is); splat_stage_time_stats then averages over those.  Default 1. */
+int splat_set_timing_sampling(splat_ctx *ctx, uint32_t every);
 /* Duration of the most recent run of `stage`; synchronises on that stage's end event. */
 int splat_stage_time_ms(splat_ctx *ctx, int stage, float *ms);
 /* Every timed run of `stage` since timing was last enabled: number of samples and their summed

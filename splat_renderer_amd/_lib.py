@@ -58,6 +58,7 @@ SIGNATURES = {
     "splat_sync": (_i, [_vp]),
     "splat_set_timing": (_i, [_vp, _i]),
     "splat_set_timing_stages": (_i, [_vp, _u32]),
+    "splat_set_timing_sampling": (_i, [_vp, _u32]),
     "splat_stage_time_ms": (_i, [_vp, _i, C.POINTER(C.c_float)]),
     "splat_stage_time_stats": (_i, [_vp, _i, C.POINTER(_u32), C.POINTER(C.c_double)]),
     "splat_timing_consumed": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -46,6 +46,7 @@ struct splat_ctx {
     uint32_t inject_order_position = 0; // ... at entries position, position + 1
     int tile_sort_digits = 0; // k_tile_sort's in-LDS passes: 0 = not resolved yet, 8 = byte passes (default), 12 = wide passes (SPLAT_TILE_SORT_DIGITS=12)
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
+    uint32_t timing_every = 1, timing_tick = 0; // one-kernel stages (the composite): an event pair on every timing_every-th launch
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars
     void *scan_ws = nullptr;

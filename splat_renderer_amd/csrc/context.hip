@@ -65,6 +65,7 @@ void stage_begin(splat_ctx *ctx, int stage) {
 // hipEventRecord pair costs ~6 us of idle GPU per launch).  False when the stage is not being timed.
 bool stage_event_pair(splat_ctx *ctx, int stage, hipEvent_t *start, hipEvent_t *stop) {
     if (!ctx->timing || !((ctx->timing_mask >> stage) & 1u)) return false;
+    if (ctx->timing_every > 1 && (ctx->timing_tick++ % ctx->timing_every) != 0) return false; // (splat_set_timing_sampling)
     StageTimer &t = ctx->timers[stage];
     if (t.used == t.beg.size()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -162,6 +163,14 @@ int splat_set_timing(splat_ctx *ctx, int enabled) {
         for (auto &t : ctx->timers) t.used = 0; // start a new sample set
         if (ctx->d_consumed) HIP_TRY(ctx, hipMemsetAsync(ctx->d_consumed, 0, (size_t)ctx->consumed_tiles * 16, ctx->stream));
     }
+    return SPLAT_OK;
+}
+
+int splat_set_timing_sampling(splat_ctx *ctx, uint32_t every) {
+    if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
+    ARG_CHECK(ctx, every >= 1);
+    ctx->timing_every = every;
+    ctx->timing_tick = 0;
     return SPLAT_OK;
 }
 
