@@ -182,53 +182,70 @@ def time_composite_alone(dev, r, u, pbuf, nbuf, width, height, tile, early_out, 
 def orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, static_ms, static_composite_ms, frames=60, degrees=0.5):
     """K frames of an orbit, the camera turned by `degrees` of azimuth between frames by OrbitCameraController (a drag of
     degrees / 0.005 rad-per-pixel pixels: OrbitCameraController.ts:12,47-49), through FrameLoop; ms/frame, the composite's own
-    duration, frames that had to be rendered again.  Then the same orbit with the composite's two history-fed mechanisms
-    switched, to say which one a slowdown comes from."""
+    duration (events on every fourth frame, as in the timed region), frames that had to be rendered again.  Then the SAME camera
+    path with the composite's look-ahead bound switched off, and with a chunk of slack on it — to say which mechanism a slowdown
+    comes from — and the default once more (the legs run one after the other: the second default says how much they drift)."""
     lib, ctx = dev.lib, dev.ctx
     loop = sr.FrameLoop(dev, n, width, height, tile, records=args.records)
     ctrl = sr.OrbitCameraController(loop.camera)
     dx = np.radians(degrees) / ctrl.rotationSpeed
+    az0, el0 = loop.camera.azimuth, loop.camera.elevation
+    warm = 12
+    # the camera path once: the host's matrix arithmetic is not what is measured, and every leg renders the same frames
     ctrl.onMouseDown(sr.MouseEvent(0.0, 0.0, 0))
+    uniforms = []
+    for k in range(warm + frames):
+        ctrl.onMouseMove(sr.MouseEvent((k + 1) * dx, 0.0, 0))
+        uniforms.append(loop.camera.uniforms(width, height, time=k / 60.0).copy())
+    ctrl.onMouseUp()
+    turned = float(np.degrees(loop.camera.azimuth - az0))
+    loop.camera.azimuth, loop.camera.elevation = az0, el0
 
-    def run(k_frames, x0):
-        uniforms = []
-        for k in range(k_frames):  # the camera path first: the host's matrix arithmetic is not what is measured
-            ctrl.onMouseMove(sr.MouseEvent(x0 + (k + 1) * dx, 0.0, 0))
-            uniforms.append(loop.camera.uniforms(width, height, time=k / 60.0).copy())
+    def run(us):
         again = 0
         dev.sync()
         t0 = time.perf_counter()
-        for uk in uniforms:
+        for uk in us:
             loop.renderer.previousFrameOverflowed = False
             loop.renderer.render(uk, pbuf, nbuf, None, width, height)
             again += int(loop.renderer.previousFrameOverflowed)
         dev.sync()
-        return (time.perf_counter() - t0) / k_frames * 1e3, again, x0 + k_frames * dx
+        return (time.perf_counter() - t0) / len(us) * 1e3, again
 
-    def leg(label, **opts):
-        dev.compositeOptions(**opts)
-        _, _, x = run(12, leg.x)  # the history re-learns under the moving camera
+    def leg(**opts):
+        dev.compositeOptions(**opts)  # (also forgets the composite's history: the warm frames re-learn it under the moving camera)
+        run(uniforms[:warm])
         _lib.check(lib.splat_set_timing_stages(ctx, 1 << _lib.STAGE_COMPOSITE), ctx)
+        _lib.check(lib.splat_set_timing_sampling(ctx, 4), ctx)
         dev.setTiming(True)
-        ms, again, leg.x = run(frames, x)
+        ms, again = run(uniforms[warm:])
         cnt, tot = C.c_uint32(), C.c_double()
         _lib.check(lib.splat_stage_time_stats(ctx, _lib.STAGE_COMPOSITE, C.byref(cnt), C.byref(tot)), ctx)
         dev.setTiming(False)
+        _lib.check(lib.splat_set_timing_sampling(ctx, 1), ctx)
         loop.renderer.finish()
         return {"ms_per_step": round(ms, 4), "composite_ms": round(tot.value / max(cnt.value, 1), 4), "frames_rendered_again": again}
-    leg.x = 0.0
-    out = leg("default")
-    out.update({"frames": frames, "degrees_per_frame": degrees, "value": n / out["ms_per_step"] / 1e3, "unit": "Msplats/s",
+    run(uniforms)  # (the whole path once, untimed: a new renderer's first frames size its buffers)
+    out = leg()
+    out["pairs_P_of_the_last_view"] = loop.renderer.finish()
+    out.update({"frames": frames, "degrees_per_frame": degrees, "degrees_turned_incl_warmup": round(turned, 2),
+                "value": n / out["ms_per_step"] / 1e3, "unit": "Msplats/s",
                 "static_ms_per_step": round(static_ms, 4), "static_composite_ms": round(static_composite_ms, 4),
                 "over_static": round(out["ms_per_step"] / static_ms, 4),
-                "frames_misranked": loop.renderer.framesMisranked,
                 "note": "FrameLoop + OrbitCameraController, frames enqueued back to back (no host sync between frames); the static figures are "
-                        "the timed region's"})
-    # which mechanism: the same orbit without the look-ahead bound, and with one chunk of slack on it
-    out["without_lookahead_bound"] = leg("nopredict", predict=False)
-    out["with_one_chunk_of_slack"] = leg("slack1", slack=1)
+                        "the timed region's; the views of an orbit differ from the static view in their pair totals too"})
+    # the same renderer standing still at the orbit's last view: what of the difference to the timed region is the VIEW (the pair
+    # total and its distribution over the tiles change with the camera), what the motion
     dev.compositeOptions()
-    ctrl.onMouseUp()
+    run([uniforms[-1]] * 20)
+    still_ms, _ = run([uniforms[-1]] * 40)
+    out["standing_still_at_the_last_view_ms_per_step"] = round(still_ms, 4)
+    out["over_standing_still_at_the_last_view"] = round(out["ms_per_step"] / still_ms, 4)
+    out["without_lookahead_bound"] = leg(predict=False)
+    out["with_one_chunk_of_slack"] = leg(slack=1)
+    out["default_again"] = leg()
+    out["frames_misranked"] = loop.renderer.framesMisranked
+    dev.compositeOptions()
     loop.destroy()
     return out
 
