@@ -45,9 +45,18 @@ for case in range(cases):
     pbuf = {"interleaved": pm.getPropertyBuffer, "planes": pm.getPropertyPlanes, "prelit": lambda: pm.getLitPlanes(nbuf)}[layout]()
     r = sr.Renderer(dev, None, "rgba8unorm", n, mode=sr.MODE_FRONT_TO_BACK if mode == 0 else sr.MODE_REFERENCE_LITERAL, earlyOut=eo,
                     records=records)
+    # which kernel composites (these screens are below the 2048 tiles from which k_composite_px is the library's choice): a third
+    # of the cases each with the default, with k_composite_px one chunk ahead, and two chunks ahead with lanes running ahead —
+    # and half of the forced ones as the THIRD launch over the same lists (its look-ahead bounded by the second's costs, its
+    # tiles in the order the first's costs gave)
+    kernel = str(rng.choice(["default", "px1", "px2"]))
+    warm = bool(rng.integers(0, 2))
+    dev.compositeOptions(None if kernel == "default" else "pixel", ahead={"default": 0, "px1": 1, "px2": 2}[kernel])
+    for _ in range(2 if (warm and kernel != "default") else 0):
+        r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
     r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
     got, got8 = r.readPixelsFloat(), r.readPixels()
-    tag = (case, n, w, h, rs, mode, eo, records, layout)
+    tag = (case, n, w, h, rs, mode, eo, records, layout, kernel, warm)
     err = np.abs(got - want).max(axis=2)
     err8 = np.abs(got8.astype(int) - want8.astype(int)).max(axis=2)
     strict = (near == 0) if eo else np.ones_like(err, bool)
@@ -64,6 +73,7 @@ for case in range(cases):
         o.destroy()
     if case % 25 == 24:
         print(f"{case + 1} cases, {pixels} pixels, worst off-threshold error {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+dev.compositeOptions()
 status = dev.rankStatus()
 assert status["orderFaults"] == 0, f"a frame of this sweep was re-rendered after a failed order check: {status}"
 print(f"ok: {cases} random frames, {pixels} pixels: largest error off the threshold {worst:.2e} (tolerance {TOL}), "
