@@ -348,6 +348,9 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     const uint32_t tf_bits = tile_id_bits(tiles), tf_lo_bits = tile_id_low_bits(tiles);
     const bool hist_ready = b->tf_hist_ready;
     b->tf_hist_ready = false;
+    const uint32_t *tf_cidx = b->tf_cidx, *tf_kept = b->tf_kept; // (this run's only)
+    b->tf_cidx = nullptr;
+    b->tf_kept = nullptr;
     ARG_CHECK(ctx, !tile_first || hist_ready); // the caller's projector / band prepare has counted the first pass's histogram
 
     stage_begin(ctx, SPLAT_STAGE_BIN);
@@ -409,7 +412,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         stage_begin(ctx, SPLAT_STAGE_BIN_SCATTER); // (the row scan in front of it ran above: a few us not in this interval)
         rc = tf_scatter_launch(ctx, range32, depth_keys, n_splats, ntx, (1u << tf_lo_bits) - 1u, b->tf_hist, b->d_total, b->pair_limit,
                                b->d_total + 1, b->tf_hi, b->wide_a, b->tf_block, tf_lo_bits, tf_hi_bits > 0, &b->tf_runs, b->offsets, tiles,
-                               nullptr, 0u);
+                               nullptr, 0u, tf_cidx, tf_kept);
         stage_end(ctx, SPLAT_STAGE_BIN_SCATTER);
         if (rc != SPLAT_OK) return rc;
         // second pass (high digit) into wide_b, and the tile offsets out of its histogram; a screen of at most 256
@@ -559,6 +562,7 @@ void splat_bin_destroy(splat_binner *b) {
     if (b->expanded) (void)hipFree(b->expanded);
     if (b->discs) (void)hipFree(b->discs);
     if (b->band_lit) (void)hipFree(b->band_lit);
+    if (b->band_idx) (void)hipFree(b->band_idx);
     if (b->pinned) (void)hipHostFree(b->pinned);
     if (b->readback_done) (void)hipEventDestroy(b->readback_done);
     delete b;

@@ -171,6 +171,11 @@ struct splat_binner {
     uint32_t band_lit_cap = 0;
     bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
     uint32_t tf_block = 1024;                       // splats per block of that histogram (TF_BLOCK_SMALL for small frames)
+    // a multi-GPU band frame whose prepare pass compacted the kept splats per group of 4096 records (k_band_prepare_tfc): their
+    // indices and the groups' kept counts, for the next tile-first run only (binner_run clears them)
+    const uint32_t *tf_cidx = nullptr, *tf_kept = nullptr;
+    uint32_t *band_idx = nullptr;                   // storage of tf_cidx (one index per gathered record)
+    uint32_t band_idx_cap = 0;
     uint64_t total = 0;
     bool ran = false;
     // sync-free operation: when the previous frame's pair total is known and 1.125x of it fits the
@@ -241,7 +246,8 @@ int binner_reserve(splat_binner *b, uint32_t tiles, uint32_t n_sorted); // per-t
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint8_t *out_hi,
                       uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs,
-                      uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq);
+                      uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq, const uint32_t *cidx = nullptr,
+                      const uint32_t *kept = nullptr); // cidx / kept: a band's kept splats compacted per group of 4096 records (frame.hip)
 int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in, uint2 *val_out, const TfRuns *runs, uint32_t pairs_bound,
                           uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts

@@ -166,6 +166,125 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
     }
 }
 
+// The same pass for bands that keep a FRACTION of the records (every band of a multi-GPU frame): a workgroup takes a group of
+// BTC_GROUP = 4096 consecutive records and leaves the splats the band keeps COMPACTED, in index order, at the start of the
+// group's segment of the range / key arrays, their indices beside them, their number in kept_groups[group]; the first-pass
+// histogram and the pair count are per group.  k_tf_scatter then runs one workgroup per group over the kept splats only
+// (tile_first.hip, COMPACTED): a band of an eighth of the screen keeps an eighth of the splats, and what the scatter costs
+// is its workgroups (C2, eight virtual ranks: scatter 34 -> 17 us per rank, this pass 26 -> 33 us, the rank's frame 0.154 ->
+// 0.144 ms; profiles/r04_j_band_compaction_C2.txt).
+constexpr uint32_t BTC_THREADS = 512, BTC_WAVES = BTC_THREADS / 64, BTC_PER_THREAD = 8, BTC_GROUP = BTC_THREADS * BTC_PER_THREAD;
+static_assert(BTC_GROUP == 4096 && BTC_PER_THREAD * BTC_WAVES == 64, "a group is 4096 records = 64 (row, wave) cells of 64 records");
+template <int FORMAT>
+__global__ __launch_bounds__(BTC_THREADS) void k_band_prepare_tfc(const float4 *__restrict__ records, uint32_t n, BinParams bp,
+                                                                  uint32_t *__restrict__ keys_c, uint32_t *__restrict__ range_c,
+                                                                  uint32_t *__restrict__ idx_c, uint32_t *__restrict__ kept_groups,
+                                                                  TfHistOut ho) {
+    __shared__ uint32_t lh[BTC_WAVES][256];
+    __shared__ uint32_t rowcnt[64]; // kept per (row of 512 records, wave), then its exclusive scan: the cells in index order
+    __shared__ uint32_t wsum[BTC_WAVES];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
+    for (uint32_t j = tid; j < BTC_WAVES * 256; j += BTC_THREADS) (&lh[0][0])[j] = 0;
+    __syncthreads();
+    const uint32_t g0 = blockIdx.x * BTC_GROUP;
+    // every record of the thread is in flight before the first is looked at (one memory round trip per workgroup)
+    float4 ra[BTC_PER_THREAD], rb[BTC_PER_THREAD], rc[BTC_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < BTC_PER_THREAD; ++k) {
+        const uint32_t i = g0 + k * BTC_THREADS + tid;
+        ra[k] = rb[k] = rc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < n) {
+            if (FORMAT == SPLAT_RECORDS_DISC48) {
+                ra[k] = records[(size_t)i * 3];
+                rb[k] = records[(size_t)i * 3 + 1];
+                rc[k] = records[(size_t)i * 3 + 2];
+            } else if (FORMAT == SPLAT_RECORDS_COMPACT) {
+                ra[k] = records[i];
+            } else {
+                ra[k] = records[(size_t)i * 2];
+                rb[k] = records[(size_t)i * 2 + 1];
+            }
+        }
+    }
+    uint32_t rng[BTC_PER_THREAD], key[BTC_PER_THREAD];
+    uint32_t okbits = 0, pairs = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BTC_PER_THREAD; ++k) {
+        const uint32_t i = g0 + k * BTC_THREADS + tid;
+        bool ok = false;
+        rng[k] = 1u; // (the empty range)
+        key[k] = 0u;
+        if (i < n) {
+            float4 a;
+            float depth;
+            if (FORMAT == SPLAT_RECORDS_DISC48) {
+                const DiscRecord d = {ra[k], rb[k]};
+                disc_bounds(d, a); // (NaN padding records: not finite -> all zero -> bins nowhere)
+                depth = rc[k].x;
+            } else if (FORMAT == SPLAT_RECORDS_COMPACT) {
+                const float4 c = ra[k];
+                const float padded = c.z * 1.5f; // SplatProjector.ts:119-121 (this file is compiled with -ffp-contract=off)
+                a = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
+                depth = c.w;
+            } else {
+                a = ra[k];
+                depth = rb[k].x;
+            }
+            uint32_t tx0, tx1, ty0, ty1;
+            ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
+            if (ok) {
+                rng[k] = pack_range32(true, tx0, tx1, ty0, ty1);
+                key[k] = depth_key_of(depth);
+                pairs += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        okbits |= ok ? (1u << k) : 0u;
+        if (lane == 0) rowcnt[k * BTC_WAVES + w] = (uint32_t)__popcll(m);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pairs += __shfl_xor(pairs, d);
+    if (lane == 0) wsum[w] = pairs;
+    __syncthreads();
+    // where each (row, wave) cell's kept splats go: an exclusive scan of the 64 counts in (row, wave) order = ascending index
+    if (w == 0) {
+        const uint32_t mine = rowcnt[lane];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += x;
+        }
+        rowcnt[lane] = incl - mine;
+        if (lane == 63) {
+            kept_groups[blockIdx.x] = incl;
+            uint32_t ps = 0;
+#pragma unroll
+            for (uint32_t v = 0; v < BTC_WAVES; ++v) ps += wsum[v];
+            ho.blocksums[blockIdx.x] = ps;
+        }
+    }
+    if (tid <= ho.mask) {
+        uint32_t hs = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < BTC_WAVES; ++v) hs += lh[v][tid];
+        ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = hs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < BTC_PER_THREAD; ++k) {
+        const bool ok = (okbits >> k) & 1u;
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const uint32_t pos = g0 + rowcnt[k * BTC_WAVES + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            range_c[pos] = rng[k];
+            keys_c[pos] = key[k];
+            idx_c[pos] = g0 + k * BTC_THREADS + tid;
+        }
+    }
+}
+
 // compact: the kept (key, global index) pairs of block b go to [base[b], ...) in ascending index order
 __global__ __launch_bounds__(BAND_THREADS) void k_band_compact(const uint32_t *__restrict__ keys_by_idx,
                                                                const uint32_t *__restrict__ range32, uint32_t n,
@@ -317,8 +436,6 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         rc = binner_reserve(binner, ntx * nty, n_records);
         if (rc != SPLAT_OK) return rc;
         const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
-        const uint32_t blocks = div_up(n_records, BTF_BLOCK);
-        const TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         // cfg->record_format = SPLAT_RECORDS_LIT32 (or SPLAT_BAND_RECORDS=lit for every band frame of the process): the band's
         // composite gathers ONE 32-byte lit composite record per staged entry, written here for the splats the band keeps,
         // instead of the exchange record + colour (+ normal).  Same image.  Measured on one MI355X with eight virtual ranks
@@ -342,8 +459,37 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
             }
             lio = {(const float4 *)band_color, (const float4 *)normals, band_color_stride, 1u, cfg->prelit, (float4 *)binner->band_lit};
         }
+        // A band that is a fraction of the screen keeps a fraction of the records: its prepare pass compacts them per group of
+        // 4096 records and the scatter runs over the kept splats only (k_band_prepare_tfc).  Measured with virtual ranks at C2:
+        // a gain from a third of the rows down (four ranks: level; eight: -10 us per rank), a loss at half of them (two ranks:
+        // +13 us: the compacting pass costs 7 us more than the plain one).  (SPLAT_BAND_COMPACT=0 | 1 forces one of them.)
+        static int s_compact = -2;
+        if (s_compact == -2) {
+            const char *e = getenv("SPLAT_BAND_COMPACT");
+            s_compact = !e ? -1 : (e[0] == '0' ? 0 : 1);
+        }
+        const bool compacting = !lio.records && (s_compact == 1 || (s_compact == -1 && 3u * (row1 - row0) <= nty));
+        const uint32_t blocks = div_up(n_records, compacting ? BTC_GROUP : BTF_BLOCK);
+        if (compacting && n_records > binner->band_idx_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (binner->band_idx) (void)hipFree(binner->band_idx);
+            binner->band_idx = nullptr;
+            binner->band_idx_cap = 0;
+            const size_t slots = (size_t)div_up(n_records, BTC_GROUP) * BTC_GROUP;
+            if (hipMalloc((void **)&binner->band_idx, slots * 4 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "band index hipMalloc");
+            binner->band_idx_cap = n_records;
+        }
+        const TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
-        if (disc)
+        if (compacting) {
+#define SPLAT_BAND_PREPARE_C(FORMAT)                                                                                                  \
+    hipLaunchKernelGGL(k_band_prepare_tfc<FORMAT>, dim3(blocks), dim3(BTC_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp, \
+                       sorter->keys, binner->range32, binner->band_idx, sorter->hist, ho)
+            if (disc) SPLAT_BAND_PREPARE_C(SPLAT_RECORDS_DISC48);
+            else if (compact) SPLAT_BAND_PREPARE_C(SPLAT_RECORDS_COMPACT);
+            else SPLAT_BAND_PREPARE_C(SPLAT_RECORDS_PROJECTED);
+#undef SPLAT_BAND_PREPARE_C
+        } else if (disc)
             hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_DISC48>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
                                (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho, lio);
         else if (compact)
@@ -355,7 +501,9 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
         binner->tf_hist_ready = true;
-        binner->tf_block = BTF_BLOCK;
+        binner->tf_block = compacting ? BTC_GROUP : BTF_BLOCK;
+        binner->tf_cidx = compacting ? binner->band_idx : nullptr;
+        binner->tf_kept = compacting ? sorter->hist : nullptr;
         sorter->ran = false;
         sorter->count_pending = false;
         sorter->kept_blocks = blocks; // the kept count is summed on demand (splat_band_kept / splat_band_settle)

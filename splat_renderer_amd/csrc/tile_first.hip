@@ -176,7 +176,13 @@ struct TfScatterShared {
 #ifndef TF_SCATTER_WAVES
 #define TF_SCATTER_WAVES 5 // (tuning knob of tools/build_variant.sh: 4 and 6 measured, profiles/r03_q_small_knobs_C2.txt)
 #endif
-template <bool RANK_ATOMIC, uint32_t TF_PER_THREAD>
+// COMPACTED (a multi-GPU band's frame, frame.hip: k_band_prepare_tfc): a workgroup's input is not 1024 consecutive splat
+// indices but the splats its band KEEPS of a group of TF_GROUP consecutive records, compacted in index order to the start of
+// the group's segment of range32 / depth_keys, their indices beside them (`cidx`), their number in kept[group] — a band of
+// an eighth of the screen keeps an eighth of the splats, and what this kernel costs is its workgroups, not its pairs.  The
+// histogram has one column per group.  A group that keeps more than 1024 splats goes in rounds of 1024.
+constexpr uint32_t TF_GROUP = 4096;
+template <bool RANK_ATOMIC, uint32_t TF_PER_THREAD, bool COMPACTED = false>
 __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(const uint32_t *__restrict__ range32,
                                                            const uint32_t *__restrict__ depth_keys, uint32_t n, uint32_t ntx,
                                                            uint32_t mask, uint32_t num_parts,
@@ -186,18 +192,23 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
                                                            uint8_t *__restrict__ out_hi, uint2 *__restrict__ out_val,
                                                            uint32_t lo_bits, uint32_t align_m1, TfRuns runs,
                                                            uint32_t *__restrict__ offsets_out, uint32_t tiles, uint32_t *report,
-                                                           uint32_t seq) {
+                                                           uint32_t seq, const uint32_t *__restrict__ cidx,
+                                                           const uint32_t *__restrict__ kept) {
+    static_assert(!COMPACTED || TF_PER_THREAD == 4, "compacted groups are read four splats per thread");
     __shared__ TfScatterShared sh;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
     __shared__ uint32_t s_key[TF_THREADS * TF_PER_THREAD];
+    __shared__ uint32_t s_idx[COMPACTED ? TF_THREADS * TF_PER_THREAD : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t first = blockIdx.x * (TF_THREADS * TF_PER_THREAD);
+    uint32_t first = blockIdx.x * (COMPACTED ? TF_GROUP : TF_THREADS * TF_PER_THREAD);
+    // (COMPACTED: n = this group's kept splats end at first + kept[group]; the loads below stop there)
+    if (COMPACTED) n = first + min(kept[blockIdx.x], TF_GROUP);
     // every global load of the prologue is issued before anything waits on one: the block's ranges and
     // keys, the digit totals, and this block's row of scanned histogram (measured per phase, a workgroup
     // spent 15 % of its life on the totals alone when they were loaded, scanned and waited for first)
     static_assert(TF_PER_THREAD == 4 || TF_PER_THREAD == 1, "uint4 or scalar loads");
-    const uint32_t i0 = first + tid * TF_PER_THREAD; // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
+    uint32_t i0 = first + tid * TF_PER_THREAD; // thread t owns splats first + 4t .. 4t+3 (one 16-byte load each of ranges and keys)
     uint4 rr = make_uint4(1u, 1u, 1u, 1u), kk = make_uint4(0, 0, 0, 0); // 1 = empty range
     if (TF_PER_THREAD == 1) {
         if (i0 < n) { rr.x = range32[i0]; kk.x = depth_keys[i0]; }
@@ -267,12 +278,25 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
         }
     }
     if (all_pairs > pair_limit) return;
-    __syncthreads(); // wave_sums and wsum are reused below
+    // where this block's pairs of digit tid start: digit start + the earlier blocks' share
+    sh.global_base[tid] = run_start + row_prefix;
+    for (;;) { // (COMPACTED: rounds of 1024 kept splats; otherwise once)
+    __syncthreads(); // wave_sums and wsum are reused below (and the round before has left stage, s_key, s_idx)
 
     uint32_t r[TF_PER_THREAD], h[TF_PER_THREAD];
     if constexpr (TF_PER_THREAD == 4) {
         reinterpret_cast<uint4 *>(s_key)[tid] = kk;
         r[0] = rr.x; r[1] = rr.y; r[2] = rr.z; r[3] = rr.w;
+        if constexpr (COMPACTED) { // the kept splats' own indices (what a pair carries)
+            uint4 ii = make_uint4(0, 0, 0, 0);
+            if (i0 + 3 < n) ii = reinterpret_cast<const uint4 *>(cidx)[i0 >> 2];
+            else {
+                if (i0 < n) ii.x = cidx[i0];
+                if (i0 + 1 < n) ii.y = cidx[i0 + 1];
+                if (i0 + 2 < n) ii.z = cidx[i0 + 2];
+            }
+            reinterpret_cast<uint4 *>(s_idx)[tid] = ii;
+        }
     } else {
         s_key[tid] = kk.x;
         r[0] = rr.x;
@@ -302,9 +326,8 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
         carry = s0 + s1 + s2 + s3;
     }
     const uint32_t total = carry;
-    if (total == 0) return;
-    // where this block's pairs of digit tid start: digit start + the earlier blocks' share
-    sh.global_base[tid] = run_start + row_prefix;
+    const bool more_splats = COMPACTED && first + TF_THREADS * TF_PER_THREAD < n; // (uniform) another round of this group's kept splats follows
+    if (total == 0 && !more_splats) return;
     // rounds of TF_STAGE pairs (one round unless the block's splats are unusually large)
     for (uint32_t c0 = 0; c0 < total; c0 += TF_STAGE) {
         const uint32_t cnt = (total - c0 < TF_STAGE) ? total - c0 : TF_STAGE;
@@ -362,13 +385,31 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
             const uint32_t e = stage[pos], slot = e & 1023u, d = (e >> 10) & mask;
             const uint32_t g = sh.global_base[d] + (pos - sh.digit_base[d]);
             out_hi[g] = (uint8_t)(e >> (10u + lo_bits)); // (the low digit is the run the pair sits in)
-            out_val[g] = make_uint2(s_key[slot], first + slot);
+            out_val[g] = make_uint2(s_key[slot], COMPACTED ? s_idx[slot] : first + slot);
         }
-        if (c0 + TF_STAGE >= total) break; // (the usual case: one round)
+        if (c0 + TF_STAGE >= total && !more_splats) break; // (the usual case: one round)
         __syncthreads();
         sh.global_base[tid] += dcount; // the next round's pairs of digit tid follow this round's
         __syncthreads();
     }
+    if (!more_splats) return;
+    // the group's next 1024 kept splats
+    first += TF_THREADS * TF_PER_THREAD;
+    {
+        const uint32_t j0 = first + tid * TF_PER_THREAD;
+        rr = make_uint4(1u, 1u, 1u, 1u);
+        kk = make_uint4(0, 0, 0, 0);
+        if (j0 + 3 < n) {
+            rr = reinterpret_cast<const uint4 *>(range32)[j0 >> 2];
+            kk = reinterpret_cast<const uint4 *>(depth_keys)[j0 >> 2];
+        } else {
+            if (j0 < n) { rr.x = range32[j0]; kk.x = depth_keys[j0]; }
+            if (j0 + 1 < n) { rr.y = range32[j0 + 1]; kk.y = depth_keys[j0 + 1]; }
+            if (j0 + 2 < n) { rr.z = range32[j0 + 2]; kk.z = depth_keys[j0 + 2]; }
+        }
+        i0 = j0;
+    }
+    } // (rounds of kept splats)
 }
 
 // The end of the in-LDS sort: the tile's index list goes out, and THE ORDER CHECK.  The tile's list must be in strictly
@@ -1064,19 +1105,25 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
 int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *depth_keys, uint32_t n, uint32_t ntx, uint32_t mask,
                       const uint32_t *hist, uint32_t *d_total, uint32_t pair_limit, uint32_t *overflow, uint8_t *out_hi,
                       uint2 *out_val, uint32_t block_splats, uint32_t lo_bits, bool second_pass, const TfRuns *runs,
-                      uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq) {
+                      uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq, const uint32_t *cidx,
+                      const uint32_t *kept) {
     const uint32_t parts = div_up(n, block_splats);
+    if (cidx && block_splats != TF_GROUP) return ctx_fail(ctx, SPLAT_ERR_INVALID, "tf_scatter_launch: compacted input comes in groups of 4096 records");
     const uint32_t *totals = hist + (size_t)256 * parts;
     {
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
     }
     const bool ra = rank_atomic_ok(ctx, true); // (checked: k_tile_sort verifies every list this pass contributes to)
-#define SPLAT_TF_SCATTER(RA, PER)                                                                                                 \
-    hipLaunchKernelGGL((k_tf_scatter<RA, PER>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
+#define SPLAT_TF_SCATTER_(RA, PER, COMPACTED)                                                                                     \
+    hipLaunchKernelGGL((k_tf_scatter<RA, PER, COMPACTED>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
                        hist, totals, d_total, pair_limit, overflow, out_hi, out_val, lo_bits, second_pass ? TF_RUN_ALIGN - 1u : 0u, *runs,         \
-                       second_pass ? nullptr : offsets_if_final, tiles, report, seq)
-    if (block_splats == TF_BLOCK_SMALL) {
+                       second_pass ? nullptr : offsets_if_final, tiles, report, seq, cidx, kept)
+#define SPLAT_TF_SCATTER(RA, PER) SPLAT_TF_SCATTER_(RA, PER, false)
+    if (cidx) { // a multi-GPU band's kept splats, compacted per group of TF_GROUP records
+        if (ra) SPLAT_TF_SCATTER_(true, 4, true);
+        else SPLAT_TF_SCATTER_(false, 4, true);
+    } else if (block_splats == TF_BLOCK_SMALL) {
         if (ra) SPLAT_TF_SCATTER(true, 1);
         else SPLAT_TF_SCATTER(false, 1);
     } else {
@@ -1084,6 +1131,7 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
         else SPLAT_TF_SCATTER(false, 4);
     }
 #undef SPLAT_TF_SCATTER
+#undef SPLAT_TF_SCATTER_
     LAUNCH_CHECK(ctx, "k_tf_scatter");
     return SPLAT_OK;
 }
