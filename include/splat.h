@@ -203,14 +203,17 @@ int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr);
 int splat_composite_forget_history(splat_ctx *ctx);
 /* Per-context choices the environment otherwise makes for the whole process (environment table):
  *   kernel  -1 default (SPLAT_COMPOSITE: lane-efficient k_composite_px on screens of >= 2048 tiles), 0 k_composite ("quadrant"),
- *            1 k_composite_px ("pixel") — for isotropic nearest-on-top frames; the disc footprint and the reference-literal
- *            blend always take k_composite;
- *   ahead    0 default (SPLAT_PX_AHEAD, 2), 1 or 2: chunks k_composite_px's builder wave stays ahead of its consumer wave
- *            (2: lanes whose queue for a chunk is empty go on with the next chunk's);
+ *            1 k_composite_px ("pixel") — for nearest-on-top frames of either footprint; the reference-literal blend always
+ *            takes k_composite;
+ *   ahead    0 default (SPLAT_PX_AHEAD: 1 for the isotropic footprint with the early-out, 2 otherwise), 1 or 2: chunks
+ *            k_composite_px's builder wave stays ahead of its consumer wave (2: lanes whose queue for a chunk is empty go on
+ *            with the next chunk's);
  *   predict -1 default (SPLAT_PX_PREDICT, on), 0 / 1: bound each tile's look-ahead by what the previous launch walked;
  *   slack   -1 default (SPLAT_PX_SLACK, 0), else chunks added to that bound.
- * Every combination gives the same image (tests/test_gpu_stages.py runs the oracle comparisons over them).  Forgets the
- * composite's history. */
+ * ahead, predict and slack change the schedule only: the same bytes.  The two kernels evaluate the Gaussian differently
+ * (k_composite_px builds an entry's table by a recurrence from five exponentials) and agree within the composite's stated
+ * tolerance, 2e-5 per float channel, <= 1 LSB on rgba8 (tests/test_gpu_stages.py runs the oracle comparisons over all of
+ * them).  Forgets the composite's history. */
 int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict, int slack);
 /* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
  * (the result is then invalid).  Synchronises. */

@@ -147,7 +147,8 @@ class Device:
 
     def compositeOptions(self, kernel=None, ahead=0, predict=None, slack=None):
         """splat_composite_options: kernel None (library default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict None |
-        False | True; slack None | chunks.  Every combination gives the same image."""
+        False | True; slack None | chunks.  ahead / predict / slack change the schedule only (same bytes); the two kernels agree within
+        the composite's stated tolerance."""
         k = -1 if kernel is None else {"quadrant": 0, "pixel": 1}[kernel]
         check(self.lib.splat_composite_options(self.ctx, k, int(ahead), -1 if predict is None else int(bool(predict)),
                                                -1 if slack is None else int(slack)), self.ctx)

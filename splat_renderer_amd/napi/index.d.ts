@@ -18,6 +18,11 @@ export class Device {
   createCommandEncoder(): CommandEncoder;
   sync(): void;
   rankStatus(): { policy: string; atomicsOrdered: boolean; orderFaults: number };
+  compositeOptions(kernel?: 'quadrant' | 'pixel' | null, ahead?: number, predict?: boolean | null, slack?: number | null): void;
+  forgetCompositeHistory(): void;
+  setTiming(enabled: boolean, stageMask?: number, every?: number): void;
+  stageTimeStats(stage: number): { samples: number; totalMs: number };
+  timingConsumed(): { staged: number; consumed: number };
   destroy(): void;
 }
 export interface CommandEncoder { finish(): null; }

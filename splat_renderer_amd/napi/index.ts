@@ -21,6 +21,8 @@ declare const module: { exports: any };
 type TypedArray = Float32Array | Uint32Array | Uint8Array | Int32Array;
 interface CommandEncoder { finish(): null; }
 interface RankStatus { policy: string; atomicsOrdered: boolean; orderFaults: number }
+interface StageTimeStats { samples: number; totalMs: number }
+interface EntriesCounted { staged: number; consumed: number }
 interface PointerLikeEvent {
   clientX?: number;
   clientY?: number;
@@ -99,6 +101,33 @@ class Device {
   rankStatus(): RankStatus {
     const s = native.rank_status(this.ctx);
     return { policy: ['checked', 'atomic', 'ballot'][s[0]], atomicsOrdered: s[1] === 1, orderFaults: s[2] };
+  }
+  /** splat_composite_options: which composite kernel this context runs and how far its builder looks ahead (ahead / predict /
+   *  slack change the schedule only: same bytes; the two kernels agree within the composite's stated tolerance).  kernel null (library default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict null |
+   *  boolean (the look-ahead bound from the previous launch's per-tile costs); slack null | chunks.  host.py Device.compositeOptions. */
+  compositeOptions(kernel: string | null = null, ahead: number = 0, predict: boolean | null = null, slack: number | null = null): void {
+    const k = kernel === null ? -1 : kernel === 'quadrant' ? 0 : kernel === 'pixel' ? 1 : NaN;
+    if (Number.isNaN(k)) throw new Error("compositeOptions: kernel is null, 'quadrant' or 'pixel'");
+    native.composite_options(this.ctx, k, ahead, predict === null ? -1 : predict ? 1 : 0, slack === null ? -1 : slack);
+  }
+  /** splat_composite_forget_history: the next composite behaves like a context's first (row-major tile order, no look-ahead bound). */
+  forgetCompositeHistory(): void { native.composite_forget_history(this.ctx); }
+  /** splat_set_timing / _stages / _sampling: HIP-event timing of the stages in `stageMask` (bit = stage id; 0 = all), every
+   *  `every`-th launch. */
+  setTiming(enabled: boolean, stageMask: number = 0, every: number = 1): void {
+    native.set_timing(this.ctx, enabled ? 1 : 0);
+    if (enabled && stageMask) native.set_timing_stages(this.ctx, stageMask);
+    if (enabled) native.set_timing_sampling(this.ctx, every);
+  }
+  /** splat_stage_time_stats: launches timed and their total since timing was switched on. */
+  stageTimeStats(stage: number): StageTimeStats {
+    const s = native.stage_time_stats(this.ctx, stage);
+    return { samples: s[0], totalMs: s[1] };
+  }
+  /** splat_timing_consumed: list entries staged and consumed by the timed composites (counted only when asked for in setTiming's mask). */
+  timingConsumed(): EntriesCounted {
+    const s = native.timing_consumed(this.ctx);
+    return { staged: s[0], consumed: s[1] };
   }
   destroy(): void {
     if (this.ctx) native.ctx_destroy(this.ctx);

@@ -33,7 +33,7 @@ if (!threw) throw new Error('getter before binSplats did not throw');
   if (orderPath) fs.writeFileSync(orderPath, Buffer.from(sorter.getSortedIndicesBuffer().read(new Uint32Array(n)).buffer));
   if (countsPath) fs.writeFileSync(countsPath, Buffer.from(binner.getTileCountsBuffer().read(new Uint32Array(binner.numTiles)).buffer));
   if (indicesPath) fs.writeFileSync(indicesPath, Buffer.from(binner.getTileIndicesBuffer().read(new Uint32Array(binner.getTotalIndices())).buffer));
-  let framePairs = -1, recordFormat = -1, bandEqualsFrame = null, bandPairs = -1, pointManagerOk = null;
+  let framePairs = -1, recordFormat = -1, schedulesKeepTheBytes = null, kernelsWithinOneLsb = null, timed = null, bandEqualsFrame = null, bandPairs = -1, pointManagerOk = null;
   if (framePath) { // the whole-frame facade (tile-first order inside), fed the native two-plane property layout, twice (2nd: sync-free)
     const whole = new sr.Renderer(device, null, 'rgba8unorm', n, 16);
     whole.binner.setFrameOrder('tileFirst');
@@ -42,6 +42,22 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     fs.writeFileSync(framePath, Buffer.from(framePixels.buffer));
     framePairs = whole.binner.getTotalIndices();
     recordFormat = whole.recordFormat;
+    // the composite's per-context options and the timing detail from JS: the per-pixel-queue kernel under two schedules (one chunk
+    // of look-ahead bounded by history; two chunks, no history, a chunk of slack) gives the same bytes, and the default kernel's
+    // image within 1 LSB; one composite launch timed, its entries counted
+    device.compositeOptions('pixel', 1, true, null);
+    for (let k = 0; k < 3; k++) whole.render(uniforms, props.getPropertyPlanes(), normals, null, W, H);
+    const pixelA = whole.readPixels();
+    device.compositeOptions('pixel', 2, false, 1);
+    device.forgetCompositeHistory();
+    device.setTiming(true, (1 << 3) + 0x80000000, 1); // the bit of SPLAT_STAGE_COMPOSITE + SPLAT_TIMING_COUNT_ENTRIES
+    whole.render(uniforms, props.getPropertyPlanes(), normals, null, W, H);
+    const pixelB = whole.readPixels();
+    schedulesKeepTheBytes = pixelB.length === pixelA.length && pixelB.every((v, i) => v === pixelA[i]);
+    kernelsWithinOneLsb = pixelA.length === framePixels.length && pixelA.every((v, i) => Math.abs(v - framePixels[i]) <= 1);
+    timed = Object.assign(device.stageTimeStats(3), device.timingConsumed());
+    device.setTiming(false);
+    device.compositeOptions(null, 0, null, null);
     // north_star's multi-GPU frame from JS, on the one GPU there is: a one-rank RCCL communicator behind the C ABI,
     // project my slice -> all-gather -> my band (= every tile row) from the gathered 16-byte records
     const comm = new sr.Comm(device, 0, 1, sr.Comm.uniqueId());
@@ -81,6 +97,6 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     fs.writeFileSync(discFramePath, Buffer.from(whole.readPixels().buffer));
     discFramePairs = whole.binner.getTotalIndices();
   }
-  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, seqPairs, discFramePairs, recordFormat, bandEqualsFrame, bandPairs,
+  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, schedulesKeepTheBytes, kernelsWithinOneLsb, timed, seqPairs, discFramePairs, recordFormat, bandEqualsFrame, bandPairs,
     pointManagerOk, ranking: device.rankStatus(), uniforms: Array.from(uniforms) }));
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -413,6 +413,120 @@ FN(allgather_records) { /* (ctx, comm, shard, gathered, bytesPerRank) */
     return check(env, x, splat_allgather_records(x, comm, shard, all, nb), mk_undefined(env));
 }
 
+/* ---- the rest of the ABI: timing detail, composite options, multi-GPU helpers, diagnostics ---- */
+static napi_value mk_pair(napi_env env, double a, double b) {
+    napi_value arr;
+    if (napi_create_array_with_length(env, 2, &arr) != napi_ok) return NULL;
+    napi_set_element(env, arr, 0, mk_number(env, a));
+    napi_set_element(env, arr, 1, mk_number(env, b));
+    return arr;
+}
+FN(ctx_create_on_stream) { /* (device, hipStream as a number) -> ctx */
+    ARGS(2); int dev = (int)arg_number(&c, 0); void *stream = arg_dptr(&c, 1); BAIL;
+    splat_ctx *ctx = NULL;
+    int rc = splat_ctx_create_on_stream(dev, stream, &ctx);
+    return check(env, NULL, rc, rc == SPLAT_OK ? mk_external(env, ctx) : NULL);
+}
+FN(last_error) { /* (ctx|null) -> string */
+    ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL;
+    const char *m = splat_last_error(x);
+    napi_value r;
+    napi_create_string_utf8(env, m ? m : "", NAPI_AUTO_LENGTH, &r);
+    return r;
+}
+FN(set_timing_stages) { ARGS(2); splat_ctx *x = arg_external(&c, 0); uint32_t m = (uint32_t)arg_number(&c, 1); BAIL; return check(env, x, splat_set_timing_stages(x, m), mk_undefined(env)); }
+FN(set_timing_sampling) { ARGS(2); splat_ctx *x = arg_external(&c, 0); uint32_t e = (uint32_t)arg_number(&c, 1); BAIL; return check(env, x, splat_set_timing_sampling(x, e), mk_undefined(env)); }
+FN(stage_time_stats) { /* (ctx, stage) -> [samples, totalMs] */
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); int st = (int)arg_number(&c, 1); BAIL;
+    uint32_t n = 0; double ms = 0;
+    int rc = splat_stage_time_stats(x, st, &n, &ms);
+    return rc == SPLAT_OK ? mk_pair(env, n, ms) : check(env, x, rc, NULL);
+}
+FN(timing_consumed) { /* (ctx) -> [staged, consumed] */
+    ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL;
+    uint64_t a = 0, b = 0;
+    int rc = splat_timing_consumed(x, &a, &b);
+    return rc == SPLAT_OK ? mk_pair(env, (double)a, (double)b) : check(env, x, rc, NULL);
+}
+FN(buf_copy) { /* (ctx, dst, src, bytes) */
+    ARGS(4); splat_ctx *x = arg_external(&c, 0); void *d = arg_dptr(&c, 1), *s = arg_dptr(&c, 2); size_t nb = (size_t)arg_number(&c, 3); BAIL;
+    return check(env, x, splat_buf_copy(x, d, s, nb), mk_undefined(env));
+}
+FN(probe_lds_atomic_order) { /* (ctx) -> mismatches */
+    ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL;
+    uint64_t m = 0;
+    int rc = splat_probe_lds_atomic_order(x, &m);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_number(env, (double)m) : NULL);
+}
+FN(debug_inject_order_fault) { ARGS(3); splat_ctx *x = arg_external(&c, 0); uint32_t t = (uint32_t)arg_number(&c, 1), p = (uint32_t)arg_number(&c, 2); BAIL; return check(env, x, splat_debug_inject_order_fault(x, t, p), mk_undefined(env)); }
+FN(debug_set_tile_order) { ARGS(2); splat_ctx *x = arg_external(&c, 0); void *o = arg_dptr(&c, 1); BAIL; return check(env, x, splat_debug_set_tile_order(x, o), mk_undefined(env)); }
+FN(debug_set_tile_sort_order) { ARGS(2); splat_ctx *x = arg_external(&c, 0); void *o = arg_dptr(&c, 1); BAIL; return check(env, x, splat_debug_set_tile_sort_order(x, o), mk_undefined(env)); }
+FN(composite_forget_history) { ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL; return check(env, x, splat_composite_forget_history(x), mk_undefined(env)); }
+FN(composite_options) { /* (ctx, kernel, ahead, predict, slack): -1 leaves a setting as it is */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0);
+    int k = (int)arg_number(&c, 1), a = (int)arg_number(&c, 2), p = (int)arg_number(&c, 3), sl = (int)arg_number(&c, 4); BAIL;
+    return check(env, x, splat_composite_options(x, k, a, p, sl), mk_undefined(env));
+}
+FN(sort_lookback_timeouts) { /* (sorter) -> flag */
+    ARGS(1); splat_sorter *s = arg_external(&c, 0); BAIL;
+    uint32_t f = 0;
+    int rc = splat_sort_lookback_timeouts(s, &f);
+    return check(env, NULL, rc, rc == SPLAT_OK ? mk_number(env, f) : NULL);
+}
+FN(bin_dims) { /* (binner) -> [tilesX, tilesY] */
+    ARGS(1); splat_binner *b = arg_external(&c, 0); BAIL;
+    uint32_t ntx = 0, nty = 0;
+    int rc = splat_bin_dims(b, &ntx, &nty);
+    return rc == SPLAT_OK ? mk_pair(env, ntx, nty) : check(env, NULL, rc, NULL);
+}
+FN(bin_tile_size) { ARGS(1); splat_binner *b = arg_external(&c, 0); BAIL; return mk_number(env, splat_bin_tile_size(b)); }
+FN(project_slice) { /* (ctx, Float32Array(22), posRadius, strideVec4, first, count, projectedSlice) */
+    ARGS(7); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
+    void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3), first = (uint32_t)arg_number(&c, 4), count = (uint32_t)arg_number(&c, 5);
+    void *out = arg_dptr(&c, 6); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_project_slice(x, u, pr, st, first, count, out), mk_undefined(env));
+}
+FN(project_slice_disc) { /* (ctx, Float32Array(22), posRadius, strideVec4, normals, normalStrideVec4, first, count, records48Slice) */
+    ARGS(9); splat_ctx *x = arg_external(&c, 0); size_t ub = 0; float *u = arg_hostbuf(&c, 1, &ub);
+    void *pr = arg_dptr(&c, 2); uint32_t st = (uint32_t)arg_number(&c, 3); void *nrm = arg_dptr(&c, 4);
+    uint32_t ns = (uint32_t)arg_number(&c, 5), first = (uint32_t)arg_number(&c, 6), count = (uint32_t)arg_number(&c, 7);
+    void *out = arg_dptr(&c, 8); BAIL;
+    if (ub < 22 * sizeof(float)) { napi_throw_range_error(env, NULL, "uniform block needs 22 floats"); return NULL; }
+    return check(env, x, splat_project_slice_disc(x, u, pr, st, nrm, ns, first, count, out), mk_undefined(env));
+}
+FN(expand_compact) { /* (ctx, records16, n, indexBase, projected) */
+    ARGS(5); splat_ctx *x = arg_external(&c, 0); void *rec = arg_dptr(&c, 1);
+    uint32_t n = (uint32_t)arg_number(&c, 2), base = (uint32_t)arg_number(&c, 3); void *out = arg_dptr(&c, 4); BAIL;
+    return check(env, x, splat_expand_compact(x, rec, n, base, out), mk_undefined(env));
+}
+FN(band_keys) { /* (ctx, sorter, projected, n, W, H, tile, row0, row1) -> kept */
+    ARGS(9); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); void *proj = arg_dptr(&c, 2);
+    uint32_t n = (uint32_t)arg_number(&c, 3), w = (uint32_t)arg_number(&c, 4), h = (uint32_t)arg_number(&c, 5), t = (uint32_t)arg_number(&c, 6);
+    uint32_t r0 = (uint32_t)arg_number(&c, 7), r1 = (uint32_t)arg_number(&c, 8); BAIL;
+    uint32_t kept = 0;
+    int rc = splat_band_keys(x, s, proj, n, w, h, t, r0, r1, &kept);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_number(env, kept) : NULL);
+}
+FN(band_kept) { /* (ctx, sorter) -> kept */
+    ARGS(2); splat_ctx *x = arg_external(&c, 0); splat_sorter *s = arg_external(&c, 1); BAIL;
+    uint32_t kept = 0;
+    int rc = splat_band_kept(x, s, &kept);
+    return check(env, x, rc, rc == SPLAT_OK ? mk_number(env, kept) : NULL);
+}
+FN(comm_rank) { /* (comm) -> [rank, world] */
+    ARGS(1); splat_comm *cm = arg_external(&c, 0); BAIL;
+    int r = 0, w = 0;
+    int rc = splat_comm_rank(cm, &r, &w);
+    return rc == SPLAT_OK ? mk_pair(env, r, w) : check(env, NULL, rc, NULL);
+}
+FN(comm_count) { /* (comm) -> [ranks RCCL reports, this rank as RCCL reports it] */
+    ARGS(1); splat_comm *cm = arg_external(&c, 0); BAIL;
+    int n = 0, r = 0;
+    int rc = splat_comm_count(cm, &n, &r);
+    return rc == SPLAT_OK ? mk_pair(env, n, r) : check(env, NULL, rc, NULL);
+}
+
 static napi_value init(napi_env env, napi_value exports) {
 #define EXPORT(name) { #name, NULL, name, NULL, NULL, NULL, napi_enumerable, NULL }
     napi_property_descriptor d[] = {
@@ -423,6 +537,10 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(scan_u32), EXPORT(bin_create), EXPORT(bin_destroy), EXPORT(bin_run), EXPORT(bin_counts), EXPORT(bin_offsets),
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
         EXPORT(project_slice_compact), EXPORT(band_frame), EXPORT(band_settle), EXPORT(comm_unique_id), EXPORT(comm_init), EXPORT(comm_destroy),
+        EXPORT(ctx_create_on_stream), EXPORT(last_error), EXPORT(set_timing_stages), EXPORT(set_timing_sampling), EXPORT(stage_time_stats), EXPORT(timing_consumed),
+        EXPORT(buf_copy), EXPORT(probe_lds_atomic_order), EXPORT(debug_inject_order_fault), EXPORT(debug_set_tile_order), EXPORT(debug_set_tile_sort_order),
+        EXPORT(composite_forget_history), EXPORT(composite_options), EXPORT(sort_lookback_timeouts), EXPORT(bin_dims), EXPORT(bin_tile_size), EXPORT(project_slice),
+        EXPORT(project_slice_disc), EXPORT(expand_compact), EXPORT(band_keys), EXPORT(band_kept), EXPORT(comm_rank), EXPORT(comm_count),
         EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature), EXPORT(sdf_seed_positions), EXPORT(sdf_generate),
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);

@@ -38,6 +38,24 @@ def test_python_binding_covers_the_header():
     assert lib.splat_abi_version() == 2
 
 
+def test_napi_addon_has_one_method_per_abi_entry_point():
+    """the N-API shim carries one method per export (same name without the prefix) — read from its source, and
+    from the built addon itself when Node is here (loading it needs no GPU)."""
+    import shutil
+    import subprocess
+    src = open(os.path.join(ROOT, "splat_renderer_amd", "napi", "splat_napi.c")).read()
+    exported = set(re.findall(r"EXPORT\(([a-z0-9_]+)\)", src.split("napi_property_descriptor d[]")[1]))
+    wanted = {n[len("splat_"):] for n in declared_functions()}
+    assert wanted - exported == set(), f"ABI entry points without an addon method: {sorted(wanted - exported)}"
+    assert exported - wanted == set(), f"addon methods that are not ABI entry points: {sorted(exported - wanted)}"
+    addon = os.path.join(ROOT, "splat_renderer_amd", "napi", "splat_napi.node")
+    if shutil.which("node") and os.path.exists(addon):
+        out = subprocess.run(["node", "-e", f"console.log(Object.keys(require({addon!r})).sort().join(' '))"], capture_output=True, text=True,
+                             timeout=60)
+        assert out.returncode == 0, out.stderr
+        assert set(out.stdout.split()) == wanted
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

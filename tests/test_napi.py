@@ -142,6 +142,13 @@ def test_js_frame_matches_oracle(tmp_path):
     frame8 = np.fromfile(tmp_path / "frame.rgba8", np.uint8).reshape(h, w, 4)
     assert np.array_equal(frame8, got8)  # same lists, same composite: same bytes as the staged path
     assert info["recordFormat"] == 3  # the facade's projector wrote lit composite records (SPLAT_RECORDS_LIT32)
+    # Device.compositeOptions / forgetCompositeHistory / setTiming / stageTimeStats / timingConsumed from JS: another schedule
+    # of k_composite_px, the same bytes; the other kernel within 1 LSB; one composite launch timed; its consumed entries
+    # within its staged ones within the lists
+    assert info["schedulesKeepTheBytes"] is True and info["kernelsWithinOneLsb"] is True
+    t = info["timed"]
+    assert t["samples"] == 1 and 0.0 < t["totalMs"] < 50.0
+    assert 0 < t["consumed"] <= t["staged"] <= ref["indices"].shape[0] + 32 * ref["counts"].shape[0]
     # north_star's multi-GPU frame from JS (one-rank RCCL communicator behind the C ABI) and PointManager
     assert info["bandEqualsFrame"] is True and info["bandPairs"] == ref["indices"].shape[0]
     assert info["pointManagerOk"] is True
