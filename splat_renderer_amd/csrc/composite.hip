@@ -493,17 +493,19 @@ typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 constexpr int PXC = 32;     // entries per chunk = bits of a lane's queue
 constexpr int PX_ROW = 35;  // float2 slots per table row: the idle slot, 32 entries, 2 of padding — rows 3 slots apart (mod 32),
                             // so the eight rows a wave reads for ONE entry fall into eight different bank pairs of a ds_read_b64
-constexpr int PX_TROWS = 18;
+constexpr int PX_TROWS = 16;
 // One chunk as the builder wave leaves it for the consumer wave.  Slot 0 of every row is the IDLE entry (zeros): what a
 // lane with an empty queue "takes" — entry j lives at slot 1 + j, so ffbl's -1 for an empty queue addresses the idle
 // slot without a select.
 struct PxBuf {
     float2 t[PX_TROWS][PX_ROW]; // t[c][1 + j] = {gx_j(2c), gx_j(2c+1)}: entry j's factor at the tile's pixel columns 2c, 2c+1 (c < 8);
                                 // t[8 + r][1 + j] = {gy_j(2r), gy_j(2r+1)} at its pixel rows; only the pairs entry j's box touches are
-                                // written (no lane is ever sent to another);  t[16][1 + j] = {lit r, g}, t[17][1 + j] = {lit b, 1}:
-                                // every read of a trip is 8 bytes at slot-stride 8 off ONE computed address
+                                // written (no lane is ever sent to another)
+    float4 col[PX_ROW];         // col[1 + j] = {lit r, g, b, 1}: ONE 16-byte read per trip (ds_read_b128, four LDS-array cycles) — as two
+                                // 8-byte rows the compiler merged the pair into a ds_read2_b64: eight cycles on 32 banks
     uint4 q4[4];                // as uint2 q[8]: q[c].x: bit j = entry j's box meets pixel columns 2c, 2c+1; q[r].y: ... pixel rows 2r, 2r+1
 };
+static_assert(offsetof(PxBuf, col) % 16 == 0, "the colour entries are read 16 bytes at a time");
 static_assert(sizeof(PxBuf) * 3 * 10 + 64 <= 160 * 1024, "ten tiles (twenty waves) per CU with three buffers");
 // The same for the oriented-disc footprint (SequentialRenderer.ts:91-142; disc.h), which is not separable: no tables — per
 // entry the inverse homography's eleven numbers, evaluated by the consumer for the four pixels of every lane the entry's
@@ -633,6 +635,16 @@ __device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost,
 #else
 #define PX_PRIORITY(N) do { } while (0)
 #endif
+// clamp(a b + c, 0, 1) per component in one fused operation (the clamp is the instruction's output modifier).  Packed: with
+// composite.hip compiled WITHOUT the packed f32 instructions (-target-feature -packed-fp32-ops: 42 plain instead of 26 vector
+// instructions per trip) a trip took 435 instead of 387 cycles, 348 instead of 285 for a wave alone on its SIMD
+// (profiles/r04_o_trip_cost_C2.txt): a trip costs its instruction count.
+__device__ __forceinline__ v2f fma_clamp01(v2f a, v2f b, v2f c) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <bool EARLY_OUT, bool LIT32, bool COUNT, int AH, bool DISC>
 __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams p, uint32_t band_tiles) {
     constexpr uint32_t NB = AH + 1;
@@ -671,9 +683,12 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
         const float tile_c = (h ? tile_y0 : tile_x0) + 0.5f, tile_0 = h ? tile_y0 : tile_x0; // :169 pixel centres, this lane's axis
         if constexpr (DISC) {
             if (lane < 3 * NB) s_buf[lane / 3].par[0][lane % 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // the idle entry of every buffer
-        } else if (lane < PX_TROWS) { // the idle slots of every buffer
+        } else if (lane <= PX_TROWS) { // the idle slots of every buffer
 #pragma unroll
-            for (uint32_t b = 0; b < NB; ++b) s_buf[b].t[lane][0] = make_float2(0.0f, 0.0f);
+            for (uint32_t b = 0; b < NB; ++b) {
+                if (lane < PX_TROWS) s_buf[b].t[lane][0] = make_float2(0.0f, 0.0f);
+                else s_buf[b].col[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
         // Entries are fetched two chunks ahead of their build and their indices three (the gather depends on the index).
         // Every load of this pipeline is UNCONDITIONAL — positions past the last one wanted re-read that one (one line for
@@ -759,8 +774,8 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
                 // cover by half: the uncovered pixel's factor is zero
                 if (m16 && (ia & 1u)) row[0].x = 0.0f;
                 if (m16 && !(ib & 1u)) reinterpret_cast<float2 *>(reinterpret_cast<char *>(row) + __umul24(npairs - 1u, PX_ROW * 8u))->y = 0.0f;
-                // the lit colour as two more rows of the table ({r, g}, {b, 1}: the 1 is the factor of T's update, PX_BLEND)
-                B.t[16 + h][1 + e] = h ? make_float2(colr.z, 1.0f) : make_float2(colr.x, colr.y);
+                // the lit colour beside the tables ({r, g | b, 1}: the 1 is the factor of T's update, PX_BLEND), a half per lane
+                reinterpret_cast<float2 *>(&B.col[1 + e])[h] = h ? make_float2(colr.z, 1.0f) : make_float2(colr.x, colr.y);
                 }
                 // queue words: one ballot gives X[c] (lanes 0..31 test the x mask) and Y[c] (lanes 32..63 the y mask)
                 const uint32_t mm = m16 | (m16 >> 1);
@@ -826,7 +841,8 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
     // byte offsets inside a PxBuf of slot 1 (entry 0) of this lane's x row; its y row and the colour rows relative to that
     // (DISC: slot 1 of the parameter array, the same for every lane)
     const uint32_t lane_x = DISC ? 48u : (bx * PX_ROW + 1u) * 8u;
-    const uint32_t d_xy = ((8u + by - bx) * PX_ROW) * 8u, d_xc = ((16u - bx) * PX_ROW) * 8u;
+    const uint32_t d_xy = ((8u + by - bx) * PX_ROW) * 8u;
+    const uint32_t d_col = DISC ? 0u : (uint32_t)offsetof(PxBuf, col) + 16u - lane_x; // from that slot to slot 1 of the colours
     // DISC: this lane's pixel centres (:169; global coordinates, as the disc records' centres are)
     const v2f pxc = {(float)px0 + 0.5f, (float)px0 + 1.5f}, pyc = {(float)py0 + 0.5f, (float)py0 + 1.5f};
     const char *const lds = reinterpret_cast<const char *>(s_buf);
@@ -914,8 +930,9 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             const char *a_ = lds + (A + (uint32_t)((int)J * 8));                       \
             E.gx = *reinterpret_cast<const float2 *>(a_);                              \
             E.gy = *reinterpret_cast<const float2 *>(a_ + d_xy);                       \
-            E.c0 = *reinterpret_cast<const float2 *>(a_ + d_xc);                       \
-            E.c1 = *reinterpret_cast<const float2 *>(a_ + d_xc + PX_ROW * 8);          \
+            const float4 c_ = *reinterpret_cast<const float4 *>(lds + (A + d_col + (uint32_t)((int)J * 16))); \
+            E.c0 = make_float2(c_.x, c_.y);                                            \
+            E.c1 = make_float2(c_.z, c_.w);                                            \
         }                                                                              \
     } while (0)
 // The per-pixel stop (:187-190: a pixel that has reached alpha >= 0.99, i.e. T <= T_STOP, takes nothing more) as a FACTOR:
@@ -943,7 +960,7 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
         /* :128-133 discard outside the unit circle, as a factor: clamp((1 - d2) 2^23 + 1, 0, 1) is exactly 1 for d2 <= 1 and  \
            exactly 0 from the next binary32 number above 1 on (and for NaN): one packed multiply-add for two compares + selects */ \
         v2f in_;                                                                                                              \
-        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(in_) : "v"(d2_), "v"(k_in_a), "v"(k_in_b));                             \
+        in_ = fma_clamp01(d2_, k_in_a, k_in_b);                                                                               \
         G = (v2f){__builtin_amdgcn_exp2f(ar_.x), __builtin_amdgcn_exp2f(ar_.y)} * in_;                                        \
     } while (0)
 #define PX_BLEND(J, R, S, E, CHECK)                                                                                           \
@@ -969,8 +986,8 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
         }                                                                                                                     \
         if (EARLY_OUT) {                                                                                                      \
             v2f m0, m1;                                                                                                       \
-            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m0) : "v"(T[0]), "v"(k_huge), "v"(k_stop));                        \
-            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m1) : "v"(T[1]), "v"(k_huge), "v"(k_stop));                        \
+            m0 = fma_clamp01(T[0], k_huge, k_stop);                                                                          \
+            m1 = fma_clamp01(T[1], k_huge, k_stop);                                                                          \
             if (CHECK) {                                                                                                      \
                 const v2f ms_ = m0 + m1; /* the four factors are 0 or 1: their sum says whether any pixel of the lane still accumulates */ \
                 const unsigned long long al_ = __ballot(ms_.x + ms_.y > 0.0f);                                               \
@@ -984,11 +1001,14 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
             w0 *= m0;                                                                                                         \
             w1 *= m1;                                                                                                         \
         }                                                                                                                     \
-        cr[0] += (v2f){C0.x, C0.x} * w0; cr[1] += (v2f){C0.x, C0.x} * w1; /* SURVEY §8a contract 3: nearest on top */         \
-        cg[0] += (v2f){C0.y, C0.y} * w0; cg[1] += (v2f){C0.y, C0.y} * w1;                                                     \
-        cb[0] += (v2f){C1.x, C1.x} * w0; cb[1] += (v2f){C1.x, C1.x} * w1;                                                     \
-        /* T (1 - g) with the product in hand; C1.y is 1.0 for an entry (the same bits as T - w), 0 for the idle one */        \
-        T[0] -= (v2f){C1.y, C1.y} * w0; T[1] -= (v2f){C1.y, C1.y} * w1;                                                       \
+        /* SURVEY §8a contract 3: nearest on top.  C += c w in ONE rounding (v_pk_fma_f32; composite.hip is the one file built     \
+           with contraction on: the sum is within the composite's stated tolerance either way) */                             \
+        cr[0] = __builtin_elementwise_fma((v2f){C0.x, C0.x}, w0, cr[0]); cr[1] = __builtin_elementwise_fma((v2f){C0.x, C0.x}, w1, cr[1]); \
+        cg[0] = __builtin_elementwise_fma((v2f){C0.y, C0.y}, w0, cg[0]); cg[1] = __builtin_elementwise_fma((v2f){C0.y, C0.y}, w1, cg[1]); \
+        cb[0] = __builtin_elementwise_fma((v2f){C1.x, C1.x}, w0, cb[0]); cb[1] = __builtin_elementwise_fma((v2f){C1.x, C1.x}, w1, cb[1]); \
+        /* T (1 - g) with the product in hand; C1.y is 1.0 for an entry, 0 for the idle one: the product is exact, so this is \
+           the same bits as T - w */                                                                                          \
+        T[0] = __builtin_elementwise_fma((v2f){-C1.y, -C1.y}, w0, T[0]); T[1] = __builtin_elementwise_fma((v2f){-C1.y, -C1.y}, w1, T[1]); \
     } while (0)
 #ifdef PX_PROFILE
             const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
