@@ -322,6 +322,13 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
                const uint32_t *depth_keys) {
     splat_ctx *ctx = b->ctx;
     const bool tile_first = depth_keys != nullptr;
+    // what the caller prepared for THIS run (its projector's histogram; a band's compacted splats) is taken and cleared before
+    // anything can return: a call that fails below must not leave it for another frame function's run
+    const bool hist_ready = b->tf_hist_ready;
+    const uint32_t *tf_cidx = b->tf_cidx, *tf_kept = b->tf_kept;
+    b->tf_hist_ready = false;
+    b->tf_cidx = nullptr;
+    b->tf_kept = nullptr;
     ARG_CHECK(ctx, width >= 1 && height >= 1);
     ARG_CHECK(ctx, n_sorted == 0 || (projected && (sorted || tile_first)));
     ARG_CHECK(ctx, !tile_first || (range32 && n_sorted == n_splats && !n_sorted_dev));
@@ -346,11 +353,6 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
     // tile ids up to 16 bits, sorted in two passes with the bits split evenly (13 bits -> 6 + 7) rather
     // than 8 + 5: a pass scatters in digit runs, and 64 + 128 bins give longer runs than 256 + 32
     const uint32_t tf_bits = tile_id_bits(tiles), tf_lo_bits = tile_id_low_bits(tiles);
-    const bool hist_ready = b->tf_hist_ready;
-    b->tf_hist_ready = false;
-    const uint32_t *tf_cidx = b->tf_cidx, *tf_kept = b->tf_kept; // (this run's only)
-    b->tf_cidx = nullptr;
-    b->tf_kept = nullptr;
     ARG_CHECK(ctx, !tile_first || hist_ready); // the caller's projector / band prepare has counted the first pass's histogram
 
     stage_begin(ctx, SPLAT_STAGE_BIN);
