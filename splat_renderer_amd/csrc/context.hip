@@ -189,9 +189,11 @@ int ctx_ensure_consumed(splat_ctx *ctx, uint32_t tiles) {
     unsigned long long *bigger = nullptr;
     // (two counters per tile: entries staged, entries consumed)
     if (hipMalloc((void **)&bigger, (size_t)tiles * 16) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "consumed counters hipMalloc");
-    HIP_TRY(ctx, hipMemset(bigger, 0, (size_t)tiles * 16));
+    // (on the context's own stream: it is non-blocking, so null-stream work is not ordered before what is launched next)
+    HIP_TRY(ctx, hipMemsetAsync(bigger, 0, (size_t)tiles * 16, ctx->stream));
     if (ctx->d_consumed) {
-        HIP_TRY(ctx, hipMemcpy(bigger, ctx->d_consumed, (size_t)ctx->consumed_tiles * 16, hipMemcpyDeviceToDevice));
+        HIP_TRY(ctx, hipMemcpyAsync(bigger, ctx->d_consumed, (size_t)ctx->consumed_tiles * 16, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->d_consumed);
     }
     ctx->d_consumed = bigger;

@@ -742,7 +742,13 @@ int sorter_reserve(splat_sorter *s, uint32_t capacity) {
     }
     s->payload = s->keys + padded;
     s->payload_b = s->keys_b + padded;
-    if (hipMemset(s->hist, 0, hist_bytes) != hipSuccess) {
+    // ON THE CONTEXT'S STREAM: that stream is non-blocking, so a fill on the null stream (plain hipMemset returns before the fill
+    // has run) is not ordered before the kernels launched next — and the very next ones write this workspace.  The first
+    // sort of a fresh sorter could find parts of its scanned histogram zeroed afterwards: a binner's first sort-first frame
+    // with its tile ids out of order — seen twice in three rounds of suite runs, both times in the test that renders ONE
+    // frame on a fresh Renderer (tests/test_gpu_stages.py: test_tile_lists_equal_the_reference_own_code; round 2's
+    // "small300" record; profiles/r04_s_gpu_test_matrix_and_null_stream_memset.txt).
+    if (hipMemsetAsync(s->hist, 0, hist_bytes, ctx->stream) != hipSuccess) {
         sorter_free(s);
         return ctx_fail(ctx, SPLAT_ERR_HIP, "sorter workspace hipMemset");
     }

@@ -275,6 +275,9 @@ def test_disc_virtual_ranks_band_frame_matches_single_gpu(device, world):
     """SURVEY §8e for the oriented-disc footprint, without a cluster: every rank's work in turn on the one GPU, the
     all-gather of the 48-byte exchange records is a concat; the stitched rgba8 image must be bit-identical to the
     single-GPU disc frame, and the records those of the oracle."""
+    import os
+    if os.environ.get("SPLAT_FRAME_ORDER") == "sortfirst":
+        pytest.skip("splat_band_frame takes oriented-disc records in the tile-first order of work only (splat.h: an INVALID error otherwise)")
     import torch
     from splat_renderer_amd import dist
     n, w, h = 30001, 400, 232  # odd n: the last shard is padded with NaN records
@@ -321,6 +324,9 @@ def test_disc_virtual_ranks_band_frame_matches_single_gpu(device, world):
 
 def test_disc_frame_pipeline_two_frames_in_flight(device):
     """FramePipeline with the disc footprint (world 1: the exchange is the projection alone): frames stay apart."""
+    import os
+    if os.environ.get("SPLAT_FRAME_ORDER") == "sortfirst":
+        pytest.skip("splat_band_frame takes oriented-disc records in the tile-first order of work only (splat.h: an INVALID error otherwise)")
     import torch
     from splat_renderer_amd import dist
     from splat_renderer_amd.camera import Camera

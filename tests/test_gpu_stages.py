@@ -722,6 +722,9 @@ def test_sync_free_overflow_is_detected_and_recovered(device):
     """A frame whose pairs exceed 1.5x the previous frame's cannot fit its sync-free limit: the
     library reports it at the next call and the host facade renders it again; the final lists and
     image are the oracle's."""
+    import os
+    if os.environ.get("SPLAT_BIN_SYNC") == "1":
+        pytest.skip("SPLAT_BIN_SYNC=1: every frame reads its pair total back before it sizes anything: no frame can overflow")
     n, w, h = 20000, 320, 200
     small, normals, u = make_case(n, w, h, 61, 0.5)
     big = small.copy()
@@ -1114,6 +1117,9 @@ def test_ranking_policies(monkeypatch):
 
 
 def test_tile_first_sync_free_repeat_and_overflow(device):
+    import os
+    if os.environ.get("SPLAT_BIN_SYNC") == "1":
+        pytest.skip("SPLAT_BIN_SYNC=1: every frame reads its pair total back before it sizes anything: no frame can overflow")
     n, w, h = 20000, 320, 200
     small, normals, u = make_case(n, w, h, 61, 0.5)
     big = small.copy()
@@ -1585,6 +1591,9 @@ def test_frame_loop_dolly_in_and_out_sync_free(device):
     sized from the frame before are caught at the next call and rendered again.  Every seventh frame's lists (four
     different camera distances) and the last checked frame's pixels against the oracle; the layout of the first sort pass (runs aligned to the second pass's
     partitions) moves with every frame's digit totals."""
+    import os
+    if os.environ.get("SPLAT_BIN_SYNC") == "1":
+        pytest.skip("SPLAT_BIN_SYNC=1: every frame reads its pair total back before it sizes anything: no frame can overflow")
     n, w, h = 60000, 480, 272
     props, normals, _ = make_case(n, w, h, 77, 1.0)
     pbuf, nbuf = device.createBufferFrom(props), device.createBufferFrom(normals)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# tools/gpu_test_matrix.sh <outdir>: the GPU suite (one process each) under every environment switch of the library that selects
+# another code path, on the box this runs on.  A summary line per switch goes to <outdir>/matrix.txt.
+out=$1; mkdir -p "$out"; : > "$out/matrix.txt"
+run() { # label, env assignments...
+  label=$1; shift
+  log="$out/$(echo "$label" | tr ' =' '__').log"
+  env "$@" timeout -k 10 400 python -m pytest tests -m gpu -q -x > "$log" 2>&1
+  printf '%-34s %s\n' "$label" "$(tail -1 "$log")" >> "$out/matrix.txt"
+}
+run "default" SPLAT_NOOP=1
+run "SPLAT_RANK=ballot" SPLAT_RANK=ballot
+run "SPLAT_FRAME_ORDER=sortfirst" SPLAT_FRAME_ORDER=sortfirst
+run "SPLAT_TILE_SORT_DIGITS=12" SPLAT_TILE_SORT_DIGITS=12
+run "SPLAT_TILE_SORT_CLASSES=1" SPLAT_TILE_SORT_CLASSES=1
+run "SPLAT_COMPOSITE=pixel" SPLAT_COMPOSITE=pixel
+run "SPLAT_COMPOSITE=quadrant" SPLAT_COMPOSITE=quadrant
+run "SPLAT_TILE_ORDER=0" SPLAT_TILE_ORDER=0
+run "SPLAT_PX_AHEAD=2" SPLAT_PX_AHEAD=2
+run "SPLAT_PX_AHEAD=1" SPLAT_PX_AHEAD=1
+run "SPLAT_PX_PREDICT=0" SPLAT_PX_PREDICT=0
+run "SPLAT_PX_SLACK=1" SPLAT_PX_SLACK=1
+run "SPLAT_BAND_COMPACT=1" SPLAT_BAND_COMPACT=1
+run "SPLAT_BAND_COMPACT=0" SPLAT_BAND_COMPACT=0
+run "SPLAT_BAND_RECORDS=lit" SPLAT_BAND_RECORDS=lit
+run "SPLAT_RADIX_MODE=onesweep" SPLAT_RADIX_MODE=onesweep
+run "SPLAT_BIN_SYNC=1" SPLAT_BIN_SYNC=1
+run "SPLAT_RANK=atomic" SPLAT_RANK=atomic
+cat "$out/matrix.txt"
