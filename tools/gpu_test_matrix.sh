@@ -5,7 +5,7 @@ out=$1; mkdir -p "$out"; : > "$out/matrix.txt"
 run() { # label, env assignments...
   label=$1; shift
   log="$out/$(echo "$label" | tr ' =' '__').log"
-  env "$@" timeout -k 10 400 python -m pytest tests -m gpu -q -x > "$log" 2>&1
+  env "$@" timeout -k 10 400 python -m pytest tests -m gpu -q > "$log" 2>&1
   printf '%-34s %s\n' "$label" "$(tail -1 "$log")" >> "$out/matrix.txt"
 }
 run "default" SPLAT_NOOP=1
