@@ -16,6 +16,7 @@
 // implementation's own extra traffic (hit counts, packed ranges, the pair sort's ping-pong) is
 // accounted in DESIGN.md.
 #include "common.h"
+#include <cstring>
 #include "tile_range.h"
 
 #include <chrono>
@@ -548,6 +549,9 @@ int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out) {
         delete b;
         return ctx_fail(ctx, SPLAT_ERR_OOM, "binner allocation");
     }
+    // the report words start at zero: binner_settle waits for word 2 to become the frame's sequence number (from 1 up), and
+    // recycled pinned memory may well hold an earlier binner's "1"
+    memset(b->pinned, 0, 16);
     if (const char *e = getenv("SPLAT_BIN_SYNC")) b->allow_async = !(e[0] == '1');
     *out = b;
     return SPLAT_OK;
