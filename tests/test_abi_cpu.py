@@ -56,6 +56,21 @@ def test_napi_addon_has_one_method_per_abi_entry_point():
         assert set(out.stdout.split()) == wanted
 
 
+def test_no_null_stream_work_in_the_library():
+    """A context's stream is non-blocking: nothing orders it against the null stream, and plain hipMemset / hipMemcpy /
+    hipMemcpy*Symbol return before a device-side fill or copy has run.  One such call cleared a new sorter's workspace until
+    round 4 and raced with the sort that followed (profiles/r04_s_gpu_test_matrix_and_null_stream_memset.txt): every fill and
+    copy in csrc/ names the context's stream."""
+    import glob
+    bad = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "splat_renderer_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "splat_renderer_amd", "csrc", "*.h"))):
+        text = re.sub(r"//[^\n]*", "", open(path).read())
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\bhip(Memset|Memcpy|MemcpyDtoD|MemcpyHtoD|MemcpyDtoH|MemcpyToSymbol|MemcpyFromSymbol|Memset2D|MemsetD32|MemsetD8)\s*\(", text):
+            bad.append((os.path.basename(path), m.group(0)))
+    assert not bad, f"null-stream calls: {bad}"
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

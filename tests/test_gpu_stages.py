@@ -609,6 +609,30 @@ def test_tile_lists_equal_the_reference_own_code(device, name):
     nbuf.destroy()
 
 
+def test_fresh_renderers_first_frames(device):
+    """The FIRST frame of a fresh Renderer (every buffer, sorter and workspace reserved inside that frame), in both orders of
+    work, twenty times over: the fixture's lists every time.  (What the reference-fixture test above does once per run — where,
+    once in three rounds, a workspace fill on the null stream landed after the sort that used the workspace.)"""
+    import os
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, "ref_binsorted_ragged1000.npz"))
+    f = np.load(os.path.join(here, "ragged1000.npz"))
+    w, h, tile = (int(x) for x in g["dims"])
+    n = g["projected"].shape[0]
+    props, nbuf = device.createBufferFrom(f["props"]), device.createBufferFrom(f["normals"])
+    for k in range(20):
+        for order in ("tileFirst", "sortFirst"):
+            r = sr.Renderer(device, None, "rgba8unorm", n, frameOrder=order)
+            r.render(f["uniforms"], props, nbuf, None, w, h)
+            assert r.finish() == g["indices"].shape[0]
+            assert_same(r.binner.getTileCountsBuffer().read(np.uint32), g["counts"], ("fresh renderer", k, order, "counts"))
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, g["indices"].shape[0]), g["indices"], ("fresh renderer", k, order, "lists"),
+                        offsets=g["offsets"])
+            r.destroy()
+    for o in (props, nbuf):
+        o.destroy()
+
+
 def test_scan_equals_the_reference_own_code(device):
     """ref_scan.npz: the loop of PrefixSumScanner.scanCPU (src/PrefixSumScanner.ts:150-155) run under Node."""
     import os
