@@ -622,19 +622,14 @@ __device__ __forceinline__ void px_make_order(const uint32_t *__restrict__ cost,
 //   * both waves execute the same barriers by construction: the consumer's "every pixel has stopped" is latched into
 //     s_done[(k + 1) & 1] BEFORE barrier k + 1 and read by the builder AFTER it — the word the consumer may write while
 //     walking chunk k + 1 is the other one.
-#ifndef PX_PRIO
-#define PX_PRIO 1
-#endif
-#if PX_PRIO
+// a tile that has come this far is one of the long ones the kernel's end waits for: its waves go first (measured worth nothing
+// either way once the tiles are dispatched longest first: profiles/r04_i_px_priority_variants_C2.txt; kept: it costs nothing)
 #define PX_PRIORITY(N)                                         \
     do {                                                       \
         if ((N) == 3u) __builtin_amdgcn_s_setprio(1);          \
         else if ((N) == 6u) __builtin_amdgcn_s_setprio(2);     \
         else if ((N) == 10u) __builtin_amdgcn_s_setprio(3);    \
     } while (0)
-#else
-#define PX_PRIORITY(N) do { } while (0)
-#endif
 // clamp(a b + c, 0, 1) per component in one fused operation (the clamp is the instruction's output modifier).  Packed: with
 // composite.hip compiled WITHOUT the packed f32 instructions (-target-feature -packed-fp32-ops: 42 plain instead of 26 vector
 // instructions per trip) a trip took 435 instead of 387 cycles, 348 instead of 285 for a wave alone on its SIMD
