@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """SPLAT_TEST_SHUFFLE=<seed>: the tests in a seeded random order.  The GPU tests share one context (below): another order is
+    another history of that context — of its buffers' addresses and contents, its learnt sizes, its streams' timing — and a result
+    that depends on any of it is a bug (tools/gpu_test_matrix.sh runs a few seeds; the default order stays the file order)."""
+    seed = os.environ.get("SPLAT_TEST_SHUFFLE")
+    if seed:
+        import random
+        random.Random(int(seed)).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def device():
     """One splat ctx for the whole GPU session (a ctx is one device + one stream)."""

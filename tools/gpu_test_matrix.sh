@@ -26,4 +26,7 @@ run "SPLAT_BAND_RECORDS=lit" SPLAT_BAND_RECORDS=lit
 run "SPLAT_RADIX_MODE=onesweep" SPLAT_RADIX_MODE=onesweep
 run "SPLAT_BIN_SYNC=1" SPLAT_BIN_SYNC=1
 run "SPLAT_RANK=atomic" SPLAT_RANK=atomic
+run "SPLAT_TEST_SHUFFLE=1" SPLAT_TEST_SHUFFLE=1
+run "SPLAT_TEST_SHUFFLE=2" SPLAT_TEST_SHUFFLE=2
+run "SPLAT_TEST_SHUFFLE=3" SPLAT_TEST_SHUFFLE=3
 cat "$out/matrix.txt"
