@@ -1724,6 +1724,35 @@ def test_pipelined_renderer_keeps_frames_identical(device):
         o.destroy()
 
 
+def test_four_contexts_interleaved_keep_their_frames(device):
+    """Four contexts (four non-blocking streams) fed alternately from one thread, nothing waited for in between — each its own
+    scene, screen size and order of work, each rendering several sync-free frames: every image is the one the same context
+    gives alone.  (Distinct contexts are independent by contract; this holds the library to it: no shared scratch, no
+    process-wide state, nothing on the null stream.)"""
+    cases = [(20000, 320, 200, 81, 1.0, "tileFirst"), (9000, 400, 240, 82, 2.0, "sortFirst"), (30000, 256, 256, 83, 0.7, "tileFirst"),
+             (5000, 640, 352, 84, 3.0, "tileFirst")]
+    devs, sets, want = [sr.Device(0) for _ in cases], [], []
+    for d, (n, w, h, seed, rs, order) in zip(devs, cases):
+        props, normals, u = make_case(n, w, h, seed, rs)
+        r = sr.Renderer(d, None, "rgba8unorm", n, frameOrder=order)
+        pb, nb = d.createBufferFrom(props), d.createBufferFrom(normals)
+        r.render(u, pb, nb, None, w, h)
+        want.append(r.readPixels().copy())  # alone (and the frame that sizes the sync-free ones)
+        sets.append((r, u, pb, nb, w, h))
+    for rounds in range(5):
+        for r, u, pb, nb, w, h in sets:  # enqueue all four, twice over, before anything is read
+            r.render(u, pb, nb, None, w, h)
+        for r, u, pb, nb, w, h in reversed(sets):
+            r.render(u, pb, nb, None, w, h)
+        for k, (r, u, pb, nb, w, h) in enumerate(sets):
+            assert_same(r.readPixels(), want[k], ("four contexts", rounds, k))
+    assert len({w_.tobytes() for w_ in want}) == len(want)
+    for (r, u, pb, nb, w, h), d in zip(sets, devs):
+        assert r.framesMisranked == 0
+        for o in (r, pb, nb, d):
+            o.destroy()
+
+
 def test_C4_workload_eight_virtual_ranks_through_the_all_gather_cut(device):
     """BASELINE.json configs[4] — 10M Gaussians @3840x2160 sharded by tile rows over 8 ranks with ONE all-gather of projected
     splats — as far as one GPU can run it: the eight ranks' device work runs in turn on the one device.  Every rank projects
