@@ -51,7 +51,7 @@ constexpr uint32_t TS_THREADS = 256, TS_WAVES = 4;
 //   short  <= 2048 elements:  8 per thread, 16 KiB staged -> seven workgroups per CU
 //   long    > 2048 elements: up to 24 per thread, 46 KiB staged -> three workgroups per CU; beyond 5888
 //           elements the passes go through global memory
-constexpr uint32_t TS_SHORT_ITEMS = 8, TS_LONG_ITEMS = 24;
+constexpr uint32_t TS_SHORT_ITEMS = 8, TS_MIDDLE_ITEMS = 16, TS_LONG_ITEMS = 24; // (the middle class: screens of >= 16384 tiles only)
 constexpr uint32_t TS_LDS_ELEMS = 5888; // 46 KiB + 5 KiB of counters: three workgroups in a CU's 160 KiB
 constexpr uint32_t TS_CHUNK_ITEMS = 16, TS_CHUNK = TS_CHUNK_ITEMS * TS_THREADS;
 
@@ -456,7 +456,7 @@ __device__ __forceinline__ void tile_list_out(uint2 *s_el, uint32_t n, uint32_t 
 }
 
 template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS, bool WIDE>
-__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : (WIDE ? 2 : 3)) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
+__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : TS_MAX_ITEMS <= 16 ? (WIDE ? 2 : 4) : (WIDE ? 2 : 3)) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
                                                                                     uint32_t n_above, uint2 *vals, uint2 *scratch,
                                                                                     uint32_t *__restrict__ out_idx,
                                                                                     uint32_t *__restrict__ counts,
@@ -846,12 +846,16 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
     // a tenth of a C0 frame).
-    // (SPLAT_TILE_SORT_CLASSES=1 / =2 force one launch / two launches: measuring knob, profiles/r03_j_tile_sort_one_launch_C2.txt)
+    // (SPLAT_TILE_SORT_CLASSES=1 / =2 / =3 force one, two or three launches: measuring knob, profiles/r03_j_tile_sort_one_launch_C2.txt)
     static const int force_classes = [] {
         const char *e = getenv("SPLAT_TILE_SORT_CLASSES");
-        return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
+        return (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) ? e[0] - '0' : 0;
     }();
     const bool one_class = force_classes ? force_classes == 1 : tiles <= 3u * 256u;
+    // A screen of very many tiles (4K: 32 400) gains from a MIDDLE class — lists of 2049 .. 4096 elements, 16 per thread, 37 KiB:
+    // four workgroups per CU instead of the long class's three — more than that class's launch costs: C3 194 -> 184 us; at
+    // 1080p (8160 tiles) the launch costs more than it gains: C2 77.0 -> 83.5 us (EXPERIMENTS.md 7.4).
+    const bool three_classes = force_classes ? force_classes == 3 : tiles >= 16384u;
     // SPLAT_TILE_SORT_DIGITS=12: the wide passes (two of up to 12 bits instead of three of 8; built and measured in round 3:
     // slower — 76 + 33 us against 56 + 23 at C2, profiles/r03_f_tile_sort_wide_digits_C2.txt — kept selectable, and tested)
     if (ctx->tile_sort_digits == 0) {
@@ -871,6 +875,10 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     } while (0)
     if (one_class) {
         SPLAT_TILE_SORT(TS_LONG_ITEMS, true, 0u, counts);
+    } else if (three_classes) {
+        SPLAT_TILE_SORT(TS_SHORT_ITEMS, false, 0u, counts);
+        SPLAT_TILE_SORT(TS_MIDDLE_ITEMS, false, short_cap, nullptr);
+        SPLAT_TILE_SORT(TS_LONG_ITEMS, true, TS_MIDDLE_ITEMS * TS_THREADS, nullptr);
     } else {
         SPLAT_TILE_SORT(TS_SHORT_ITEMS, false, 0u, counts);
         SPLAT_TILE_SORT(TS_LONG_ITEMS, true, short_cap, nullptr);
