@@ -430,7 +430,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         // (its first launch also writes the tile counts); every list's order is checked there
         stage_begin(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
-                              b->counts, b->d_total + 1);
+                              b->counts, b->d_total + 1, (uint32_t)(b->total / (tile_row1 > tile_row0 ? (uint64_t)(tile_row1 - tile_row0) * ntx : 1u)));
         stage_end(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;

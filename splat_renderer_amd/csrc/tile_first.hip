@@ -48,10 +48,12 @@ constexpr uint32_t TS_THREADS = 256, TS_WAVES = 4;
 // Two size classes, one launch each over all tiles (a workgroup whose tile belongs to the other class
 // exits at once): the kernel is latency-bound (six barriers per pass, dependent LDS round trips), so
 // what matters is resident workgroups per CU, and most lists are short.
-//   short  <= 2048 elements:  8 per thread, 16 KiB staged -> seven workgroups per CU
-//   long    > 2048 elements: up to 24 per thread, 46 KiB staged -> three workgroups per CU; beyond 5888
-//           elements the passes go through global memory
-constexpr uint32_t TS_SHORT_ITEMS = 8, TS_MIDDLE_ITEMS = 16, TS_LONG_ITEMS = 24; // (the middle class: screens of >= 16384 tiles only)
+//   short  <= 2048 / 3072 / 4096 elements: 8 / 12 / 16 per thread, 16 / 24 / 32 KiB staged -> six / five / four workgroups per
+//           CU.  Which of the three: by the frame's mean list length (tile_sort_launch) — the denser the lists, the more of
+//           them are worth taking out of the long class at the price of fewer resident workgroups in the short one
+//   long    the rest: up to 24 per thread, 46 KiB staged -> three workgroups per CU; beyond 5888 elements the passes go
+//           through global memory
+constexpr uint32_t TS_LONG_ITEMS = 24; // (the short class holds 8, 12 or 16 elements per thread: tile_sort_launch picks per frame)
 constexpr uint32_t TS_LDS_ELEMS = 5888; // 46 KiB + 5 KiB of counters: three workgroups in a CU's 160 KiB
 constexpr uint32_t TS_CHUNK_ITEMS = 16, TS_CHUNK = TS_CHUNK_ITEMS * TS_THREADS;
 
@@ -456,7 +458,7 @@ __device__ __forceinline__ void tile_list_out(uint2 *s_el, uint32_t n, uint32_t 
 }
 
 template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS, bool WIDE>
-__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : TS_MAX_ITEMS <= 16 ? (WIDE ? 2 : 4) : (WIDE ? 2 : 3)) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
+__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : TS_MAX_ITEMS <= 12 ? (WIDE ? 2 : 5) : TS_MAX_ITEMS <= 16 ? (WIDE ? 2 : 4) : (WIDE ? 2 : 3)) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
                                                                                     uint32_t n_above, uint2 *vals, uint2 *scratch,
                                                                                     uint32_t *__restrict__ out_idx,
                                                                                     uint32_t *__restrict__ counts,
@@ -832,13 +834,13 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : TS
     if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
 }
 
+// mean_list: the frame's pairs per tile of its band, as far as the host knows them (the previous frame's in a sync-free frame).
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts, uint32_t *frame_flags) {
+                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list) {
     {
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
     }
-    const uint32_t short_cap = TS_SHORT_ITEMS * TS_THREADS;
     const bool ra = rank_atomic_ok(ctx, true); // (every list is checked below: atomics are allowed here by default)
     const uint32_t inject = ctx->inject_order_fault ? ctx->inject_order_fault - 1u : 0xffffffffu; // one-shot test hook
     const uint32_t inject_pos = ctx->inject_order_position;
@@ -846,16 +848,22 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
     // a tenth of a C0 frame).
-    // (SPLAT_TILE_SORT_CLASSES=1 / =2 / =3 force one, two or three launches: measuring knob, profiles/r03_j_tile_sort_one_launch_C2.txt)
+    // (SPLAT_TILE_SORT_CLASSES=1 / =2 force one launch / two launches: measuring knob, profiles/r03_j_tile_sort_one_launch_C2.txt)
     static const int force_classes = [] {
         const char *e = getenv("SPLAT_TILE_SORT_CLASSES");
-        return (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) ? e[0] - '0' : 0;
+        return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
     }();
     const bool one_class = force_classes ? force_classes == 1 : tiles <= 3u * 256u;
-    // A screen of very many tiles (4K: 32 400) gains from a MIDDLE class — lists of 2049 .. 4096 elements, 16 per thread, 37 KiB:
-    // four workgroups per CU instead of the long class's three — more than that class's launch costs: C3 194 -> 184 us; at
-    // 1080p (8160 tiles) the launch costs more than it gains: C2 77.0 -> 83.5 us (EXPERIMENTS.md 7.4).
-    const bool three_classes = force_classes ? force_classes == 3 : tiles >= 16384u;
+    // The short class's size, by the frame's mean list length (measured, `bin_tile_sort` with 8 | 12 | 16 elements per thread:
+    // C1, mean 570: 45.6 | 41.4 | 45.9 us; C3, mean 910: 193 | 180 | 188; C2, mean 1380: 77.0 | 76.6 | 72.9 — and a third
+    // class in between loses its launch: profiles/r04_u_tile_sort_classes.txt).  SPLAT_TILE_SORT_SHORT=8 | 12 | 16 forces one.
+    static const uint32_t force_short = [] {
+        const char *e = getenv("SPLAT_TILE_SORT_SHORT");
+        const int v = e ? atoi(e) : 0;
+        return (v == 8 || v == 12 || v == 16) ? (uint32_t)v : 0u;
+    }();
+    const uint32_t short_items = force_short ? force_short : mean_list < 320u ? 8u : mean_list < 1152u ? 12u : 16u;
+    const uint32_t short_cap = short_items * TS_THREADS;
     // SPLAT_TILE_SORT_DIGITS=12: the wide passes (two of up to 12 bits instead of three of 8; built and measured in round 3:
     // slower — 76 + 33 us against 56 + 23 at C2, profiles/r03_f_tile_sort_wide_digits_C2.txt — kept selectable, and tested)
     if (ctx->tile_sort_digits == 0) {
@@ -875,12 +883,10 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     } while (0)
     if (one_class) {
         SPLAT_TILE_SORT(TS_LONG_ITEMS, true, 0u, counts);
-    } else if (three_classes) {
-        SPLAT_TILE_SORT(TS_SHORT_ITEMS, false, 0u, counts);
-        SPLAT_TILE_SORT(TS_MIDDLE_ITEMS, false, short_cap, nullptr);
-        SPLAT_TILE_SORT(TS_LONG_ITEMS, true, TS_MIDDLE_ITEMS * TS_THREADS, nullptr);
     } else {
-        SPLAT_TILE_SORT(TS_SHORT_ITEMS, false, 0u, counts);
+        if (short_items == 8u) SPLAT_TILE_SORT(8, false, 0u, counts);
+        else if (short_items == 12u) SPLAT_TILE_SORT(12, false, 0u, counts);
+        else SPLAT_TILE_SORT(16, false, 0u, counts);
         SPLAT_TILE_SORT(TS_LONG_ITEMS, true, short_cap, nullptr);
     }
 #undef SPLAT_TILE_SORT_

@@ -13,7 +13,9 @@ run "SPLAT_RANK=ballot" SPLAT_RANK=ballot
 run "SPLAT_FRAME_ORDER=sortfirst" SPLAT_FRAME_ORDER=sortfirst
 run "SPLAT_TILE_SORT_DIGITS=12" SPLAT_TILE_SORT_DIGITS=12
 run "SPLAT_TILE_SORT_CLASSES=1" SPLAT_TILE_SORT_CLASSES=1
-run "SPLAT_TILE_SORT_CLASSES=3" SPLAT_TILE_SORT_CLASSES=3
+run "SPLAT_TILE_SORT_SHORT=8" SPLAT_TILE_SORT_SHORT=8
+run "SPLAT_TILE_SORT_SHORT=12" SPLAT_TILE_SORT_SHORT=12
+run "SPLAT_TILE_SORT_SHORT=16" SPLAT_TILE_SORT_SHORT=16
 run "SPLAT_COMPOSITE=pixel" SPLAT_COMPOSITE=pixel
 run "SPLAT_COMPOSITE=quadrant" SPLAT_COMPOSITE=quadrant
 run "SPLAT_TILE_ORDER=0" SPLAT_TILE_ORDER=0
