@@ -428,9 +428,13 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         if (rc != SPLAT_OK) return rc;
         // PerTileSorter: depth order inside every tile; the index lists land in the primary payload array
         // (its first launch also writes the tile counts); every list's order is checked there
+        // (the frame's mean list length picks the short class's size — on a band of a few thousand tiles, a multi-GPU rank's,
+        //  every class is one round of workgroups and the smallest short class is the fastest: measured at G = 2, 4, 8,
+        //  profiles/r04_u_tile_sort_classes.txt)
+        const uint32_t band_tiles = tile_row1 > tile_row0 ? (tile_row1 - tile_row0) * ntx : 1u;
         stage_begin(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
-                              b->counts, b->d_total + 1, (uint32_t)(b->total / (tile_row1 > tile_row0 ? (uint64_t)(tile_row1 - tile_row0) * ntx : 1u)));
+                              b->counts, b->d_total + 1, band_tiles >= 6144u ? (uint32_t)(b->total / band_tiles) : 0u);
         stage_end(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
