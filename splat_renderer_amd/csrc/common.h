@@ -207,7 +207,10 @@ struct BinParams {
 // Splats per block of the tile-first binner's first pass: 1024, or 256 for small frames — a 10 000-splat frame in
 // 1024-splat blocks is a ten-workgroup kernel expanding 14 pairs per splat in four rounds on an otherwise idle device
 // (64 of that frame's 120 us).
-constexpr uint32_t TF_BLOCK_LARGE = 1024, TF_BLOCK_SMALL = 256, TF_SMALL_FRAME_SPLATS = 131072;
+// (frames of up to 2^20 splats: 256-splat blocks — at C1, 1 M splats with 4.6 pairs each, a 1024-splat block holds more pairs than
+//  the scatter stages in one round, and 977 blocks are less than one round of workgroups: 0.1554 -> 0.1515 ms per frame; at C2, 5 M
+//  splats, the scatter's 19 500 small blocks cost it 78 instead of 48 us: profiles/r04_v_first_pass_block_size.txt)
+constexpr uint32_t TF_BLOCK_LARGE = 1024, TF_BLOCK_SMALL = 256, TF_SMALL_FRAME_SPLATS = 1u << 20;
 // Where the frame path's projector leaves the first sort pass's histogram (tile_first.hip): per
 // block of splats the pairs per low tile-id digit (digit-major, num_parts columns) and in total.
 struct TfHistOut {

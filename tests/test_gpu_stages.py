@@ -582,7 +582,7 @@ def test_tile_lists_equal_the_reference_own_code(device, name):
     # offsets that name the tile, and which ranking / block size this process used)
     keys = O.extract_keys(g["projected"])[0]
     info = {"SPLAT_RANK": os.environ.get("SPLAT_RANK", "(library default)"), "n": n, "tiles": int(g["counts"].shape[0]),
-            "first_pass_block": 256 if n <= 131072 else 1024}
+            "first_pass_block": 256 if n <= (1 << 20) else 1024}
     b = sr.GPUTileBinner(device, tile)
     b.binSplats(None, pbuf, sbuf, n, w, h, numSorted=g["sorted"].shape[0])
     assert_same(b.getTileCountsBuffer().read(np.uint32), g["counts"], (name, "staged binner", "counts"), extra=info)
