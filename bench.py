@@ -281,6 +281,10 @@ def main():
                          "traces of the timed frames alone — frames in flight on two streams overlap, which inflates every kernel's duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--band-path", action="store_true", default=os.environ.get("SPLAT_BENCH_BAND_PATH", "0") == "1",
+                    help="run the N > 1 code path (slice projection, the all-gather through the communicator, band frame, the exchange's "
+                         "self-checks) whatever WORLD_SIZE is: with one rank the band is the whole screen and the all-gather a one-rank "
+                         "collective.  A rehearsal of run_multi on one GPU (VERDICT r4 item 1), not the N = 1 headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -301,7 +305,7 @@ def main():
     u = cam.uniforms(width, height)
     workload = f"{name}: {n} synthetic Gaussians @{width}x{height}, {tile}x{tile} tiles"
 
-    if world == 1:  # one GPU is one GPU, launched through torchrun or not (the band path is for N > 1)
+    if world == 1 and not args.band_path:  # one GPU is one GPU, launched through torchrun or not (the band path is for N > 1)
         result = run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload)
     else:
         result = run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world)
@@ -541,6 +545,12 @@ def run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, w
 def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, workload, rank, local_rank, world):
     import torch
     import torch.distributed as td
+    if world == 1 and "MASTER_ADDR" not in os.environ:  # --band-path without a launcher: a one-rank group of our own
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     torch.cuda.set_device(local_rank)
     if not td.is_initialized():
         td.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -559,7 +569,7 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
             collective = "splat_allgather_records (the C ABI's own RCCL communicator)"
         except Exception as e:  # (RCCL could not be bound in this process: every rank fails alike, before any collective)
             print(f"[rank {rank}] C-ABI communicator unavailable ({e!r}); torch.distributed issues the all-gather", file=sys.stderr)
-    br = dist.BandRenderer(stages, n, width, height, rank, world, gather, tile)
+    br = dist.BandRenderer(stages, n, width, height, rank, world, gather, tile, always_gather=args.band_path)
     if args.layout == "planes":  # as at N=1: shading applied once per property update, not per staged list entry
         stages.set_lit(pt.data_ptr(), nt.data_ptr(), n)
 
@@ -682,7 +692,7 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
     # every other rank's gathered shard against this rank's own projection of that slice, bit for bit
     rccl_view = gather.rccl_view() if hasattr(gather, "rccl_view") else (td.get_world_size(), td.get_rank())
     br.render(u, pt.data_ptr(), nt.data_ptr(), settle=True)
-    verified = br.verify_exchange(u, pt.data_ptr(), nt.data_ptr())
+    verified = br.verify_exchange(u, pt.data_ptr(), nt.data_ptr(), include_self=args.band_path)
     r0, r1 = br.pixel_rows()
     kept = n if local is not None else stages.kept  # (no band filter without an exchange: every rank bins from all n splats)
     info = torch.tensor([kept, br.row0, br.row1, int(p_used), int(comp_ms * 1e6), rccl_view[0], rccl_view[1], verified,
@@ -722,7 +732,7 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                                 "bytes_contributed_per_rank": per * stages.rec_floats * 4,
                                 "bytes_received_per_rank": (world - 1) * per * stages.rec_floats * 4,
                                 "rccl_ranks_seen": [i[5] for i in infos], "rccl_rank_of_each_process": [i[6] for i in infos],
-                                "shards_verified_per_rank": [i[7] for i in infos], "shards_expected_per_rank": world - 1,
+                                "shards_verified_per_rank": [i[7] for i in infos], "shards_expected_per_rank": world - 1 + int(args.band_path),
                                 "verification": "after the timed region every rank re-projected every other rank's slice from its own copy of "
                                                 "the splats and compared it bit for bit with the block the all-gather delivered",
                                 "in_timed_region": local is None},
@@ -734,6 +744,9 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                      "avg_launch_ms": infos[slow][4] / 1e6, "rank": slow},
         "cpu_baseline": None,  # reported at N=1 only
     }
+    if args.band_path:
+        result["config"]["band_path"] = ("--band-path: run_multi's code path (slice projection, all-gather through the communicator, band "
+                                         "frame, self-checks) with WORLD_SIZE " + str(world) + "; not the N = 1 headline (run_single)")
     td.barrier()
     if pipe is not None:
         pipe.destroy()

@@ -309,9 +309,11 @@ class BandRenderer:
     """One rank of a multi-GPU frame.  `all_gather(out, shard)` is AbiAllGather (the C ABI's RCCL communicator) or
     torch.distributed.all_gather_into_tensor (RCCL on GPUs; gloo in the CPU tests)."""
 
-    def __init__(self, stages, n, width, height, rank, world, all_gather, tile=TILE, gathered=None):
+    def __init__(self, stages, n, width, height, rank, world, all_gather, tile=TILE, gathered=None, always_gather=False):
         # gathered: a records tensor to gather into instead of one of this renderer's own (virtual ranks on one device share it)
+        # always_gather: issue the collective with one rank too (bench.py --band-path: the N > 1 path rehearsed on one GPU)
         self.stages, self.n, self.rank, self.world = stages, n, rank, world
+        self.exchanging = world > 1 or always_gather
         self.width, self.height, self.tile = width, height, tile
         self.per = shard_size(n, world)
         self.first, self.count = slice_range(n, rank, world)
@@ -320,13 +322,13 @@ class BandRenderer:
         self.all_gather = all_gather
         # shard padding (indices >= n) is all-NaN once: NaN bins nowhere and never changes
         self.shard = stages.new_records(self.per, fill_nan=True)
-        self.gathered = gathered if gathered is not None else stages.new_records(self.per * world) if world > 1 else self.shard
+        self.gathered = gathered if gathered is not None else stages.new_records(self.per * world) if self.exchanging else self.shard
         self.image = stages.new_image()
 
     def render(self, uniforms, props_ptr, normals_ptr, settle=False):
         st = self.stages
         st.project_slice(uniforms, props_ptr, self.first, self.count, self.shard, normals_ptr)
-        if self.world > 1:
+        if self.exchanging:
             self.all_gather(self.gathered, self.shard)
         if settle:
             st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image, True)
@@ -334,16 +336,17 @@ class BandRenderer:
             st.band_frame(self.gathered, self.per * self.world, props_ptr, normals_ptr, self.row0, self.row1, self.image)
         return self.image
 
-    def verify_exchange(self, uniforms, props_ptr, normals_ptr=None):
+    def verify_exchange(self, uniforms, props_ptr, normals_ptr=None, include_self=False):
         """Self-check of the frame's exchange (every rank holds all splats, so it can recompute any shard): projects each
         OTHER rank's slice locally and compares it, bit for bit, with the block that rank contributed to the last
-        all-gather (render() with the same uniforms first).  Returns the number of other ranks whose block matched."""
+        all-gather (render() with the same uniforms first).  Returns the number of other ranks whose block matched.
+        include_self: this rank's own block too (a one-rank rehearsal has no other)."""
         st, torch = self.stages, self.stages.torch
         tmp = st.new_records(self.per, fill_nan=True)
         rec = self.gathered.reshape(self.world, self.per, -1)
         ok = 0
         for r in range(self.world):
-            if r == self.rank:
+            if r == self.rank and not include_self:
                 continue
             first, count = slice_range(self.n, r, self.world)
             st.project_slice(uniforms, props_ptr, first, count, tmp, normals_ptr)
@@ -422,7 +425,7 @@ class FramePipeline:
             br.all_gather.register(self.comm, self.proj.ctx)
         st = br.stages
         self.shards = [br.shard, st.new_records(br.per, fill_nan=True)]
-        self.gathered = [br.gathered, st.new_records(br.per * br.world) if br.world > 1 else self.shards[1]]
+        self.gathered = [br.gathered, st.new_records(br.per * br.world) if br.exchanging else self.shards[1]]
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
         self.free = [torch.cuda.Event(), torch.cuda.Event()]
         self.used = [False, False]
@@ -434,7 +437,7 @@ class FramePipeline:
             if self.used[s]:
                 self.comm.wait_event(self.free[s])  # the band frame that read this pair has finished
             self.proj.project_slice(uniforms, props_ptr, br.first, br.count, self.shards[s], normals_ptr)
-            if br.world > 1:
+            if br.exchanging:
                 br.all_gather(self.gathered[s], self.shards[s])
             self.ready[s].record(self.comm)
 
