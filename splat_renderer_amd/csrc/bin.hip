@@ -536,6 +536,18 @@ int binner_settle(splat_binner *b) {
 
 extern "C" {
 
+// EXPERIMENT HOOK (tools/overlap_probe.py): the per-tile sort of the binner's last tile-first frame once more, on `ctx`'s stream
+// (any context of the device), from the second pass's output as it stands.  Timing only: tiles beyond the LDS path's size
+// were sorted through both pair arrays and are sorted again from whatever that left.
+int splat_debug_rerun_tile_sort(splat_ctx *ctx, splat_binner *b) {
+    if (!ctx || !b) return ctx_fail(ctx, SPLAT_ERR_INVALID, "ctx/binner is NULL");
+    ARG_CHECK(ctx, b->ran && b->wide_a && b->wide_b && b->ntx && b->nty);
+    const uint32_t tiles = b->ntx * b->nty;
+    const bool primary = tile_id_bits(tiles) - tile_id_low_bits(tiles) == 0;
+    return tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload_b,
+                            nullptr, b->d_total + 3, tiles >= 6144u ? (uint32_t)(b->total / tiles) : 0u);
+}
+
 int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, out != nullptr);

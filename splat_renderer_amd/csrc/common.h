@@ -217,7 +217,19 @@ struct TfHistOut {
     uint32_t *hist, *blocksums, *overflow_flag;
     uint32_t mask, num_parts;
     uint32_t block = TF_BLOCK_LARGE; // splats per block
+    uint32_t xcd_per = 0;            // (set by project_launch: xcd_block_of's second argument)
 };
+// Which logical block (partition, 1024-splat block) workgroup i of a grid takes.  xcd_per == 0: block i.  Otherwise (xcd_per =
+// ceil(blocks / 8), grid = 8 * xcd_per): the hardware deals consecutive workgroups to the eight XCDs in turn, so workgroup i
+// runs on XCD i % 8; it takes block (i % 8) * xcd_per + i / 8 — each XCD's L2 then sees a CONTIGUOUS eighth of the blocks:
+// the 4-byte column entries that neighbouring blocks write into one histogram row, the 128-byte lines of the scanned rows they
+// read back, and the neighbouring fragments of one digit run in a pass's output (16 pairs = 128 bytes per partition and digit
+// at C3) are merged / fetched once in one L2 instead of partially in eight (C3: k_tf_upsweep2 33.6 -> 19.8 us,
+// k_tf_downsweep2 158.9 -> 147.4; nothing either way at C2: profiles/r05_b_second_pass_xcd_C3_C2.txt).  A block past the
+// last one is skipped by the caller.
+__device__ __forceinline__ uint32_t xcd_block_of(uint32_t i, uint32_t xcd_per) {
+    return xcd_per ? (i & 7u) * xcd_per + (i >> 3) : i;
+}
 // tile-id bits and their split over the two sort passes (13 bits -> 6 + 7: longer digit runs than 8 + 5)
 static inline uint32_t tile_id_bits(uint32_t tiles) {
     uint32_t bits = 1;

@@ -247,23 +247,25 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
     __shared__ uint32_t lh[4][256];
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const uint32_t blk = xcd_block_of(blockIdx.x, ho.xcd_per); // (blocks past the grid's last: nothing to project, no key to pad)
+    if (blk * (PER * 256u) >= n_padded) return;
     SplatIn in[PER]; // (unrolled: a splat's registers are live from its load to its last use only)
 #pragma unroll
     for (uint32_t k = 0; k < AHEAD; ++k) { // AHEAD splats' loads in flight before the first dependent instruction
-        const uint32_t i = blockIdx.x * (PER * 256u) + k * 256u + tid;
+        const uint32_t i = blk * (PER * 256u) + k * 256u + tid;
         if (i < n) in[k] = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
     }
-    if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
+    if (blk == 0 && tid == 0) *ho.overflow_flag = 0;
     for (uint32_t j = tid; j < 4 * 256; j += 256) (&lh[0][0])[j] = 0;
     __syncthreads();
     uint32_t local = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) { // (PER * 256 splats per workgroup: the binner's block)
         if (k + AHEAD < PER) { // ... and AHEAD of them in flight from then on
-            const uint32_t i = blockIdx.x * (PER * 256u) + (k + AHEAD) * 256u + tid;
+            const uint32_t i = blk * (PER * 256u) + (k + AHEAD) * 256u + tid;
             if (i < n) in[k + AHEAD] = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
         }
-        const uint32_t i = blockIdx.x * (PER * 256u) + k * 256u + tid;
+        const uint32_t i = blk * (PER * 256u) + k * 256u + tid;
         if (i >= n) {
             if (i < n_padded) keys[i] = 0xffffffffu;
             continue;
@@ -277,9 +279,9 @@ __global__ __launch_bounds__(256) void k_project_hist(FrameUniforms u, const flo
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
     if ((tid & 63) == 0) wsum[w] = local;
     __syncthreads();
-    if (blockIdx.x < ho.num_parts) { // (blocks that only pad keys past n have no histogram column)
-        if (tid <= ho.mask) ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
-        if (tid == 0) ho.blocksums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (blk < ho.num_parts) { // (blocks that only pad keys past n have no histogram column)
+        if (tid <= ho.mask) ho.hist[(size_t)tid * ho.num_parts + blk] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+        if (tid == 0) ho.blocksums[blk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
@@ -425,12 +427,16 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
                        (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio)
 #define SPLAT_PROJECT_HIST_LAUNCH_PER(D, L)                                                                                                \
     do {                                                                                                                                   \
+        TfHistOut ho_ = *hist_out;                                                                                                         \
+        const uint32_t blocks_ = div_up(work, hist_out->block == TF_BLOCK_SMALL ? 256u : 1024u);                                           \
+        ho_.xcd_per = blocks_ >= 64u ? div_up(blocks_, 8u) : 0u; /* the blocks dealt as k_tf_scatter's are (common.h: xcd_block_of) */      \
+        const dim3 grid_(ho_.xcd_per ? 8u * ho_.xcd_per : blocks_);                                                                        \
         if (hist_out->block == TF_BLOCK_SMALL)                                                                                             \
-            hipLaunchKernelGGL((k_project_hist<D, L, 1>), dim3(div_up(work, 256)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, \
-                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio);                                  \
+            hipLaunchKernelGGL((k_project_hist<D, L, 1>), grid_, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,               \
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, ho_, dio, lio);                                        \
         else                                                                                                                               \
-            hipLaunchKernelGGL((k_project_hist<D, L, 4>), dim3(div_up(work, 1024)), block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded, \
-                               (float4 *)projected, (uint32_t *)keys, range32, *bp, *hist_out, dio, lio);                                  \
+            hipLaunchKernelGGL((k_project_hist<D, L, 4>), grid_, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,               \
+                               (float4 *)projected, (uint32_t *)keys, range32, *bp, ho_, dio, lio);                                        \
     } while (0)
     if (hist_out && keys && range32 && !payload && index_base == 0) {
         // (a strict band's kernel works in 1024-splat blocks only: the caller keeps hist_out->block at TF_BLOCK_LARGE for it)

@@ -70,13 +70,15 @@ template <bool IN_PAIRS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__restrict__ keys, uint32_t n_host,
                                                               const uint32_t *__restrict__ n_dev, uint32_t shift,
                                                               uint32_t mask, uint32_t num_parts, uint32_t part_keys,
-                                                              uint32_t *__restrict__ hist) {
+                                                              uint32_t *__restrict__ hist, uint32_t xcd_per) {
     __shared__ uint32_t lh[RS_WAVES][256]; // one private histogram per wave: fewer same-bank collisions
     const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const uint32_t part = xcd_block_of(blockIdx.x, xcd_per); // (each XCD takes a contiguous eighth of the partitions: common.h)
+    if (part >= num_parts) return;
     const uint32_t n = sort_count(n_host, n_dev);
-    const uint32_t base = blockIdx.x * part_keys; // multiple of 256 keys = 1 KiB: uint4 loads stay aligned
+    const uint32_t base = part * part_keys; // multiple of 256 keys = 1 KiB: uint4 loads stay aligned
     if (base >= n) { // partition past the end (device-side n): an all-zero column
-        if (tid <= mask) hist[(size_t)tid * num_parts + blockIdx.x] = 0;
+        if (tid <= mask) hist[(size_t)tid * num_parts + part] = 0;
         return;
     }
     for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&lh[0][0])[i] = 0;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(const uint32_t *__
     }
     __syncthreads();
     // (rows above the mask are never read: a 4-byte store per row is a 64-byte line at the memory side)
-    if (tid <= mask) hist[(size_t)tid * num_parts + blockIdx.x] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+    if (tid <= mask) hist[(size_t)tid * num_parts + part] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,17 +407,19 @@ template <uint32_t ITEMS, bool RANK_ATOMIC, bool IN_PAIRS, bool OUT_PAIRS>
 __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ pay_out, uint32_t n_host, const uint32_t *__restrict__ n_dev, uint32_t shift, uint32_t mask,
-    uint32_t num_parts, const uint32_t *__restrict__ scanned_hist, const uint32_t *__restrict__ totals) {
+    uint32_t num_parts, const uint32_t *__restrict__ scanned_hist, const uint32_t *__restrict__ totals, uint32_t xcd_per) {
     __shared__ DownsweepShared sh;
     __shared__ uint2 s_kp[ITEMS * RS_THREADS]; // (key, payload) reordered by digit
+    const uint32_t part = xcd_block_of(blockIdx.x, xcd_per);
+    if (part >= num_parts) return;
     const uint32_t n = sort_count(n_host, n_dev);
-    if (blockIdx.x * ITEMS * RS_THREADS >= n) return; // partition past the end (device-side n)
+    if (part * ITEMS * RS_THREADS >= n) return; // partition past the end (device-side n)
     // every partition but (possibly) the last is full: it takes the path with no per-key bounds checks
-    if ((blockIdx.x + 1) * ITEMS * RS_THREADS <= n)
-        downsweep_body<ITEMS, true, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+    if ((part + 1) * ITEMS * RS_THREADS <= n)
+        downsweep_body<ITEMS, true, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                            scanned_hist, totals, nullptr, nullptr);
     else
-        downsweep_body<ITEMS, false, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, blockIdx.x, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+        downsweep_body<ITEMS, false, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
                                             scanned_hist, totals, nullptr, nullptr);
 }
 
@@ -519,17 +523,19 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
     uint32_t npasses = 0;
     for (uint32_t sh = bit_begin, w = first_bits; sh < bit_end; sh += w, w = 8) ++npasses;
     uint32_t shift = bit_begin;
+    const uint32_t xcd_per = parts >= 64u ? div_up(parts, 8u) : 0u;
+    const uint32_t grid_parts = xcd_per ? 8u * xcd_per : parts;
     for (uint32_t pass = 0; pass < npasses; ++pass) {
         const uint32_t want = pass == 0 ? first_bits : 8u;
         const uint32_t bits = bit_end - shift < want ? bit_end - shift : want;
         const uint32_t mask = (1u << bits) - 1u;
         const bool in_pairs = can_pair && pass > 0, out_pairs = can_pair && pass + 1 < npasses;
         if (in_pairs)
-            hipLaunchKernelGGL(k_radix_upsweep<true>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
-                               RS_PART_KEYS, hist);
+            hipLaunchKernelGGL(k_radix_upsweep<true>, dim3(grid_parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
+                               RS_PART_KEYS, hist, xcd_per);
         else
-            hipLaunchKernelGGL(k_radix_upsweep<false>, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
-                               RS_PART_KEYS, hist);
+            hipLaunchKernelGGL(k_radix_upsweep<false>, dim3(grid_parts), dim3(RS_THREADS), 0, ctx->stream, ki, n, n_dev, shift, mask, parts,
+                               RS_PART_KEYS, hist, xcd_per);
         LAUNCH_CHECK(ctx, "k_radix_upsweep");
         uint32_t *totals = hist + (size_t)256 * parts;
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, totals, mask + 1);
@@ -538,8 +544,8 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
         // synthesises it instead of reading 4 B per key that the projector would have had to write
         const uint32_t *pin = (iota_payload && pass == 0) ? nullptr : pi;
 #define SPLAT_DS(RA, IP, OP)                                                                                                   \
-    hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, RA, IP, OP>), dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n, \
-                       n_dev, shift, mask, parts, hist, totals)
+    hipLaunchKernelGGL((k_radix_downsweep<RS_ITEMS, RA, IP, OP>), dim3(grid_parts), dim3(RS_THREADS), 0, ctx->stream, ki, pin, ko, po, n, \
+                       n_dev, shift, mask, parts, hist, totals, xcd_per)
         if (rank_atomic) {
             if (in_pairs && out_pairs) SPLAT_DS(true, true, true);
             else if (in_pairs) SPLAT_DS(true, true, false);

@@ -195,17 +195,19 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
                                                            uint32_t lo_bits, uint32_t align_m1, TfRuns runs,
                                                            uint32_t *__restrict__ offsets_out, uint32_t tiles, uint32_t *report,
                                                            uint32_t seq, const uint32_t *__restrict__ cidx,
-                                                           const uint32_t *__restrict__ kept) {
+                                                           const uint32_t *__restrict__ kept, uint32_t xcd_per) {
     static_assert(!COMPACTED || TF_PER_THREAD == 4, "compacted groups are read four splats per thread");
+    const uint32_t blk = xcd_block_of(blockIdx.x, xcd_per); // this workgroup's block of splats = its histogram column
+    if (blk >= num_parts) return;
     __shared__ TfScatterShared sh;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t stage[TF_STAGE]; // tile id << 10 | block-local slot
     __shared__ uint32_t s_key[TF_THREADS * TF_PER_THREAD];
     __shared__ uint32_t s_idx[COMPACTED ? TF_THREADS * TF_PER_THREAD : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint32_t first = blockIdx.x * (COMPACTED ? TF_GROUP : TF_THREADS * TF_PER_THREAD);
+    uint32_t first = blk * (COMPACTED ? TF_GROUP : TF_THREADS * TF_PER_THREAD);
     // (COMPACTED: n = this group's kept splats end at first + kept[group]; the loads below stop there)
-    if (COMPACTED) n = first + min(kept[blockIdx.x], TF_GROUP);
+    if (COMPACTED) n = first + min(kept[blk], TF_GROUP);
     // every global load of the prologue is issued before anything waits on one: the block's ranges and
     // keys, the digit totals, and this block's row of scanned histogram (measured per phase, a workgroup
     // spent 15 % of its life on the totals alone when they were loaded, scanned and waited for first)
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
         if (i0 + 2 < n) { rr.z = range32[i0 + 2]; kk.z = depth_keys[i0 + 2]; }
     }
     const uint32_t digit_total = totals[tid];
-    const uint32_t row_prefix = tid <= mask ? scanned_hist[(size_t)tid * num_parts + blockIdx.x] : 0u;
+    const uint32_t row_prefix = tid <= mask ? scanned_hist[(size_t)tid * num_parts + blk] : 0u;
 
     // digit starts = exclusive scan of the digit totals, each rounded up to whole partitions of the second pass when
     // there is one (align_m1 = TF2_PART - 1: every partition then holds pairs of ONE low digit, see k_tf_downsweep2);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
     const unsigned long long all_pairs64 = wsum64[0] + wsum64[1] + wsum64[2] + wsum64[3];
     const uint32_t all_pairs = all_pairs64 > 0xffffffffull ? 0xffffffffu : (uint32_t)all_pairs64; // saturated: it can only fail `fits`
     const uint32_t run_start = aprefix + aincl - digit_room; // where digit tid's pairs start in the output
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
         const bool fits = all_pairs <= pair_limit;
         if (tid == 0) {
             d_total[0] = all_pairs;
@@ -919,9 +921,10 @@ __device__ __forceinline__ uint32_t tf2_valid(const TfRuns &runs, uint32_t p) {
 }
 
 __global__ __launch_bounds__(TF_THREADS) void k_tf_upsweep2(const uint8_t *__restrict__ hi, TfRuns runs, uint32_t hmask,
-                                                           uint32_t num_parts, uint32_t *__restrict__ hist) {
+                                                           uint32_t num_parts, uint32_t *__restrict__ hist, uint32_t xcd_per) {
     __shared__ uint32_t lh[TS_WAVES][256];
-    const uint32_t tid = threadIdx.x, w = tid >> 6, p = blockIdx.x;
+    const uint32_t tid = threadIdx.x, w = tid >> 6, p = xcd_block_of(blockIdx.x, xcd_per);
+    if (p >= num_parts) return;
     const uint32_t valid = tf2_valid(runs, p);
     if (valid == 0) { // (uniform) a column of zeros: the row scans run over all num_parts columns
         if (tid <= hmask) hist[(size_t)tid * num_parts + p] = 0;
@@ -953,8 +956,9 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_upsweep2(const uint8_t *__res
     if (tid <= hmask) hist[(size_t)tid * num_parts + p] = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
 }
 
+template <uint32_t NW>
 struct TfDownsweepShared {
-    uint32_t wave_hist[TS_WAVES][256];
+    uint32_t wave_hist[NW][256];
     uint32_t global_base[256]; // (where this partition's pairs of each digit start in the output) - (their local start)
     uint32_t wave_sums[TS_WAVES], wave_gsums[TS_WAVES];
 };
@@ -968,10 +972,12 @@ struct TfOffsetsArgs {
     uint32_t *offsets;
     const uint32_t *d_total;
 };
+// (the first 256 threads of the workgroup: one per digit / per tile of the block)
 __device__ __forceinline__ void tf_offsets_block(uint32_t block, const TfOffsetsArgs &o, const TfRuns &runs, uint32_t num_parts,
                                                  const uint32_t *__restrict__ scanned, const uint32_t *__restrict__ totals, uint32_t *hstart,
                                                  uint32_t *wsums) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid >= 256u) return; // (whole waves: the barriers below count the waves that are left)
     const uint32_t t = block * 256u + tid;
     const uint32_t total = o.d_total[2];
     // start of every high digit's run in the sorted order: exclusive scan of the second pass's digit totals
@@ -996,33 +1002,39 @@ __device__ __forceinline__ void tf_offsets_block(uint32_t block, const TfOffsets
     o.offsets[t] = hstart[h] + (first_part < num_parts ? scanned[(size_t)h * num_parts + first_part] : totals[h]);
 }
 
-template <bool RANK_ATOMIC>
-__global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *__restrict__ hi_in, const uint2 *__restrict__ val_in,
-                                                                uint2 *__restrict__ val_out, TfRuns runs, uint32_t hmask,
-                                                                uint32_t num_parts, const uint32_t *__restrict__ scanned,
-                                                                const uint32_t *__restrict__ totals, TfOffsetsArgs off) {
-    __shared__ TfDownsweepShared sh;
+// NW waves per workgroup (4: sixteen pairs per thread; 8: eight)
+template <bool RANK_ATOMIC, uint32_t NW>
+__global__ __launch_bounds__(NW * 64, 3) void k_tf_downsweep2(const uint8_t *__restrict__ hi_in, const uint2 *__restrict__ val_in,
+                                                              uint2 *__restrict__ val_out, TfRuns runs, uint32_t hmask,
+                                                              uint32_t num_parts, const uint32_t *__restrict__ scanned,
+                                                              const uint32_t *__restrict__ totals, TfOffsetsArgs off, uint32_t part_blocks,
+                                                              uint32_t xcd_per) {
+    constexpr uint32_t THREADS = NW * 64, ITEMS = TF2_PART / THREADS;
+    __shared__ TfDownsweepShared<NW> sh;
     __shared__ uint2 s_val[TF2_PART];
     __shared__ uint8_t s_dig[TF2_PART];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6, p = blockIdx.x;
-    if (p >= num_parts) { // (uniform) not a partition: a block of 256 tile offsets
-        tf_offsets_block(p - num_parts, off, runs, num_parts, scanned, totals, sh.global_base, sh.wave_sums);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (blockIdx.x >= part_blocks) { // (uniform) not a partition: a block of 256 tile offsets
+        tf_offsets_block(blockIdx.x - part_blocks, off, runs, num_parts, scanned, totals, sh.global_base, sh.wave_sums);
         return;
     }
+    const uint32_t p = xcd_block_of(blockIdx.x, xcd_per);
+    if (p >= num_parts) return;
     const uint32_t valid = tf2_valid(runs, p);
     if (valid == 0) return;
-    for (uint32_t i = tid; i < TS_WAVES * 256; i += TF_THREADS) (&sh.wave_hist[0][0])[i] = 0;
-    const uint32_t row_prefix = tid <= hmask ? scanned[(size_t)tid * num_parts + p] : 0u; // digit tid in earlier partitions
-    const uint32_t digit_total = totals[tid];                                              // ... and in the whole frame
-    // wave-striped: item i of lane l of wave w is element w * 1024 + i * 64 + l, the order the ranking preserves.
+    for (uint32_t i = tid; i < NW * 256; i += THREADS) (&sh.wave_hist[0][0])[i] = 0;
+    const bool digit_thread = tid < 256u; // thread tid < 256 owns digit tid in the scans below
+    const uint32_t row_prefix = (digit_thread && tid <= hmask) ? scanned[(size_t)tid * num_parts + p] : 0u; // digit tid in earlier partitions
+    const uint32_t digit_total = digit_thread ? totals[tid] : 0u;                                              // ... and in the whole frame
+    // wave-striped: item i of lane l of wave w is element w * ITEMS * 64 + i * 64 + l, the order the ranking preserves.
     // Slots past `valid` read the last pair and rank as digit 255 behind every real one: they end up past `valid`
     // in the reordered partition and are not written.
     const size_t base = (size_t)p * TF2_PART;
-    const uint32_t wbase = w * (TF2_ITEMS * 64) + lane;
-    uint32_t dig[TF2_ITEMS];
-    uint2 val[TF2_ITEMS];
+    const uint32_t wbase = w * (ITEMS * 64) + lane;
+    uint32_t dig[ITEMS];
+    uint2 val[ITEMS];
 #pragma unroll
-    for (uint32_t i = 0; i < TF2_ITEMS; ++i) {
+    for (uint32_t i = 0; i < ITEMS; ++i) {
         const uint32_t q = wbase + i * 64;
         const uint32_t c = q < valid ? q : valid - 1;
         dig[i] = q < valid ? (uint32_t)hi_in[base + c] : 255u;
@@ -1032,22 +1044,29 @@ __global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *
     // LDS atomics that collide on one counter serialise (see radix_sort.hip)
     bool use_atomic = RANK_ATOMIC;
     if (RANK_ATOMIC) {
-        const uint32_t next = tid > hmask ? 0u : (p + 1 < num_parts) ? scanned[(size_t)tid * num_parts + p + 1] : digit_total;
+        const uint32_t next = (!digit_thread || tid > hmask) ? 0u : (p + 1 < num_parts) ? scanned[(size_t)tid * num_parts + p + 1] : digit_total;
         use_atomic = !__syncthreads_or((next - row_prefix) > TF2_PART / 4);
     } else {
         __syncthreads();
     }
-    uint32_t rank[TF2_ITEMS];
+    uint32_t rank[ITEMS];
     if (use_atomic) {
 #pragma unroll
-        for (uint32_t i = 0; i < TF2_ITEMS; ++i) rank[i] = wave_rank<true>(sh.wave_hist[w], dig[i]);
+        for (uint32_t i = 0; i < ITEMS; ++i) rank[i] = wave_rank<true>(sh.wave_hist[w], dig[i]);
     } else {
 #pragma unroll
-        for (uint32_t i = 0; i < TF2_ITEMS; ++i) rank[i] = wave_rank<false>(sh.wave_hist[w], dig[i]);
+        for (uint32_t i = 0; i < ITEMS; ++i) rank[i] = wave_rank<false>(sh.wave_hist[w], dig[i]);
     }
     __syncthreads();
-    const uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
-    const uint32_t dcount = (c0 + c1) + (c2 + c3);
+    uint32_t cs[NW];
+    uint32_t dcount = 0;
+    if (digit_thread) {
+#pragma unroll
+        for (uint32_t v = 0; v < NW; ++v) {
+            cs[v] = sh.wave_hist[v][tid];
+            dcount += cs[v];
+        }
+    }
     // exclusive scans over the 256 digits of the partition's counts (local starts) and, in the same shuffles, of the
     // frame's digit totals (where each digit's run starts in the output)
     uint32_t incl = dcount, gincl = digit_total;
@@ -1059,23 +1078,27 @@ __global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *
             gincl += g;
         }
     }
-    if (lane == 63) {
+    if (digit_thread && lane == 63) {
         sh.wave_sums[w] = incl;
         sh.wave_gsums[w] = gincl;
     }
     __syncthreads();
-    const uint32_t wprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
-    const uint32_t gprefix = (w > 0 ? sh.wave_gsums[0] : 0u) + (w > 1 ? sh.wave_gsums[1] : 0u) + (w > 2 ? sh.wave_gsums[2] : 0u);
-    const uint32_t local_start = wprefix + incl - dcount;
-    sh.wave_hist[0][tid] = local_start;
-    sh.wave_hist[1][tid] = local_start + c0;
-    sh.wave_hist[2][tid] = local_start + c0 + c1;
-    sh.wave_hist[3][tid] = local_start + c0 + c1 + c2;
-    sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix - local_start;
+    if (digit_thread) {
+        const uint32_t wprefix = (w > 0 ? sh.wave_sums[0] : 0u) + (w > 1 ? sh.wave_sums[1] : 0u) + (w > 2 ? sh.wave_sums[2] : 0u);
+        const uint32_t gprefix = (w > 0 ? sh.wave_gsums[0] : 0u) + (w > 1 ? sh.wave_gsums[1] : 0u) + (w > 2 ? sh.wave_gsums[2] : 0u);
+        const uint32_t local_start = wprefix + incl - dcount;
+        uint32_t run = local_start;
+#pragma unroll
+        for (uint32_t v = 0; v < NW; ++v) {
+            sh.wave_hist[v][tid] = run;
+            run += cs[v];
+        }
+        sh.global_base[tid] = gprefix + gincl - digit_total + row_prefix - local_start;
+    }
     __syncthreads();
     // reorder inside the partition: same-digit pairs become contiguous, stable
 #pragma unroll
-    for (uint32_t i = 0; i < TF2_ITEMS; ++i) {
+    for (uint32_t i = 0; i < ITEMS; ++i) {
         const uint32_t pos = sh.wave_hist[w][dig[i]] + rank[i];
         s_val[pos] = val[i];
         s_dig[pos] = (uint8_t)dig[i];
@@ -1083,8 +1106,8 @@ __global__ __launch_bounds__(TF_THREADS, 3) void k_tf_downsweep2(const uint8_t *
     __syncthreads();
     // consecutive lanes write consecutive addresses inside each digit run
 #pragma unroll
-    for (uint32_t j = 0; j < TF2_ITEMS; ++j) {
-        const uint32_t pos = j * TF_THREADS + tid;
+    for (uint32_t j = 0; j < ITEMS; ++j) {
+        const uint32_t pos = j * THREADS + tid;
         if (pos < valid) val_out[sh.global_base[s_dig[pos]] + pos] = s_val[pos];
     }
 }
@@ -1097,18 +1120,23 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
     uint32_t *totals = hist + (size_t)256 * num_parts;
     if (hi_bits > 0) {
         const uint32_t hmask = (1u << hi_bits) - 1u;
-        hipLaunchKernelGGL(k_tf_upsweep2, dim3(num_parts), dim3(TF_THREADS), 0, ctx->stream, hi, *runs, hmask, num_parts, hist);
+        // each XCD takes a contiguous eighth of the partitions (common.h: xcd_block_of)
+        const uint32_t xcd_per = num_parts >= 64u ? div_up(num_parts, 8u) : 0u;
+        const uint32_t part_blocks = xcd_per ? 8u * xcd_per : num_parts;
+        hipLaunchKernelGGL(k_tf_upsweep2, dim3(part_blocks), dim3(TF_THREADS), 0, ctx->stream, hi, *runs, hmask, num_parts, hist, xcd_per);
         LAUNCH_CHECK(ctx, "k_tf_upsweep2");
         int rc = radix_rowscan_launch(ctx, hist, num_parts, hmask + 1u);
         if (rc != SPLAT_OK) return rc;
         const TfOffsetsArgs off = {tiles, lo_bits, offsets, d_total};
-        const dim3 grid(num_parts + div_up(tiles + 1, 256)); // the partitions, then the blocks of tile offsets
-        if (rank_atomic_ok(ctx, true)) // (checked: k_tile_sort verifies every list this pass contributes to)
-            hipLaunchKernelGGL(k_tf_downsweep2<true>, grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
-                               totals, off);
+        const dim3 grid(part_blocks + div_up(tiles + 1, 256)); // the partitions, then the blocks of tile offsets
+        const bool ra = rank_atomic_ok(ctx, true); // (checked: k_tile_sort verifies every list this pass contributes to)
+        // (512 threads per partition, eight pairs per thread: measured level with this, profiles/r05_b_second_pass_xcd_C3_C2.txt)
+        if (ra)
+            hipLaunchKernelGGL((k_tf_downsweep2<true, 4>), grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
+                               totals, off, part_blocks, xcd_per);
         else
-            hipLaunchKernelGGL(k_tf_downsweep2<false>, grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
-                               totals, off);
+            hipLaunchKernelGGL((k_tf_downsweep2<false, 4>), grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
+                               totals, off, part_blocks, xcd_per);
         LAUNCH_CHECK(ctx, "k_tf_downsweep2");
     }
     return SPLAT_OK; // (hi_bits == 0: k_tf_scatter wrote the offsets itself)
@@ -1122,6 +1150,10 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
                       uint32_t *offsets_if_final, uint32_t tiles, uint32_t *report, uint32_t seq, const uint32_t *cidx,
                       const uint32_t *kept) {
     const uint32_t parts = div_up(n, block_splats);
+    // each XCD takes a contiguous eighth of the blocks (common.h: xcd_block_of; C3: this kernel 112 -> 97 us and the second
+    // pass's downsweep 145 -> 135, C2 48.5 -> 47.0 / 44.1 -> 42.6: profiles/r05_c_first_pass_projector_xcd_C3_C2.txt)
+    const uint32_t xcd_per = parts >= 64u ? div_up(parts, 8u) : 0u;
+    const uint32_t grid_blocks = xcd_per ? 8u * xcd_per : parts;
     if (cidx && block_splats != TF_GROUP) return ctx_fail(ctx, SPLAT_ERR_INVALID, "tf_scatter_launch: compacted input comes in groups of 4096 records");
     const uint32_t *totals = hist + (size_t)256 * parts;
     {
@@ -1130,9 +1162,9 @@ int tf_scatter_launch(splat_ctx *ctx, const uint32_t *range32, const uint32_t *d
     }
     const bool ra = rank_atomic_ok(ctx, true); // (checked: k_tile_sort verifies every list this pass contributes to)
 #define SPLAT_TF_SCATTER_(RA, PER, COMPACTED)                                                                                     \
-    hipLaunchKernelGGL((k_tf_scatter<RA, PER, COMPACTED>), dim3(parts), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
+    hipLaunchKernelGGL((k_tf_scatter<RA, PER, COMPACTED>), dim3(grid_blocks), dim3(TF_THREADS), 0, ctx->stream, range32, depth_keys, n, ntx, mask, parts, \
                        hist, totals, d_total, pair_limit, overflow, out_hi, out_val, lo_bits, second_pass ? TF_RUN_ALIGN - 1u : 0u, *runs,         \
-                       second_pass ? nullptr : offsets_if_final, tiles, report, seq, cidx, kept)
+                       second_pass ? nullptr : offsets_if_final, tiles, report, seq, cidx, kept, xcd_per)
 #define SPLAT_TF_SCATTER(RA, PER) SPLAT_TF_SCATTER_(RA, PER, false)
     if (cidx) { // a multi-GPU band's kept splats, compacted per group of TF_GROUP records
         if (ra) SPLAT_TF_SCATTER_(true, 4, true);
