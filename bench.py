@@ -183,8 +183,8 @@ def orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, static_ms, static_c
     """K frames of an orbit, the camera turned by `degrees` of azimuth between frames by OrbitCameraController (a drag of
     degrees / 0.005 rad-per-pixel pixels: OrbitCameraController.ts:12,47-49), through FrameLoop; ms/frame, the composite's own
     duration (events on every fourth frame, as in the timed region), frames that had to be rendered again.  Then the SAME camera
-    path with the composite's look-ahead bound switched off, and with a chunk of slack on it — to say which mechanism a slowdown
-    comes from — and the default once more (the legs run one after the other: the second default says how much they drift)."""
+    path with the composite's look-ahead bound switched off — to say which mechanism a slowdown comes from — and the default once
+    more (the legs run one after the other: the second default says how much they drift)."""
     lib, ctx = dev.lib, dev.ctx
     loop = sr.FrameLoop(dev, n, width, height, tile, records=args.records)
     ctrl = sr.OrbitCameraController(loop.camera)
@@ -242,7 +242,6 @@ def orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, static_ms, static_c
     out["standing_still_at_the_last_view_ms_per_step"] = round(still_ms, 4)
     out["over_standing_still_at_the_last_view"] = round(out["ms_per_step"] / still_ms, 4)
     out["without_lookahead_bound"] = leg(predict=False)
-    out["with_one_chunk_of_slack"] = leg(slack=1)
     out["default_again"] = leg()
     out["frames_misranked"] = loop.renderer.framesMisranked
     dev.compositeOptions()

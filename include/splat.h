@@ -155,10 +155,9 @@ void *splat_sort_sorted_keys(splat_sorter *s);
 /* Hardware probe (diagnostic): runs ~2M wave instructions of returning LDS atomics with colliding
  * addresses and counts those whose return values were NOT in ascending lane order.  Synchronises. */
 int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches);
-/* Sort algorithm of this sorter: 0 = per-pass histogram + row scan + scatter (default, fastest on
- * MI355X; ranks keys with returning LDS atomics when the lane-order probe above passes, else with
- * ballots), 1 = onesweep with decoupled look-back (the reference's structure), 2 = as 0 but always
- * ballot ranking, -1 = library default.
+/* How this sorter ranks equal digits: 0 = as the context's policy says (per-pass histogram + row scan + scatter; returning
+ * LDS atomics only where the policy allows them, see the NOTE), 2 = always with ballots, -1 = library default (0).  (Round
+ * 1's onesweep mode with decoupled look-back — the reference's structure, slower on MI355X — was removed in round 5.)
  * NOTE on ranking (mode 0, and the frame path's binning kernels).  Ranking a wave's keys with returning LDS atomics is
  * stable only if the lanes of one instruction that collide on an address complete in ascending lane order.  That is what
  * gfx950 does (splat_probe_lds_atomic_order: 0 mismatches in 8.4 M colliding instructions) but it is not an ISA guarantee,
@@ -185,6 +184,9 @@ int splat_sort_set_mode(splat_sorter *s, int mode);
  * *order_faults = frames of this context whose tile lists failed the order check (each was reported with
  * SPLAT_ERR_RETRY).  Runs the probe if it has not run yet (synchronises then). */
 int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_t *order_faults);
+#ifdef SPLAT_TEST_HOOKS
+/* ---- test and experiment hooks: compiled only into libsplat_hip_hooks.so (-DSPLAT_TEST_HOOKS, built beside the library for
+ * tests/ and tools/); the shipped library neither exports them nor carries their kernel parameters ---------------------- */
 /* TEST HOOK: the next per-tile sort of this context swaps entries `position` and `position + 1` of tile `tile`'s finished
  * list just before its order check, as an out-of-lane-order ranking would have left them: the check must raise the
  * frame's flag, the next call return SPLAT_ERR_RETRY, and the frame rendered again be right.  One shot. */
@@ -194,30 +196,32 @@ int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t posit
 int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
 /* EXPERIMENT HOOK: the same for the per-tile sort's workgroups (a permutation of ALL the screen's tiles; NULL = row-major). */
 int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr);
-/* The lane-efficient composite keeps, per context and band of tile rows, what its previous launch cost per tile (chunks of
+/* EXPERIMENT HOOK (tools/overlap_probe.py): the per-tile sort of the binner's last tile-first frame once more, on ctx's stream. */
+int splat_debug_rerun_tile_sort(splat_ctx *ctx, splat_binner *binner);
+#endif
+/* The lane-efficient composite keeps, per context, for each of the last few (four) bands of tile rows it composited (a band
+ * = these rows of this binner's lists), what its previous launch over that band cost per tile (chunks of
  * 32 list entries walked): the next launch over the same band takes its tiles longest-first and builds / gathers for each
  * tile only what that launch needed ahead of need (a tile that needs more pays one exposed gather).  Both are hints — any
  * history, stale or from another scene, gives the same image.  This forgets the history (the next two launches run
  * row-major and without a bound, as a context's first do): for measurements and tests that want the kernel's first-frame
  * behaviour. */
 int splat_composite_forget_history(splat_ctx *ctx);
-/* Per-context choices the environment otherwise makes for the whole process (environment table):
+/* Per-context choices the environment otherwise makes for the whole process (environment table).  EVERY call
+ * sets all three: a value of -1 (kernel, predict) or 0 (ahead) means "the process default", i.e. what the environment
+ * variable named beside it says — not "leave as it is"; a per-context choice takes precedence over the environment:
  *   kernel  -1 default (SPLAT_COMPOSITE: lane-efficient k_composite_px on screens of >= 2048 tiles), 0 k_composite ("quadrant"),
  *            1 k_composite_px ("pixel") — for nearest-on-top frames of either footprint; the reference-literal blend always
  *            takes k_composite;
  *   ahead    0 default (SPLAT_PX_AHEAD: 1 for the isotropic footprint with the early-out, 2 otherwise), 1 or 2: chunks
  *            k_composite_px's builder wave stays ahead of its consumer wave (2: lanes whose queue for a chunk is empty go on
  *            with the next chunk's);
- *   predict -1 default (SPLAT_PX_PREDICT, on), 0 / 1: bound each tile's look-ahead by what the previous launch walked;
- *   slack   -1 default (SPLAT_PX_SLACK, 0), else chunks added to that bound.
- * ahead, predict and slack change the schedule only: the same bytes.  The two kernels evaluate the Gaussian differently
+ *   predict -1 default (SPLAT_PX_PREDICT, on), 0 / 1: bound each tile's look-ahead by what the previous launch walked.
+ * ahead and predict change the schedule only: the same bytes.  The two kernels evaluate the Gaussian differently
  * (k_composite_px builds an entry's table by a recurrence from five exponentials) and agree within the composite's stated
  * tolerance, 2e-5 per float channel, <= 1 LSB on rgba8 (tests/test_gpu_stages.py runs the oracle comparisons over all of
  * them).  Forgets the composite's history. */
-int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict, int slack);
-/* Diagnostic: non-zero if a chained-scan look-back of the last splat_sort_run hit its spin bound
- * (the result is then invalid).  Synchronises. */
-int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag);
+int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict);
 
 /* ---- PrefixSumScanner.scan  (src/PrefixSumScanner.ts:74-87, prefix-sum.wgsl:28-96) -------- */
 /* Exclusive scan of n u32 (out[0] = 0); in may equal out.  total_dptr (optional) receives the
@@ -391,11 +395,8 @@ int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected,
  * cfg->record_format whose position is the global splat index (the all-gathered shards);
  * props/normals: the full scene in the reference's layouts (props = interleaved records); with
  * cfg->prelit, props is the plane of lit colours (splat_lit_colors) and normals may be NULL.
- * cfg->record_format = SPLAT_RECORDS_LIT32 (tile-first order, 16-byte exchange records in `records` all the same): the call
- * also writes the frame's 32-byte lit composite record for every splat the band KEEPS and composites from those — one
- * gathered line per staged list entry, as the single-GPU frame — instead of exchange record + colour (+ normal).  Same
- * image.  Not the default: on eight virtual ranks of C2 the composite gains 2-4 us per rank and writing the records costs
- * 21 us (profiles/r04_c_band_lit_records_C2.txt). */
+ * (cfg->record_format = SPLAT_RECORDS_LIT32 is not a band frame's format: round 4's variant that built lit composite records
+ * for the splats a band keeps measured 20 us per rank slower on eight ranks and was removed.) */
 int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
                      const splat_composite_cfg *cfg, const void *props, const void *normals,
                      const void *records, uint32_t n_records, uint32_t width, uint32_t height,

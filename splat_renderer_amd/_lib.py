@@ -85,12 +85,8 @@ SIGNATURES = {
     "splat_probe_lds_atomic_order": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "splat_sort_set_mode": (_i, [_vp, _i]),
     "splat_rank_status": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_u32)]),
-    "splat_debug_inject_order_fault": (_i, [_vp, _u32, _u32]),
-    "splat_debug_set_tile_order": (_i, [_vp, _vp]),
-    "splat_debug_set_tile_sort_order": (_i, [_vp, _vp]),
     "splat_composite_forget_history": (_i, [_vp]),
-    "splat_composite_options": (_i, [_vp, _i, _i, _i, _i]),
-    "splat_sort_lookback_timeouts": (_i, [_vp, C.POINTER(_u32)]),
+    "splat_composite_options": (_i, [_vp, _i, _i, _i]),
     "splat_scan_u32": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "splat_bin_create": (_i, [_vp, _u32, _pvp]),
     "splat_bin_destroy": (None, [_vp]),
@@ -132,6 +128,15 @@ SIGNATURES = {
     "splat_allgather_records": (_i, [_vp, _vp, _vp, _vp, _sz]),
 }
 COMM_ID_BYTES = 128
+# include/splat.h, #ifdef SPLAT_TEST_HOOKS: exported by the test build only (libsplat_hip_hooks.so, which tests/ and tools/
+# select with SPLAT_LIB_PATH); bound when the loaded library has them
+HOOK_SIGNATURES = {
+    "splat_debug_inject_order_fault": (_i, [_vp, _u32, _u32]),
+    "splat_debug_set_tile_order": (_i, [_vp, _vp]),
+    "splat_debug_set_tile_sort_order": (_i, [_vp, _vp]),
+    "splat_debug_rerun_tile_sort": (_i, [_vp, _vp]),
+}
+HOOKS_LIB_PATH = os.path.join(_HERE, "libsplat_hip_hooks.so")
 
 _lib = None
 
@@ -142,6 +147,9 @@ class _Bound:
     function that was added to splat.h but not to SIGNATURES must fail here, not fault on the GPU.)"""
 
     def __getattr__(self, name):
+        if name in HOOK_SIGNATURES:
+            raise AttributeError(f"libsplat_hip: {name} is a test hook: the shipped library does not carry it; run with "
+                                 f"SPLAT_LIB_PATH={HOOKS_LIB_PATH} (the -DSPLAT_TEST_HOOKS build)")
         raise AttributeError(f"libsplat_hip: {name} is not declared in splat_renderer_amd._lib.SIGNATURES")
 
 
@@ -161,6 +169,13 @@ def load():
         fn.restype = res
         fn.argtypes = args
         setattr(lib, name, fn)
+    lib.has_hooks = hasattr(dll, "splat_debug_inject_order_fault")
+    if lib.has_hooks:
+        for name, (res, args) in HOOK_SIGNATURES.items():
+            fn = getattr(dll, name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(lib, name, fn)
     lib._dll = dll
     _lib = lib
     return lib

@@ -536,6 +536,7 @@ int binner_settle(splat_binner *b) {
 
 extern "C" {
 
+#ifdef SPLAT_TEST_HOOKS
 // EXPERIMENT HOOK (tools/overlap_probe.py): the per-tile sort of the binner's last tile-first frame once more, on `ctx`'s stream
 // (any context of the device), from the second pass's output as it stands.  Timing only: tiles beyond the LDS path's size
 // were sorted through both pair arrays and are sorted again from whatever that left.
@@ -547,6 +548,7 @@ int splat_debug_rerun_tile_sort(splat_ctx *ctx, splat_binner *b) {
     return tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload_b,
                             nullptr, b->d_total + 3, tiles >= 6144u ? (uint32_t)(b->total / tiles) : 0u);
 }
+#endif
 
 int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
@@ -583,7 +585,6 @@ void splat_bin_destroy(splat_binner *b) {
     binner_free_wide(b);
     if (b->expanded) (void)hipFree(b->expanded);
     if (b->discs) (void)hipFree(b->discs);
-    if (b->band_lit) (void)hipFree(b->band_lit);
     if (b->band_idx) (void)hipFree(b->band_idx);
     if (b->pinned) (void)hipHostFree(b->pinned);
     if (b->readback_done) (void)hipEventDestroy(b->readback_done);

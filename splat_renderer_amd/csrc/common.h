@@ -15,7 +15,18 @@ constexpr int kWave = 64; // CDNA wavefront
 struct StageTimer {
     std::vector<hipEvent_t> beg, end;
     size_t used = 0;
+    uint32_t tick = 0; // launches of this stage seen while timing is on (splat_set_timing_sampling: every n-th carries a pair)
 };
+// k_composite_px's history for ONE band of one binner's lists (composite.hip, px_order_prepare): two arrays of per-tile costs
+// and two of tile orders (cap entries each), alternating between launches.  A context keeps a few (two frames in flight on
+// one context, virtual ranks, a band next to the whole frame: each has its own), the least recently used one gives way.
+struct PxHistory {
+    uint64_t key = 0; // 0 = free
+    uint32_t *mem = nullptr;
+    uint32_t cap = 0, parity = 0, streak = 0;
+    uint64_t last_use = 0;
+};
+constexpr int PX_HISTORIES = 4;
 
 struct splat_ctx {
     int device = 0;
@@ -32,21 +43,19 @@ struct splat_ctx {
     // check): nowhere.
     int rank_policy = 0;
     uint32_t order_faults = 0;      // frames whose lists failed the order check (each was reported and rendered again)
+#ifdef SPLAT_TEST_HOOKS // (libsplat_hip_hooks.so, the test build: the shipped library carries none of this)
     const uint32_t *debug_tile_order = nullptr; // experiment hook (splat_debug_set_tile_order)
     const uint32_t *debug_sort_order = nullptr; // experiment hook (splat_debug_set_tile_sort_order)
-    // splat_composite_options (-1 / 0 = the process default, i.e. the environment's): which kernel composites nearest-on-top
-    // isotropic frames (0 quadrant, 1 pixel), and k_composite_px's schedule
-    int opt_composite_kernel = -1, opt_px_ahead = 0, opt_px_predict = -1, opt_px_slack = -1;
-    // k_composite_px's dispatch order (composite.hip, px_order_prepare): for the band `px_key` describes, two arrays of
-    // per-tile costs and two of tile orders (px_cap entries each), alternating between launches
-    uint32_t *px_mem = nullptr;
-    uint32_t px_cap = 0, px_parity = 0, px_streak = 0;
-    uint64_t px_key = 0;
     uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps ...
     uint32_t inject_order_position = 0; // ... at entries position, position + 1
-    int tile_sort_digits = 0; // k_tile_sort's in-LDS passes: 0 = not resolved yet, 8 = byte passes (default), 12 = wide passes (SPLAT_TILE_SORT_DIGITS=12)
+#endif
+    // splat_composite_options (-1 / 0 = the process default, i.e. the environment's): which kernel composites nearest-on-top
+    // isotropic frames (0 quadrant, 1 pixel), and k_composite_px's schedule
+    int opt_composite_kernel = -1, opt_px_ahead = 0, opt_px_predict = -1;
+    PxHistory px_hist[PX_HISTORIES]; // k_composite_px's per-band histories
+    uint64_t px_clock = 0;
     uint32_t timing_mask = 0xffffffffu; // which stages record events while timing is on
-    uint32_t timing_every = 1, timing_tick = 0; // one-kernel stages (the composite): an event pair on every timing_every-th launch
+    uint32_t timing_every = 1; // one-kernel stages (the composite): an event pair on every timing_every-th launch (StageTimer::tick)
     StageTimer timers[SPLAT_STAGE_COUNT];
     // scratch for the generic scan (block sums) and for small device scalars
     void *scan_ws = nullptr;
@@ -110,7 +119,6 @@ static inline bool rank_atomic_ok(const splat_ctx *ctx, bool checked) {
 // frame flags word (binner d_total[1]): bit 0 = the pairs outgrew the sync-free limit, bit 1 = a tile's list failed the
 // order check of k_tile_sort
 constexpr uint32_t FRAME_FLAG_OVERFLOW = 1u, FRAME_FLAG_ORDER = 2u;
-int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value);
 
 struct splat_sorter {
     splat_ctx *ctx = nullptr;
@@ -127,7 +135,7 @@ struct splat_sorter {
     uint32_t kept_blocks = 0; // tile-first band frame: hist[0..kept_blocks) holds per-block kept counts, not yet summed
     bool result_in_primary = true;
     bool ran = false;
-    int mode = -1; // -1 = library default, 0 = upsweep/rowscan/downsweep, 1 = onesweep (chained scan)
+    int mode = -1; // -1 / 0 = rank as the context's policy says, 2 = always with ballots
 };
 
 // grows the sorter's buffers (contents are NOT preserved)
@@ -167,8 +175,6 @@ struct splat_binner {
     uint32_t expanded_cap = 0;
     void *discs = nullptr;                          // frame path, oriented-disc footprint: the projector's 32-byte disc records
     uint32_t discs_cap = 0;
-    void *band_lit = nullptr;                       // multi-GPU band frame: 32-byte lit composite records of the splats the band keeps (shade.h)
-    uint32_t band_lit_cap = 0;
     bool tf_hist_ready = false;                     // the projector already filled tf_hist / blocksums for the next tile-first run
     uint32_t tf_block = 1024;                       // splats per block of that histogram (TF_BLOCK_SMALL for small frames)
     // a multi-GPU band frame whose prepare pass compacted the kept splats per group of 4096 records (k_band_prepare_tfc): their

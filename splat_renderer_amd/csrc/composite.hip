@@ -60,7 +60,6 @@ struct CompositeParams {
     const uint32_t *order_src;  // k_composite_px, workgroup 0: the costs the PREVIOUS launch over this band left (NULL: none) ...
     uint32_t *order_dst;        // ... sorted into the order the NEXT launch takes its tiles in
     const uint32_t *cost_prev;  // k_composite_px: the same costs, read by every tile: how many chunks to build and gather ahead of need (NULL: all)
-    uint32_t cost_slack;        // ... plus this many
 #ifdef PX_PROFILE
     uint32_t debug_cap;         // (measuring build only, SPLAT_PX_CAP: every list cut after this many entries — a WRONG image: what do the long tiles cost?)
 #endif
@@ -667,10 +666,11 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
 #endif
     const uint32_t nchunks = (count + PXC - 1) / PXC;
     const float tile_x0 = (float)(tx * CT), tile_y0 = (float)(ty * CT);
-    // chunks built and gathered ahead of need: what the previous launch over this band walked for this tile (+ the slack the
-    // host asks for), at least one, at most all.  Both waves derive the same value: it decides where they meet.
+    // chunks built and gathered ahead of need: what the previous launch over this band walked for this tile, at least one, at
+    // most all.  Both waves derive the same value: it decides where they meet.  (Chunks of slack on top of it lose: every
+    // tile then builds a chunk it does not walk — 54.6 against 47.2 us at C2, profiles/EXPERIMENTS.md §7.1.)
     uint32_t lim = nchunks;
-    if (p.cost_prev) lim = min(max(p.cost_prev[t_local] + p.cost_slack, 1u), nchunks);
+    if (p.cost_prev) lim = min(max(p.cost_prev[t_local], 1u), nchunks);
     lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)lim);
 
     if (role == 1) {
@@ -1104,49 +1104,62 @@ __global__ __launch_bounds__(128, PX_WAVES) void k_composite_px(CompositeParams 
 
 static bool g_px_order_on = true;   // SPLAT_TILE_ORDER=0: workgroups take their tiles row-major (read once per process)
 static bool g_px_predict_on = true; // SPLAT_PX_PREDICT=0: every tile builds and gathers ahead of need without a bound
-static uint32_t g_px_slack = 0;     // SPLAT_PX_SLACK=n: chunks built beyond what the previous launch needed
 static int g_px_ahead = 0;          // SPLAT_PX_AHEAD=1 | 2: chunks the builder stays ahead (2: lanes run ahead too); unset: 1 with the early-out, 2 without
 
-// The per-band history of a context: two cost arrays and two order arrays, alternating.  Launch k over a band writes
-// cost[k & 1]; it sizes every tile's look-ahead by cost[(k + 1) & 1] (launch k - 1's), takes its tiles in order[k & 1] —
+// The history of one band of one binner's lists: two cost arrays and two order arrays, alternating.  Launch k over the band
+// writes cost[k & 1]; it sizes every tile's look-ahead by cost[(k + 1) & 1] (launch k - 1's), takes its tiles in order[k & 1] —
 // which launch k - 1's ordering workgroup derived from cost[k & 1] as launch k - 2 had left it — and derives
 // order[(k + 1) & 1] from cost[(k + 1) & 1].  All of it is a hint: any order and any bound give the same image.
+// A context keeps PX_HISTORIES of them, found by `key` (the band, the screen, whose lists), least recently used evicted: two
+// frames in flight on one context, a band frame next to the whole frame, virtual ranks on one context each keep theirs
+// (with ONE slot they reset each other at every launch, and neither the order nor the bound ever engaged: ADVICE r4).
 static int px_order_prepare(splat_ctx *ctx, uint32_t band_tiles, uint64_t key, CompositeParams &p) {
     p.tile_order = nullptr;
     p.tile_cost = nullptr;
     p.order_src = nullptr;
     p.order_dst = nullptr;
     p.cost_prev = nullptr;
-    p.cost_slack = ctx->opt_px_slack >= 0 ? (uint32_t)ctx->opt_px_slack : g_px_slack;
     const bool predict_on = ctx->opt_px_predict >= 0 ? ctx->opt_px_predict != 0 : g_px_predict_on;
     if (!g_px_order_on && !predict_on) return SPLAT_OK;
-    if (band_tiles > ctx->px_cap) {
+    PxHistory *h = nullptr, *lru = &ctx->px_hist[0];
+    for (auto &e : ctx->px_hist) {
+        if (e.key == key) h = &e;
+        if (e.last_use < lru->last_use) lru = &e;
+    }
+    if (!h) { // a band this context has not composited lately: the least recently used slot starts over for it
+        h = lru;
+        h->key = key;
+        h->streak = 0;
+    }
+    h->last_use = ++ctx->px_clock;
+    if (band_tiles > h->cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (a launch in flight may still write the old arrays)
-        if (ctx->px_mem) (void)hipFree(ctx->px_mem);
-        ctx->px_mem = nullptr;
-        ctx->px_cap = 0;
-        ctx->px_key = 0;
+        if (h->mem) (void)hipFree(h->mem);
+        h->mem = nullptr;
+        h->cap = 0;
+        h->streak = 0;
         // (each array padded so that px_make_order's 128 threads read whole 64-byte groups of costs past the last tile)
         const uint32_t cap = (band_tiles + 128u * 16u + 1023u) & ~1023u;
-        if (hipMalloc((void **)&ctx->px_mem, (size_t)cap * 16) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "composite tile order hipMalloc");
-        (void)hipMemsetAsync(ctx->px_mem, 0, (size_t)cap * 16, ctx->stream);
-        ctx->px_cap = cap;
+        if (hipMalloc((void **)&h->mem, (size_t)cap * 16) != hipSuccess) {
+            h->key = 0;
+            return ctx_fail(ctx, SPLAT_ERR_OOM, "composite tile order hipMalloc");
+        }
+        (void)hipMemsetAsync(h->mem, 0, (size_t)cap * 16, ctx->stream);
+        h->cap = cap;
     }
-    if (ctx->px_key != key) ctx->px_streak = 0; // another band, screen or context history: start over
-    ctx->px_key = key;
-    uint32_t *cost[2] = {ctx->px_mem, ctx->px_mem + ctx->px_cap}, *order[2] = {ctx->px_mem + 2 * (size_t)ctx->px_cap, ctx->px_mem + 3 * (size_t)ctx->px_cap};
-    const uint32_t q = ctx->px_parity & 1u;
+    uint32_t *cost[2] = {h->mem, h->mem + h->cap}, *order[2] = {h->mem + 2 * (size_t)h->cap, h->mem + 3 * (size_t)h->cap};
+    const uint32_t q = h->parity & 1u;
     p.tile_cost = cost[q];
-    if (g_px_order_on && ctx->px_streak >= 2) p.tile_order = order[q]; // written by the previous launch from the costs of the one before it
-    if (ctx->px_streak >= 1) {                                          // the previous launch left its costs
+    if (g_px_order_on && h->streak >= 2) p.tile_order = order[q]; // written by the previous launch from the costs of the one before it
+    if (h->streak >= 1) {                                          // the previous launch left its costs
         if (predict_on) p.cost_prev = cost[q ^ 1u];
         if (g_px_order_on) { // sort them for the next launch
             p.order_src = cost[q ^ 1u];
             p.order_dst = order[q ^ 1u];
         }
     }
-    ctx->px_parity ^= 1u;
-    if (ctx->px_streak < 2) ctx->px_streak++;
+    h->parity ^= 1u;
+    if (h->streak < 2) h->streak++;
 #ifdef PX_PROFILE
     { // (measuring build only, SPLAT_PX_FREEZE=1: the order found by the first launches is kept and no launch computes another: is the ordering workgroup free?)
         static int freeze = -1;
@@ -1181,6 +1194,12 @@ extern "C" int splat_composite(splat_ctx *ctx, const splat_composite_cfg *cfg, c
                                const void *projected, const void *tile_indices, const void *tile_counts,
                                const void *tile_offsets, uint32_t width, uint32_t height, void *out_rgba8, void *out_rgba32f,
                                void *consumed_dptr) {
+    // lit DISC records (48 bytes: the lit colour behind each disc record) exist only inside a frame's binner; a public caller's
+    // disc records are the projector's 32-byte ones (splat_project_disc) or 48-byte exchange records (taken at its
+    // word this pair would read idx * 48 out of an n * 32 allocation)
+    if (ctx && cfg && cfg->footprint == SPLAT_FOOTPRINT_DISC && cfg->record_format == SPLAT_RECORDS_LIT32)
+        return ctx_fail(ctx, SPLAT_ERR_INVALID, "splat_composite: the oriented-disc footprint composites from SPLAT_RECORDS_PROJECTED (32-byte disc "
+                                                "records) or SPLAT_RECORDS_DISC48; lit disc records are internal to splat_render_frame");
     return composite_launch(ctx, cfg, color_opacity, color_stride_vec4, normals, normal_stride_vec4, projected, tile_indices, tile_counts,
                             tile_offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr, nullptr, nullptr, 0u);
 }
@@ -1265,15 +1284,16 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
     p.order_src = nullptr;
     p.order_dst = nullptr;
     p.cost_prev = nullptr;
-    p.cost_slack = 0;
 #ifdef PX_PROFILE
     p.debug_cap = getenv("SPLAT_PX_CAP") ? (uint32_t)strtoul(getenv("SPLAT_PX_CAP"), nullptr, 10) : 0xffffffffu;
 #endif
     dim3 grid(ntx, r1 - r0), block(256);
     const bool eo = cfg->early_out != 0;
-    // timed runs attach the event pair to the launch itself (no marker packets around the kernel)
+    // timed runs attach the event pair to the launch itself (no marker packets around the kernel).  The pair is taken right
+    // before the launch, after everything that can fail: a pair that was handed out and never recorded would be read by
+    // splat_stage_time_stats
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const bool timed = stage_event_pair(ctx, SPLAT_STAGE_COMPOSITE, &ev0, &ev1);
+    bool timed = false;
 #define SPLAT_COMPOSITE_LAUNCH(MODE, EO, DISC, LIT)                                                                       \
     do {                                                                                                                  \
         if (timed) hipExtLaunchKernelGGL((k_composite<MODE, EO, DISC, LIT>), grid, block, 0, ctx->stream, ev0, ev1, 0, p); \
@@ -1299,8 +1319,6 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
         g_px_order_on = !(o && o[0] == '0');
         const char *pr = getenv("SPLAT_PX_PREDICT"); // =0: no look-ahead bound from the previous launch's costs
         g_px_predict_on = !(pr && pr[0] == '0');
-        const char *sl = getenv("SPLAT_PX_SLACK");
-        if (sl) g_px_slack = (uint32_t)strtoul(sl, nullptr, 10);
         const char *ah = getenv("SPLAT_PX_AHEAD");
         g_px_ahead = !ah ? 0 : ah[0] == '1' ? 1 : 2;
     }
@@ -1319,7 +1337,10 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
                               ((uint64_t)(uintptr_t)tile_counts * 0x9E3779B97F4A7C15ull)) | 1u;
         int orc = px_order_prepare(ctx, band_tiles, key, p);
         if (orc != SPLAT_OK) return orc;
+#ifdef SPLAT_TEST_HOOKS
         if (ctx->debug_tile_order) p.tile_order = ctx->debug_tile_order;
+#endif
+        timed = stage_event_pair(ctx, SPLAT_STAGE_COMPOSITE, &ev0, &ev1);
         // one workgroup of two waves (consumer, builder) per tile, behind workgroup 0 (report, next launch's tile order)
         const dim3 pgrid(band_tiles + 1u), pblock(128);
 #define SPLAT_COMPOSITE_PX_LAUNCH2(EO, LIT, CNT, AH, DISC)                                                                       \
@@ -1353,6 +1374,7 @@ static int composite_launch_checked(splat_ctx *ctx, const splat_composite_cfg *c
         LAUNCH_CHECK(ctx, "k_composite_px");
         return SPLAT_OK;
     }
+    timed = stage_event_pair(ctx, SPLAT_STAGE_COMPOSITE, &ev0, &ev1);
     if (p.disc) {
         if (eo) SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, true, true, false);
         else    SPLAT_COMPOSITE_LAUNCH(SPLAT_COMPOSITE_FRONT_TO_BACK, false, true, false);

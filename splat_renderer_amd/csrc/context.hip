@@ -65,8 +65,8 @@ void stage_begin(splat_ctx *ctx, int stage) {
 // hipEventRecord pair costs ~6 us of idle GPU per launch).  False when the stage is not being timed.
 bool stage_event_pair(splat_ctx *ctx, int stage, hipEvent_t *start, hipEvent_t *stop) {
     if (!ctx->timing || !((ctx->timing_mask >> stage) & 1u)) return false;
-    if (ctx->timing_every > 1 && (ctx->timing_tick++ % ctx->timing_every) != 0) return false; // (splat_set_timing_sampling)
     StageTimer &t = ctx->timers[stage];
+    if (ctx->timing_every > 1 && (t.tick++ % ctx->timing_every) != 0) return false; // (splat_set_timing_sampling; a count per stage)
     if (t.used == t.beg.size()) {
         hipEvent_t a = nullptr, b = nullptr;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
@@ -140,7 +140,8 @@ void splat_ctx_destroy(splat_ctx *ctx) {
         for (auto e : t.end) (void)hipEventDestroy(e);
     }
     if (ctx->d_consumed) (void)hipFree(ctx->d_consumed);
-    if (ctx->px_mem) (void)hipFree(ctx->px_mem);
+    for (auto &h : ctx->px_hist)
+        if (h.mem) (void)hipFree(h.mem);
     if (ctx->scan_ws) (void)hipFree(ctx->scan_ws);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -170,7 +171,7 @@ int splat_set_timing_sampling(splat_ctx *ctx, uint32_t every) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, every >= 1);
     ctx->timing_every = every;
-    ctx->timing_tick = 0;
+    for (auto &t : ctx->timers) t.tick = 0;
     return SPLAT_OK;
 }
 

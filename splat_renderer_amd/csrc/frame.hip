@@ -76,15 +76,13 @@ constexpr uint32_t BTF_PER_THREAD = 4, BTF_BLOCK = BAND_THREADS * BTF_PER_THREAD
 
 // FORMAT = cfg->record_format.  COMPACT: 16-byte exchange records, the bounds are rebuilt as the projector forms
 // them.  DISC48: 48-byte oriented-disc exchange records, the bounds are the disc's (disc_bounds of the record).
-// lit.records != NULL (COMPACT): for every splat the band KEEPS the kernel also writes the frame's 32-byte lit composite
-// record (shade.h) — the exchange record IS its first half, the second is the splat's lit colour, read here once per kept
-// splat in index order — so that the band composites from ONE gathered line per staged list entry, as the single-GPU frame
-// does, instead of three (exchange record, colour, normal).  Same bits: the single-GPU projector forms the record from the
-// same two halves.
+// (Round 4 also let this pass write 32-byte lit composite records for the splats the band keeps, so that the band's composite
+// gathers one line per staged entry instead of three: 20 us per rank SLOWER with eight ranks — the kept splats are an eighth
+// of all, scattered, every record a line of its own; profiles/r04_c_band_lit_records_C2.txt.  Removed in round 5.)
 template <int FORMAT>
 __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *__restrict__ records, uint32_t n, BinParams bp,
                                                                   uint32_t *__restrict__ keys_by_idx, uint32_t *__restrict__ range32,
-                                                                  uint32_t *__restrict__ kept_blocks, TfHistOut ho, LitIO lit) {
+                                                                  uint32_t *__restrict__ kept_blocks, TfHistOut ho) {
     __shared__ uint32_t lh[4][256]; // the block's pairs per low tile-id digit, as k_project_hist counts them
     __shared__ uint32_t wsum[2][4];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
@@ -92,12 +90,9 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
     for (uint32_t j = tid; j < 4 * 256; j += BAND_THREADS) (&lh[0][0])[j] = 0;
     __syncthreads();
     uint32_t kept = 0, pairs = 0;
-    float4 rec[BTF_PER_THREAD]; // COMPACT with lit records: the kept splats' exchange records (the lit records' first halves)
-    bool keep[BTF_PER_THREAD];
 #pragma unroll
     for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
         const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + tid;
-        keep[k] = false;
         if (i < n) {
             float4 a;
             float depth;
@@ -107,7 +102,6 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
                 depth = records[(size_t)i * 3 + 2].x;
             } else if (FORMAT == SPLAT_RECORDS_COMPACT) {
                 const float4 c = records[i];
-                rec[k] = c;
                 const float padded = c.z * 1.5f; // SplatProjector.ts:119-121 (this file is compiled with -ffp-contract=off)
                 a = make_float4(c.x - padded, c.y - padded, c.x + padded, c.y + padded);
                 depth = c.w;
@@ -122,30 +116,6 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
             if (ok) {
                 kept += 1u;
                 pairs += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
-                keep[k] = true;
-            }
-        }
-    }
-    if (FORMAT == SPLAT_RECORDS_COMPACT && lit.records) {
-        // the kept splats' lit composite records.  All of a thread's colour (and normal) loads are issued before the first is
-        // used: inside the loop above each sat behind its own branch and the histogram's LDS atomics, one exposed round trip
-        // per kept splat (the kernel took 49 us instead of 24 at C2 on eight ranks: profiles/r04_c_band_lit_records_C2.txt)
-        float4 col[BTF_PER_THREAD], nrm[BTF_PER_THREAD];
-#pragma unroll
-        for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
-            const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + tid;
-            col[k] = nrm[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (keep[k]) {
-                col[k] = lit.color[(size_t)i * lit.color_stride];
-                if (!lit.prelit) nrm[k] = lit.normals[(size_t)i * lit.normal_stride];
-            }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < BTF_PER_THREAD; ++k) {
-            const uint32_t i = blockIdx.x * BTF_BLOCK + k * BAND_THREADS + tid;
-            if (keep[k]) {
-                lit.records[(size_t)i * 2] = rec[k];
-                lit.records[(size_t)i * 2 + 1] = lit.prelit ? col[k] : lit_color(col[k], nrm[k]);
             }
         }
     }
@@ -390,7 +360,8 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, sorter && binner && cfg && props && (normals || cfg->prelit) && (n_records == 0 || records));
     ARG_CHECK(ctx, cfg->tile_size == splat_bin_tile_size(binner) && width >= 1 && height >= 1);
-    ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC && cfg->record_format <= SPLAT_RECORDS_LIT32);
+    // (what the gathered records are: ProjectedSplat, 16-byte exchange records, 48-byte disc exchange records)
+    ARG_CHECK(ctx, cfg->footprint <= SPLAT_FOOTPRINT_DISC && cfg->record_format <= SPLAT_RECORDS_DISC48);
     // the oriented disc travels as its own 48-byte records, and only those carry it
     ARG_CHECK(ctx, (cfg->footprint == SPLAT_FOOTPRINT_DISC) == (cfg->record_format == SPLAT_RECORDS_DISC48));
     // colours: the second vec4 of the reference's interleaved records, or (cfg->prelit) `props` IS the plane of lit colours
@@ -401,10 +372,7 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
     if (row0 > row1) row0 = row1;
     const uint32_t ntx = div_up(width, tile);
     const bool fast = ntx <= 256 && nty <= 256 && n_records > 0;
-    // SPLAT_RECORDS_LIT32 here: `records` are 16-byte exchange records all the same, and the band composites from 32-byte lit
-    // composite records this call builds for the splats the band keeps (below)
-    const bool want_lit = cfg->record_format == SPLAT_RECORDS_LIT32;
-    const bool compact = cfg->record_format == SPLAT_RECORDS_COMPACT || want_lit;
+    const bool compact = cfg->record_format == SPLAT_RECORDS_COMPACT;
     const bool disc = cfg->record_format == SPLAT_RECORDS_DISC48;
     if (disc && n_records > 0 && !(fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST))
         return ctx_fail(ctx, SPLAT_ERR_INVALID,
@@ -436,29 +404,6 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         rc = binner_reserve(binner, ntx * nty, n_records);
         if (rc != SPLAT_OK) return rc;
         const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
-        // cfg->record_format = SPLAT_RECORDS_LIT32 (or SPLAT_BAND_RECORDS=lit for every band frame of the process): the band's
-        // composite gathers ONE 32-byte lit composite record per staged entry, written here for the splats the band keeps,
-        // instead of the exchange record + colour (+ normal).  Same image.  Measured on one MI355X with eight virtual ranks
-        // (profiles/r04_c_band_lit_records_C2.txt) it LOSES: the composite gains 2-4 us per rank (its band is an eighth of the
-        // screen), writing the records costs 21 us (the kept splats are an eighth of all, scattered: every 16-byte read and
-        // 32-byte write is a line of its own) — so it is not the default.
-        static int s_band_lit = -1;
-        if (s_band_lit < 0) {
-            const char *e = getenv("SPLAT_BAND_RECORDS");
-            s_band_lit = (e && (e[0] == 'l' || e[0] == 'L')) ? 1 : 0;
-        }
-        LitIO lio = {};
-        if (compact && !disc && (want_lit || s_band_lit)) {
-            if (n_records > binner->band_lit_cap) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                if (binner->band_lit) (void)hipFree(binner->band_lit);
-                binner->band_lit = nullptr;
-                binner->band_lit_cap = 0;
-                if (hipMalloc(&binner->band_lit, (size_t)n_records * 32 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "band lit records hipMalloc");
-                binner->band_lit_cap = n_records;
-            }
-            lio = {(const float4 *)band_color, (const float4 *)normals, band_color_stride, 1u, cfg->prelit, (float4 *)binner->band_lit};
-        }
         // A band that is a fraction of the screen keeps a fraction of the records: its prepare pass compacts them per group of
         // 4096 records and the scatter runs over the kept splats only (k_band_prepare_tfc).  Measured with virtual ranks at C2:
         // a gain from a third of the rows down (four ranks: level; eight: -10 us per rank), a loss at half of them (two ranks:
@@ -468,7 +413,7 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
             const char *e = getenv("SPLAT_BAND_COMPACT");
             s_compact = !e ? -1 : (e[0] == '0' ? 0 : 1);
         }
-        const bool compacting = !lio.records && (s_compact == 1 || (s_compact == -1 && 3u * (row1 - row0) <= nty));
+        const bool compacting = s_compact == 1 || (s_compact == -1 && 3u * (row1 - row0) <= nty);
         const uint32_t blocks = div_up(n_records, compacting ? BTC_GROUP : BTF_BLOCK);
         if (compacting && n_records > binner->band_idx_cap) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -491,13 +436,13 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
 #undef SPLAT_BAND_PREPARE_C
         } else if (disc)
             hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_DISC48>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
-                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho, lio);
+                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho);
         else if (compact)
             hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_COMPACT>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
-                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho, lio);
+                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho);
         else
             hipLaunchKernelGGL(k_band_prepare_tf<SPLAT_RECORDS_PROJECTED>, dim3(blocks), dim3(BAND_THREADS), 0, ctx->stream,
-                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho, lio);
+                               (const float4 *)records, n_records, bp, sorter->keys, binner->range32, sorter->hist, ho);
         LAUNCH_CHECK(ctx, "k_band_prepare_tf");
         stage_end(ctx, SPLAT_STAGE_PROJECT);
         binner->tf_hist_ready = true;
@@ -512,11 +457,9 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         splat_composite_cfg c2 = *cfg;
         c2.tile_row0 = row0;
         c2.tile_row1 = row1;
-        if (lio.records) c2.record_format = SPLAT_RECORDS_LIT32;
         uint32_t *report = binner->report_for_composite; // (the frame's last kernel reports it: common.h)
         binner->report_for_composite = nullptr;
-        return composite_launch(ctx, &c2, band_color, band_color_stride, normals, 1, lio.records ? (const void *)lio.records : records,
-                                binner->pairs.payload, binner->counts, binner->offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr,
+        return composite_launch(ctx, &c2, band_color, band_color_stride, normals, 1, records, binner->pairs.payload, binner->counts, binner->offsets, width, height, out_rgba8, out_rgba32f, consumed_dptr,
                                 binner->d_total, report, binner->report_seq);
     }
     sorter->kept_blocks = 0;

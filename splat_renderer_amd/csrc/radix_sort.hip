@@ -18,8 +18,8 @@
 // No inter-workgroup waiting: forward progress never depends on dispatch order (the guide's "give
 // every wave an exit condition" rule), at the price of reading the keys twice per pass.  Between
 // passes the pairs are stored interleaved (uint2) so the scatter is one 8-byte access per element.
-// A selectable onesweep mode (one chained-scan kernel per pass, the reference's structure) is kept
-// for comparison; it measures slower on MI355X (see radix_sort_pairs).
+// (A onesweep mode — one chained-scan kernel per pass, the reference's structure — was built in round 1 and measured slower
+// on MI355X: 5M keys x 4 passes 227 against 176 us; removed in round 5, profiles/EXPERIMENTS.md §4.)
 //
 // Roofline: HBM.  Algorithmic bytes per key per pass: 4 (upsweep read) + 8 (read key+payload)
 // + 8 (write) = 20; 80 B/key for the 4-pass depth sort.
@@ -196,66 +196,21 @@ struct DownsweepShared {
     uint32_t wave_gsums[RS_WAVES];
 };
 
-// ---- decoupled look-back (onesweep mode) ---------------------------------------------------------
-// status[part*256 + d] = flag (2 bits) | count (30 bits): AGGREGATE = this partition's count of digit
-// d, PREFIX = the count summed over partitions 0..part.  One 4-byte word carries flag and data, so
-// no fence is needed: it is written with one relaxed agent-scope store (global_store sc1, write-
-// through) and polled with relaxed agent-scope loads (sc1: bypass this CU's L1) — the guide's
-// "granule" hand-off.  Partition ids come from an atomic ticket, so every partition a workgroup
-// waits on belongs to a workgroup that is already running and publishes its AGGREGATE before it
-// waits on anything: the chain cannot deadlock whatever the dispatch order or residency.  The spin
-// is bounded; on timeout the error word is set and the sort result is garbage but the grid drains.
-constexpr uint32_t LB_AGGREGATE = 1u << 30, LB_PREFIX = 2u << 30, LB_VALUE = (1u << 30) - 1u;
-constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
-
-__device__ __forceinline__ uint32_t lookback(uint32_t *status, uint32_t part, uint32_t d, uint32_t dcount, uint32_t *err) {
-    uint32_t *mine = status + (size_t)part * 256 + d;
-    if (part == 0) {
-        __hip_atomic_store(mine, LB_PREFIX | dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    __hip_atomic_store(mine, LB_AGGREGATE | dcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0, spins = 0;
-    uint32_t p = part - 1;
-    for (;;) {
-        const uint32_t v = __hip_atomic_load(status + (size_t)p * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t flag = v & ~LB_VALUE;
-        if (flag == LB_PREFIX) {
-            excl += v & LB_VALUE;
-            break;
-        }
-        if (flag == LB_AGGREGATE) {
-            excl += v & LB_VALUE;
-            --p; // partition 0 always ends the walk with a PREFIX
-            continue;
-        }
-        if (++spins > LB_SPIN_LIMIT) {
-            atomicOr(err, 1u);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-    __hip_atomic_store(mine, LB_PREFIX | (excl + dcount), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
-
-template <uint32_t ITEMS, bool FULL, bool ONESWEEP, bool RANK_ATOMIC, bool IN_PAIRS = false, bool OUT_PAIRS = false>
+template <uint32_t ITEMS, bool FULL, bool RANK_ATOMIC, bool IN_PAIRS = false, bool OUT_PAIRS = false>
 __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__restrict__ s_kp, uint32_t part,
                                                const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in,
                                                uint32_t *__restrict__ keys_out, uint32_t *__restrict__ pay_out, uint32_t n,
                                                uint32_t shift, uint32_t mask, uint32_t num_parts,
                                                const uint32_t *__restrict__ scanned_hist,
-                                               const uint32_t *__restrict__ totals, uint32_t *status, uint32_t *err) {
+                                               const uint32_t *__restrict__ totals) {
     constexpr uint32_t PART_KEYS = ITEMS * RS_THREADS, WAVE_KEYS = ITEMS * 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = part * PART_KEYS;
     const uint32_t valid = FULL ? PART_KEYS : (n - base);
 
-    if (!ONESWEEP) // (onesweep: zeroed by the caller before its ticket barrier)
-        for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
-    // rowscan mode: digit tid in earlier partitions; onesweep mode: found by look-back below
-    // (digits above the mask do not occur: their rows are neither written nor read)
-    uint32_t row_prefix = (ONESWEEP || tid > mask) ? 0u : scanned_hist[(size_t)tid * num_parts + part];
+    for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
+    // digit tid in earlier partitions (digits above the mask do not occur: their rows are neither written nor read)
+    const uint32_t row_prefix = tid > mask ? 0u : scanned_hist[(size_t)tid * num_parts + part];
     const uint32_t digit_total = totals[tid]; // global count of digit tid (this pass)
 
     // striped load: item i of lane l of wave w is element w*WAVE_KEYS + i*64 + l (position order =
@@ -278,7 +233,7 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
             pay[i] = pay_in ? pay_in[base + q] : (base + q); // no payload array: the payload is the element's index
         }
     }
-    // (rowscan mode: the barrier that makes the zeroed wave_hist visible is folded into the vote below)
+    // (the barrier that makes the zeroed wave_hist visible is folded into the vote below)
 
     // ---- rank, phase A: per item, the mask of lanes of this wave holding the same digit: 8 ballots,
     // each folded in with one v_bitop3 per mask half (peers &= ~(ballot ^ mybit)).  The lowest lane
@@ -290,13 +245,13 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     uint32_t rank[ITEMS];
     // Returning LDS atomics that collide on one address serialise (64 lanes on one counter = 64 LDS
     // cycles), so a partition dominated by one digit — the top byte of depth keys — ranks faster
-    // with ballots, whose cost does not depend on the digit distribution.  Rowscan mode knows the
-    // partition's digit counts before it starts (upsweep): pick per workgroup.
+    // with ballots, whose cost does not depend on the digit distribution.  The partition's digit counts
+    // are known before it starts (upsweep): pick per workgroup.
     bool use_atomic = RANK_ATOMIC;
-    if (RANK_ATOMIC && !ONESWEEP) {
+    if (RANK_ATOMIC) {
         const uint32_t next = tid > mask ? 0u : (part + 1 < num_parts) ? scanned_hist[(size_t)tid * num_parts + part + 1] : digit_total;
         use_atomic = !__syncthreads_or((next - row_prefix) > PART_KEYS / 4); // some digit holds > 25 % of the partition
-    } else if (!ONESWEEP) {
+    } else {
         __syncthreads(); // wave_hist zeroed
     }
     if (use_atomic) {
@@ -339,7 +294,6 @@ __device__ __forceinline__ void downsweep_body(DownsweepShared &sh, uint2 *__res
     // thread d: exclusive prefix over waves for digit d, and the partition's count of d
     uint32_t c0 = sh.wave_hist[0][tid], c1 = sh.wave_hist[1][tid], c2 = sh.wave_hist[2][tid], c3 = sh.wave_hist[3][tid];
     uint32_t dcount = c0 + c1 + c2 + c3;
-    if (ONESWEEP) row_prefix = lookback(status, part, tid, dcount, err);
     // exclusive scan of dcount over the 256 digits and, in the same shuffles, of the global digit
     // totals (start of digit d in the output)
     uint32_t incl = dcount, gincl = digit_total;
@@ -416,90 +370,12 @@ __global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(ITEMS)) void k_radi
     if (part * ITEMS * RS_THREADS >= n) return; // partition past the end (device-side n)
     // every partition but (possibly) the last is full: it takes the path with no per-key bounds checks
     if ((part + 1) * ITEMS * RS_THREADS <= n)
-        downsweep_body<ITEMS, true, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
-                                           scanned_hist, totals, nullptr, nullptr);
+        downsweep_body<ITEMS, true, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+                                           scanned_hist, totals);
     else
-        downsweep_body<ITEMS, false, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
-                                            scanned_hist, totals, nullptr, nullptr);
+        downsweep_body<ITEMS, false, RANK_ATOMIC, IN_PAIRS, OUT_PAIRS>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, num_parts,
+                                            scanned_hist, totals);
 }
-
-// ---------------------------------------------------------------------------------------------
-// onesweep: one histogram kernel for all passes + one chained-scan scatter kernel per pass
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t OS_ITEMS = RS_ITEMS;                    // 4096 keys per partition
-constexpr uint32_t OS_HIST_THREADS = 512, OS_HIST_BLOCKS = 512;
-
-// ghist[pass*256 + d] += number of keys whose digit of pass `pass` is d.  Global digit totals do
-// not depend on the order of the keys, so all passes are counted from the unsorted input at once.
-__global__ __launch_bounds__(OS_HIST_THREADS) void k_radix_hist(const uint32_t *__restrict__ keys, uint32_t n,
-                                                                uint32_t bit_begin, uint32_t bit_end,
-                                                                uint32_t *__restrict__ ghist) {
-    __shared__ uint32_t lh[4][256];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 1024; i += OS_HIST_THREADS) (&lh[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t passes = (bit_end - bit_begin + 7) / 8;
-    const uint32_t n4 = n / 4;
-    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
-    for (uint32_t i = blockIdx.x * OS_HIST_THREADS + tid; i < n4; i += OS_HIST_BLOCKS * OS_HIST_THREADS) {
-        const uint4 v = k4[i];
-        for (uint32_t ps = 0; ps < passes; ++ps) {
-            const uint32_t shift = bit_begin + 8 * ps;
-            const uint32_t mask = (bit_end - shift < 8) ? ((1u << (bit_end - shift)) - 1u) : 255u;
-            const uint32_t a = (v.x >> shift) & mask, b = (v.y >> shift) & mask, c = (v.z >> shift) & mask,
-                           d = (v.w >> shift) & mask;
-            // depth keys have a near-constant top byte: four equal digits become one LDS atomic
-            if (a == b && b == c && c == d) {
-                atomicAdd(&lh[ps][a], 4u);
-            } else {
-                atomicAdd(&lh[ps][a], 1u);
-                atomicAdd(&lh[ps][b], 1u);
-                atomicAdd(&lh[ps][c], 1u);
-                atomicAdd(&lh[ps][d], 1u);
-            }
-        }
-    }
-    if (blockIdx.x == 0 && tid < (n & 3u)) { // tail keys
-        const uint32_t k = keys[n4 * 4 + tid];
-        for (uint32_t ps = 0; ps < passes; ++ps) {
-            const uint32_t shift = bit_begin + 8 * ps;
-            const uint32_t mask = (bit_end - shift < 8) ? ((1u << (bit_end - shift)) - 1u) : 255u;
-            atomicAdd(&lh[ps][(k >> shift) & mask], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < passes * 256; i += OS_HIST_THREADS) {
-        const uint32_t c = (&lh[0][0])[i];
-        if (c) atomicAdd(&ghist[i], c);
-    }
-}
-
-__global__ __launch_bounds__(RS_THREADS, downsweep_wg_per_cu(OS_ITEMS)) void k_radix_onesweep(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ pay_in, uint32_t *__restrict__ keys_out,
-    uint32_t *__restrict__ pay_out, uint32_t n, uint32_t shift, uint32_t mask, const uint32_t *__restrict__ ghist,
-    uint32_t *status, uint32_t *ticket, uint32_t *err) {
-    __shared__ DownsweepShared sh;
-    __shared__ uint2 s_kp[OS_ITEMS * RS_THREADS];
-    __shared__ uint32_t s_part;
-    if (threadIdx.x == 0) s_part = atomicAdd(ticket, 1u); // partition id = order of arrival
-    for (uint32_t i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t part = s_part;
-    if ((part + 1) * OS_ITEMS * RS_THREADS <= n)
-        downsweep_body<OS_ITEMS, true, true, false>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
-                                             status, err);
-    else
-        downsweep_body<OS_ITEMS, false, true, false>(sh, s_kp, part, keys_in, pay_in, keys_out, pay_out, n, shift, mask, 0, nullptr, ghist,
-                                              status, err);
-}
-
-// Default mode: 0 = upsweep/rowscan/downsweep.  1 = onesweep is kept selectable (per sorter with
-// splat_sort_set_mode, or SPLAT_RADIX_MODE=onesweep for everything) because it is the reference's own
-// structure, but measured on MI355X it loses: 5M keys x 4 passes 227 us vs 176 us, 11.3M pairs x 2
-// passes 224 us vs 187 us (tools/sort_bench.py).  With ~1000 workgroups starting together the
-// look-back walks long chains of AGGREGATEs at ~1 us per cross-XCD hop, which costs more per pass
-// (+23 us) than the upsweep + rowscan it removes (18 us).
-static int g_radix_mode = -1;
 
 static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
                               const uint32_t *n_dev, uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary,
@@ -571,33 +447,6 @@ static int radix_sort_rowscan(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows) {
     hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(ROWSCAN_THREADS), 0, ctx->stream, hist, parts, hist + (size_t)256 * parts, rows);
     LAUNCH_CHECK(ctx, "k_radix_rowscan");
-    return SPLAT_OK;
-}
-
-// workspace layout (u32 words) for onesweep: [0,1024) global histograms of up to 4 passes,
-// [1024,1028) tickets, [1028] error word, pad to 1280, then status[pass][part][256]
-static int radix_sort_onesweep(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *ws, uint32_t n,
-                               uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary) {
-    const uint32_t passes = (bit_end - bit_begin + 7) / 8;
-    const uint32_t parts = div_up(n, OS_ITEMS * RS_THREADS);
-    uint32_t *ghist = ws, *tickets = ws + 1024, *err = ws + 1028, *status = ws + 1280;
-    HIP_TRY(ctx, hipMemsetAsync(ws, 0, ((size_t)1280 + (size_t)passes * parts * 256) * 4, ctx->stream));
-    hipLaunchKernelGGL(k_radix_hist, dim3(OS_HIST_BLOCKS), dim3(OS_HIST_THREADS), 0, ctx->stream, k0, n, bit_begin, bit_end, ghist);
-    LAUNCH_CHECK(ctx, "k_radix_hist");
-    uint32_t *ki = k0, *pi = p0, *ko = k1, *po = p1;
-    bool primary = true;
-    for (uint32_t ps = 0; ps < passes; ++ps) {
-        const uint32_t shift = bit_begin + 8 * ps;
-        const uint32_t bits = bit_end - shift < 8 ? bit_end - shift : 8;
-        const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_radix_onesweep, dim3(parts), dim3(RS_THREADS), 0, ctx->stream, ki, pi, ko, po, n, shift, mask,
-                           ghist + ps * 256, status + (size_t)ps * parts * 256, tickets + ps, err);
-        LAUNCH_CHECK(ctx, "k_radix_onesweep");
-        uint32_t *t = ki; ki = ko; ko = t;
-        t = pi; pi = po; po = t;
-        primary = !primary;
-    }
-    *result_in_primary = primary;
     return SPLAT_OK;
 }
 
@@ -692,26 +541,13 @@ int ctx_resolve_rank_mode(splat_ctx *ctx) {
 int radix_sort_pairs(splat_ctx *ctx, uint32_t *k0, uint32_t *p0, uint32_t *k1, uint32_t *p1, uint32_t *hist, uint32_t n,
                      uint32_t bit_begin, uint32_t bit_end, bool *result_in_primary, int mode, const uint32_t *n_dev,
                      bool iota_payload, uint32_t first_bits) {
-    if (g_radix_mode < 0) {
-        g_radix_mode = 0;
-        if (const char *e = getenv("SPLAT_RADIX_MODE")) g_radix_mode = (e[0] == 'o' || e[0] == '1') ? 1 : 0;
-    }
     *result_in_primary = true;
     if (n == 0 || bit_end <= bit_begin) return SPLAT_OK;
     if (n >= (1u << 30)) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: n must be below 2^30");
-    if (mode < 0) mode = g_radix_mode;
     if (first_bits < 1 || first_bits > 8) return ctx_fail(ctx, SPLAT_ERR_INVALID, "radix sort: first_bits must be 1..8");
-    if ((n_dev || iota_payload || first_bits != 8) && mode == 1) mode = 0; // these need the rowscan kernels
-    if (mode == 1) return radix_sort_onesweep(ctx, k0, p0, k1, p1, hist, n, bit_begin, bit_end, result_in_primary);
+    // mode: -1 / 0 = rank as the context's policy says; 2 = always with ballots
     return radix_sort_rowscan(ctx, k0, p0, k1, p1, hist, n, n_dev, bit_begin, bit_end, result_in_primary, iota_payload, mode == 2,
                               (uint32_t)(p0 - k0), first_bits);
-}
-
-// the look-back's timeout word (workspace word 1028): non-zero after a sort = a chained scan gave up
-int radix_sort_error_word(splat_ctx *ctx, const uint32_t *hist, uint32_t *value) {
-    HIP_TRY(ctx, hipMemcpyAsync(value, hist + 1028, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SPLAT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,11 +570,8 @@ int sorter_reserve(splat_sorter *s, uint32_t capacity) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     sorter_free(s);
     size_t bytes = (size_t)padded * 4;
-    // rowscan mode: 256 rows of one count per partition + the 256 row totals; onesweep mode:
-    // 1280 header words + status words of 4 passes
-    size_t hist_a = ((size_t)256 * div_up((uint32_t)padded, RS_PART_KEYS) + 256) * 4;
-    size_t hist_b = ((size_t)1280 + (size_t)4 * div_up((uint32_t)padded, OS_ITEMS * RS_THREADS) * 256) * 4;
-    size_t hist_bytes = hist_a > hist_b ? hist_a : hist_b;
+    // 256 rows of one count per partition + the 256 row totals
+    const size_t hist_bytes = ((size_t)256 * div_up((uint32_t)padded, RS_PART_KEYS) + 256) * 4;
     // keys|payload of each ping-pong side are ONE allocation (payload = keys + padded): between passes
     // the sort stores interleaved (key, payload) pairs over the whole of it
     if (hipMalloc((void **)&s->keys, 2 * bytes) != hipSuccess || hipMalloc((void **)&s->keys_b, 2 * bytes) != hipSuccess ||
@@ -814,8 +647,8 @@ void *splat_sort_sorted_payload(splat_sorter *s) {
 
 int splat_sort_set_mode(splat_sorter *s, int mode) {
     if (!s) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "sorter is NULL");
-    if (mode < -1 || mode > 2)
-        return ctx_fail(s->ctx, SPLAT_ERR_INVALID, "sort mode must be -1 (default), 0 (rowscan), 1 (onesweep) or 2 (rowscan, ballot ranking)");
+    if (mode != -1 && mode != 0 && mode != 2)
+        return ctx_fail(s->ctx, SPLAT_ERR_INVALID, "sort mode must be -1 (default), 0 (rank as the context's policy says) or 2 (always ballot ranking)");
     s->mode = mode;
     return SPLAT_OK;
 }
@@ -830,25 +663,26 @@ int splat_rank_status(splat_ctx *ctx, int *policy, int *atomics_ordered, uint32_
     return SPLAT_OK;
 }
 
-int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict, int slack) {
+int splat_composite_options(splat_ctx *ctx, int kernel, int ahead, int predict) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ARG_CHECK(ctx, kernel >= -1 && kernel <= 1 && ahead >= 0 && ahead <= 2 && predict >= -1 && predict <= 1 && slack >= -1 && slack <= 1024);
+    ARG_CHECK(ctx, kernel >= -1 && kernel <= 1 && ahead >= 0 && ahead <= 2 && predict >= -1 && predict <= 1);
     ctx->opt_composite_kernel = kernel;
     ctx->opt_px_ahead = ahead;
     ctx->opt_px_predict = predict;
-    ctx->opt_px_slack = slack;
-    ctx->px_key = 0; // (another schedule: its costs mean something else)
-    ctx->px_streak = 0;
-    return SPLAT_OK;
+    return splat_composite_forget_history(ctx); // (another schedule: its costs mean something else)
 }
 
 int splat_composite_forget_history(splat_ctx *ctx) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
-    ctx->px_key = 0;
-    ctx->px_streak = 0;
+    for (auto &h : ctx->px_hist) { // (the arrays stay: a slot's next launch starts a new streak in them)
+        h.key = 0;
+        h.streak = 0;
+        h.last_use = 0;
+    }
     return SPLAT_OK;
 }
 
+#ifdef SPLAT_TEST_HOOKS // (the test build only: include/splat.h)
 int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ctx->debug_sort_order = (const uint32_t *)order_dptr;
@@ -869,18 +703,11 @@ int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t posit
     ctx->inject_order_position = position;
     return SPLAT_OK;
 }
+#endif
 
 int splat_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches) {
     if (!ctx || !mismatches) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx/mismatches is NULL");
     return radix_probe_lds_atomic_order(ctx, mismatches);
-}
-
-int splat_sort_lookback_timeouts(splat_sorter *s, uint32_t *flag) {
-    if (!s || !flag) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "sorter/flag is NULL");
-    *flag = 0;
-    const int mode = s->mode < 0 ? g_radix_mode : s->mode;
-    if (mode != 1 || !s->ran) return SPLAT_OK; // only the onesweep mode has a look-back (and the word)
-    return radix_sort_error_word(s->ctx, s->hist, flag);
 }
 
 void *splat_sort_sorted_keys(splat_sorter *s) {

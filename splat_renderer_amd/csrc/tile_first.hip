@@ -64,45 +64,6 @@ struct TileSortShared {
     uint32_t kmin, kmax;
 };
 
-// The WIDE in-LDS path (round 3): digits of up to 12 bits — TWO passes for the 22..24-bit key ranges of the bench sizes'
-// tiles instead of three.  Every wave ranks into its own table of 4096 16-bit counters, two per word (counts and positions
-// of a list that fits LDS stay below 65536, so a half never carries into its neighbour).
-constexpr uint32_t TSW_MAX_BITS = 12, TSW_WORDS = (1u << TSW_MAX_BITS) / 2;
-constexpr uint32_t TSW_LDS_ELEMS = 5888; // 46 KiB + 32 KiB of counters: two workgroups in a CU's 160 KiB
-struct TileSortWide {
-    uint32_t h[TS_WAVES][TSW_WORDS]; // per wave, as the byte passes' tables
-    uint32_t wave_sums[TS_WAVES];
-    uint32_t kmin, kmax;
-};
-union TileSortLds {
-    TileSortShared sh;
-    TileSortWide wd;
-};
-
-// rank of this lane's element among the elements of the same digit seen so far by this wave (wave_rank above, for the
-// packed 16-bit counters and digits of `bits` bits)
-template <bool RANK_ATOMIC>
-__device__ __forceinline__ uint32_t wide_take(uint32_t *h, uint32_t d, uint32_t bits) {
-    const uint32_t sh16 = (d & 1u) << 4;
-    if (RANK_ATOMIC) return (atomicAdd(&h[d >> 1], 1u << sh16) >> sh16) & 0xffffu;
-    const uint64_t active = __ballot(true); // callers take under `if (p < n)`: peers are active lanes only
-    uint32_t plo = (uint32_t)active, phi = (uint32_t)(active >> 32);
-#pragma unroll
-    for (uint32_t b = 0; b < TSW_MAX_BITS; ++b) {
-        if (b < bits) { // (uniform)
-            const uint32_t m = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
-            const uint64_t bal = __ballot(m != 0);
-            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);
-            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
-        }
-    }
-    const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0));
-    const uint32_t leader = plo ? (uint32_t)__builtin_ctz(plo) : 32u + (uint32_t)__builtin_ctz(phi);
-    uint32_t prev = 0;
-    if (below == 0) prev = atomicAdd(&h[d >> 1], (uint32_t)(__popc(plo) + __popc(phi)) << sh16);
-    return (((uint32_t)__shfl((int)prev, (int)leader) >> sh16) & 0xffffu) + below;
-}
-
 // rank of this lane's element among the elements of the same digit seen so far by this wave
 // (earlier instructions, then lower lanes), adding it to the wave's digit counter
 template <bool RANK_ATOMIC>
@@ -459,201 +420,39 @@ __device__ __forceinline__ void tile_list_out(uint2 *s_el, uint32_t n, uint32_t 
     if (__any(bad) && lane == 0) atomicOr(frame_flags, FRAME_FLAG_ORDER);
 }
 
-template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS, bool WIDE>
-__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? (WIDE ? 3 : 6) : TS_MAX_ITEMS <= 12 ? (WIDE ? 2 : 5) : TS_MAX_ITEMS <= 16 ? (WIDE ? 2 : 4) : (WIDE ? 2 : 3)) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
+// The test build (-DSPLAT_TEST_HOOKS, libsplat_hip_hooks.so: tests/ only) gives the kernel three more parameters: the tile whose
+// finished list gets two neighbours swapped before the order check, where, and a dispatch order for the workgroups.  The shipped
+// kernels do not carry them.
+#ifdef SPLAT_TEST_HOOKS
+#define TS_HOOK_PARAMS , uint32_t inject_tile, uint32_t inject_pos, const uint32_t *__restrict__ order
+#define TS_HOOK_ARGS , inject, inject_pos, ctx->debug_sort_order
+#else
+#define TS_HOOK_PARAMS
+#define TS_HOOK_ARGS
+#endif
+template <bool RANK_ATOMIC, uint32_t TS_MAX_ITEMS, bool LAST_CLASS>
+__global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <= 12 ? 5 : TS_MAX_ITEMS <= 16 ? 4 : 3) void k_tile_sort(const uint32_t *__restrict__ offsets, uint32_t tiles,
                                                                                     uint32_t n_above, uint2 *vals, uint2 *scratch,
                                                                                     uint32_t *__restrict__ out_idx,
                                                                                     uint32_t *__restrict__ counts,
-                                                                                    uint32_t *__restrict__ frame_flags,
-                                                                                    uint32_t inject_tile, uint32_t inject_pos,
-                                                                                    const uint32_t *__restrict__ order) {
+                                                                                    uint32_t *__restrict__ frame_flags TS_HOOK_PARAMS) {
     static_assert(TS_MAX_ITEMS % 4 == 0, "items are processed in groups of four");
-    constexpr uint32_t TS_FIT = WIDE ? TSW_LDS_ELEMS : TS_LDS_ELEMS;
-    constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_FIT ? TS_MAX_ITEMS * TS_THREADS : TS_FIT;
-    // (the wide path's table and the byte passes' tables are never live together; the byte-pass build holds only its own)
-    __shared__ __align__(16) uint32_t lds_raw[(WIDE ? sizeof(TileSortLds) : sizeof(TileSortShared)) / 4];
-    TileSortShared &sh = *reinterpret_cast<TileSortShared *>(lds_raw);
+    constexpr uint32_t TS_CAP = TS_MAX_ITEMS * TS_THREADS < TS_LDS_ELEMS ? TS_MAX_ITEMS * TS_THREADS : TS_LDS_ELEMS;
+    __shared__ TileSortShared sh;
     __shared__ uint2 s_el[TS_CAP];
     uint32_t *run_base = reinterpret_cast<uint32_t *>(s_el); // long-list path (s_el unused there): start of each digit's run
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t t = order ? order[blockIdx.x] : blockIdx.x; // (experiment hook splat_debug_set_tile_sort_order: any permutation gives the same lists)
+#ifdef SPLAT_TEST_HOOKS
+    const uint32_t t = order ? order[blockIdx.x] : blockIdx.x; // (splat_debug_set_tile_sort_order: any permutation gives the same lists)
+#else
+    const uint32_t t = blockIdx.x;
+    constexpr uint32_t inject_tile = 0xffffffffu, inject_pos = 0; // (no tile is the victim: the swap below folds away)
+#endif
     const uint32_t base = offsets[t], n = offsets[t + 1] - base;
     if (counts && tid == 0) counts[t] = n; // (first launch: the tile counts the composite reads)
     if (n <= n_above || (!LAST_CLASS && n > TS_CAP)) return; // empty, or another class's tile
     uint2 *src = vals + base, *dst = scratch + base;
     const bool in_lds = !LAST_CLASS || n <= TS_CAP;
-
-    if (WIDE && in_lds) {
-        // ---- the wide path: passes of up to 12 bits ------------------------------------------------------------------
-        // What a pass costs is its returning LDS atomics: the LDS serves them at about one LANE per cycle (a 64-lane
-        // instruction ~64 cycles; a read, a lookup or a scattered 8-byte write 4-8), so an element costs ~64 lane-cycles per
-        // pass whatever else the pass does — measured three ways: the byte passes' time per tile is 3 x n cycles + 30 %;
-        // halving the bytes per element or adding a resident workgroup changed nothing (round 2); a variant of this path
-        // with ONE table shared by the waves (a counting add and a returning add per element and pass: 4 atomics per
-        // element of a 24-bit tile instead of 3) took 106 us where the byte passes take 56 (profiles/r03_f_*).
-        // So: the byte passes' structure — every wave ranks into its own table with ONE returning add per element — with
-        // digits of up to 12 bits: two passes for the 22..24-bit key ranges of the bench sizes' tiles instead of three.  The
-        // first pass ranks straight from the registers the pairs were loaded into.
-        TileSortWide &wd = *reinterpret_cast<TileSortWide *>(lds_raw);
-        if (tid == 0) {
-            wd.kmin = 0xffffffffu;
-            wd.kmax = 0;
-        }
-        const uint32_t items = ((n + TS_THREADS - 1) / TS_THREADS + 3u) & ~3u;
-        const uint32_t wbase = w * items * 64 + lane;
-        uint2 el[TS_MAX_ITEMS];
-#pragma unroll
-        for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-            if (g < items) {
-#pragma unroll
-                for (uint32_t i = g; i < g + 4; ++i) {
-                    const uint32_t p = wbase + i * 64;
-                    el[i] = src[p < n ? p : n - 1]; // (all of a thread's loads in flight at once; padding re-reads the last pair)
-                }
-            }
-        }
-        uint32_t lo = 0xffffffffu, hi = 0;
-#pragma unroll
-        for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-            if (g < items) {
-#pragma unroll
-                for (uint32_t i = g; i < g + 4; ++i) {
-                    lo = min(lo, el[i].x);
-                    hi = max(hi, el[i].x);
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
-        }
-        __syncthreads();
-        if (lane == 0) {
-            atomicMin(&wd.kmin, lo);
-            atomicMax(&wd.kmax, hi);
-        }
-        __syncthreads();
-        const uint32_t kmin = wd.kmin, range = wd.kmax - kmin;
-        const uint32_t bits = range == 0 ? 0u : 32u - (uint32_t)__builtin_clz(range);
-        const uint32_t passes = (bits + TSW_MAX_BITS - 1) / TSW_MAX_BITS;
-        const uint32_t dbits = passes ? (bits + passes - 1) / passes : 0u; // <= 12
-        const uint32_t dmask = (1u << dbits) - 1u;
-        const uint32_t words = dbits ? ((1u << dbits) + 1u) / 2u : 0u; // words of a wave's table in use (two 16-bit counters each)
-        const bool owner = tid * 8u < words;                             // this thread scans digits [16 tid, 16 tid + 16)
-        uint32_t *hw = wd.h[w];
-        if (passes == 0) { // every key equal: the list is in order as it stands
-#pragma unroll
-            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-                if (g < items) {
-#pragma unroll
-                    for (uint32_t i = g; i < g + 4; ++i)
-                        if (wbase + i * 64 < n) s_el[wbase + i * 64] = el[i];
-                }
-            }
-            __syncthreads();
-        }
-        for (uint32_t pass = 0; pass < passes; ++pass) {
-            const uint32_t shift = pass * dbits;
-            uint32_t wb = wbase, km = kmin; // (opaque per pass: hoisted out of the loop, every item's digit, address and bound would
-            asm volatile("" : "+v"(wb));    //  live in a register of its own, and a spill in here is a round trip to memory per pass)
-            asm volatile("" : "+s"(km));
-            if (owner) {
-#pragma unroll
-                for (uint32_t v = 0; v < TS_WAVES; ++v) {
-                    uint4 *hv = reinterpret_cast<uint4 *>(wd.h[v]) + tid * 2;
-                    hv[0] = make_uint4(0, 0, 0, 0);
-                    hv[1] = make_uint4(0, 0, 0, 0);
-                }
-            }
-            if (pass > 0) { // (the first pass's elements are in registers already)
-#pragma unroll
-                for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-                    if (g < items) {
-#pragma unroll
-                        for (uint32_t i = g; i < g + 4; ++i) {
-                            const uint32_t p = wb + i * 64;
-                            el[i] = s_el[p < n ? p : n - 1];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // rank: the element's number among its wave's earlier elements of the same digit (16-bit counter of the pair in the word)
-            uint32_t rank[TS_MAX_ITEMS];
-#pragma unroll
-            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-                if (g < items) {
-#pragma unroll
-                    for (uint32_t i = g; i < g + 4; ++i) {
-                        const uint32_t d = ((el[i].x - km) >> shift) & dmask;
-                        rank[i] = 0;
-                        if (wb + i * 64 < n) rank[i] = wide_take<RANK_ATOMIC>(hw, d, dbits);
-                    }
-                }
-            }
-            __syncthreads();
-            // counts -> first positions: digit d's run starts at the exclusive scan of the digit totals, wave v's elements of
-            // digit d follow those of the waves before it; both folded into the wave's own table (one lookup per element)
-            uint32_t tab[TS_WAVES][8]; // packed, relative to this thread's first digit
-            uint32_t total = 0;
-            if (owner) {
-#pragma unroll
-                for (uint32_t half = 0; half < 2; ++half) {
-                    uint4 q[TS_WAVES];
-#pragma unroll
-                    for (uint32_t v = 0; v < TS_WAVES; ++v) q[v] = (reinterpret_cast<const uint4 *>(wd.h[v]) + tid * 2)[half];
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) {
-                        uint32_t cw[TS_WAVES];
-#pragma unroll
-                        for (uint32_t v = 0; v < TS_WAVES; ++v) cw[v] = j == 0 ? q[v].x : j == 1 ? q[v].y : j == 2 ? q[v].z : q[v].w;
-                        uint32_t b0[TS_WAVES], b1[TS_WAVES];
-#pragma unroll
-                        for (uint32_t v = 0; v < TS_WAVES; ++v) { // even digit of the word
-                            b0[v] = total;
-                            total += cw[v] & 0xffffu;
-                        }
-#pragma unroll
-                        for (uint32_t v = 0; v < TS_WAVES; ++v) { // odd digit
-                            b1[v] = total;
-                            total += cw[v] >> 16;
-                        }
-#pragma unroll
-                        for (uint32_t v = 0; v < TS_WAVES; ++v) tab[v][half * 4 + j] = b0[v] | (b1[v] << 16);
-                    }
-                }
-            }
-            const uint32_t excl = ts_scan256(wd.wave_sums, total, tid) * 0x10001u; // (positions stay below 65536: no carry between halves)
-            if (owner) {
-#pragma unroll
-                for (uint32_t v = 0; v < TS_WAVES; ++v) {
-                    uint4 *hv = reinterpret_cast<uint4 *>(wd.h[v]) + tid * 2;
-                    hv[0] = make_uint4(tab[v][0] + excl, tab[v][1] + excl, tab[v][2] + excl, tab[v][3] + excl);
-                    hv[1] = make_uint4(tab[v][4] + excl, tab[v][5] + excl, tab[v][6] + excl, tab[v][7] + excl);
-                }
-            }
-            __syncthreads();
-            // reorder in place (every element is in registers)
-#pragma unroll
-            for (uint32_t g = 0; g < TS_MAX_ITEMS; g += 4) {
-                if (g < items) {
-                    uint32_t pos[4];
-#pragma unroll
-                    for (uint32_t i = g; i < g + 4; ++i) {
-                        const uint32_t d = ((el[i].x - km) >> shift) & dmask;
-                        pos[i - g] = ((hw[d >> 1] >> ((d & 1u) << 4)) & 0xffffu) + rank[i];
-                    }
-#pragma unroll
-                    for (uint32_t i = g; i < g + 4; ++i)
-                        if (wb + i * 64 < n) s_el[pos[i - g]] = el[i];
-                }
-            }
-            __syncthreads();
-        }
-        tile_list_out(s_el, n, out_idx + base, frame_flags, t == inject_tile, inject_pos, tid);
-        return;
-    }
 
     if (tid == 0) {
         sh.kmin = 0xffffffffu;
@@ -844,18 +643,16 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
         if (prc != SPLAT_OK) return prc;
     }
     const bool ra = rank_atomic_ok(ctx, true); // (every list is checked below: atomics are allowed here by default)
+#ifdef SPLAT_TEST_HOOKS
     const uint32_t inject = ctx->inject_order_fault ? ctx->inject_order_fault - 1u : 0xffffffffu; // one-shot test hook
     const uint32_t inject_pos = ctx->inject_order_position;
     ctx->inject_order_fault = 0;
+#endif
     // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
     // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
     // a tenth of a C0 frame).
-    // (SPLAT_TILE_SORT_CLASSES=1 / =2 force one launch / two launches: measuring knob, profiles/r03_j_tile_sort_one_launch_C2.txt)
-    static const int force_classes = [] {
-        const char *e = getenv("SPLAT_TILE_SORT_CLASSES");
-        return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
-    }();
-    const bool one_class = force_classes ? force_classes == 1 : tiles <= 3u * 256u;
+    // (forcing one launch at C2: slower, profiles/r03_j_tile_sort_one_launch_C2.txt)
+    const bool one_class = tiles <= 3u * 256u;
     // The short class's size, by the frame's mean list length (measured, `bin_tile_sort` with 8 | 12 | 16 elements per thread:
     // C1, mean 570: 45.6 | 41.4 | 45.9 us; C3, mean 910: 193 | 180 | 188; C2, mean 1380: 77.0 | 76.6 | 72.9 — and a third
     // class in between loses its launch: profiles/r04_u_tile_sort_classes.txt).  SPLAT_TILE_SORT_SHORT=8 | 12 | 16 forces one.
@@ -866,22 +663,15 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     }();
     const uint32_t short_items = force_short ? force_short : mean_list < 320u ? 8u : mean_list < 1152u ? 12u : 16u;
     const uint32_t short_cap = short_items * TS_THREADS;
-    // SPLAT_TILE_SORT_DIGITS=12: the wide passes (two of up to 12 bits instead of three of 8; built and measured in round 3:
-    // slower — 76 + 33 us against 56 + 23 at C2, profiles/r03_f_tile_sort_wide_digits_C2.txt — kept selectable, and tested)
-    if (ctx->tile_sort_digits == 0) {
-        const char *e = getenv("SPLAT_TILE_SORT_DIGITS");
-        ctx->tile_sort_digits = (e && e[0] == '1' && e[1] == '2' && e[2] == 0) ? 12 : 8;
-    }
-    const bool wide = ctx->tile_sort_digits == 12;
-#define SPLAT_TILE_SORT_(RA, ITEMS, LAST, WIDE, ABOVE, COUNTS)                                                                       \
-    hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST, WIDE>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, \
-                       scratch, out_idx, COUNTS, frame_flags, inject, inject_pos, ctx->debug_sort_order)
-#define SPLAT_TILE_SORT(ITEMS, LAST, ABOVE, COUNTS)                          \
-    do {                                                                     \
-        if (ra && wide) SPLAT_TILE_SORT_(true, ITEMS, LAST, true, ABOVE, COUNTS);   \
-        else if (ra) SPLAT_TILE_SORT_(true, ITEMS, LAST, false, ABOVE, COUNTS);     \
-        else if (wide) SPLAT_TILE_SORT_(false, ITEMS, LAST, true, ABOVE, COUNTS);   \
-        else SPLAT_TILE_SORT_(false, ITEMS, LAST, false, ABOVE, COUNTS);            \
+    // (two passes of up to 12 bits instead of three of 8 — SPLAT_TILE_SORT_DIGITS=12 in rounds 3 and 4 — measured slower, 76 + 33
+    // against 56 + 23 us at C2: profiles/r03_f_tile_sort_wide_digits_C2.txt; removed in round 5)
+#define SPLAT_TILE_SORT_(RA, ITEMS, LAST, ABOVE, COUNTS)                                                                       \
+    hipLaunchKernelGGL((k_tile_sort<RA, ITEMS, LAST>), dim3(tiles), dim3(TS_THREADS), 0, ctx->stream, offsets, tiles, ABOVE, vals, \
+                       scratch, out_idx, COUNTS, frame_flags TS_HOOK_ARGS)
+#define SPLAT_TILE_SORT(ITEMS, LAST, ABOVE, COUNTS)                  \
+    do {                                                             \
+        if (ra) SPLAT_TILE_SORT_(true, ITEMS, LAST, ABOVE, COUNTS);  \
+        else SPLAT_TILE_SORT_(false, ITEMS, LAST, ABOVE, COUNTS);    \
     } while (0)
     if (one_class) {
         SPLAT_TILE_SORT(TS_LONG_ITEMS, true, 0u, counts);

@@ -183,15 +183,13 @@ class HipStages:
     def project_slice(self, uniforms, props_ptr, first, count, out_records, normals_ptr=None):
         _project_slice(self.lib, self.ctx, self.disc, uniforms, props_ptr, normals_ptr, first, count, out_records)
 
-    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False, lit_records=False):
+    def band_frame(self, records, n_records, props_ptr, normals_ptr, row0, row1, out_image, settle=False):
         """settle=False (frame loops): sync-free; a frame whose pairs outgrew 1.5x the previous frame's
         is only noticed at the next call (which then has room).  settle=True: wait for this frame's pair
         total and render it again if it overflowed — results are final on return."""
         prelit = self.lit is not None
-        # lit_records: the band builds 32-byte lit composite records for the splats it keeps and composites from those (one
-        # gathered line per staged entry instead of two or three; same image; measured slower on eight ranks — splat.h)
         cfg = CompositeCfg(self.mode, int(self.early_out), self.tile, row0, row1,
-                           _lib.RECORDS_DISC48 if self.disc else _lib.RECORDS_LIT32 if lit_records else _lib.RECORDS_COMPACT, int(prelit),
+                           _lib.RECORDS_DISC48 if self.disc else _lib.RECORDS_COMPACT, int(prelit),
                            _lib.FOOTPRINT_DISC if self.disc else _lib.FOOTPRINT_ISOTROPIC)
         if prelit:
             props_ptr, normals_ptr = self.lit.data_ptr(), None

@@ -103,6 +103,10 @@ class Device:
         self.ctx = p
         self.ordinal = ordinal
         self.queue = _Queue(self)
+        # the SplatProjector and GPUTileBinner that last ran on this device (their project() / binSplats(), or a Renderer's
+        # frame): what TileRenderer.render — whose reference signature names neither — composites from unless told otherwise
+        self.lastProjector = None
+        self.lastBinner = None
 
     def createBuffer(self, size):
         p = C.c_void_p()
@@ -145,17 +149,17 @@ class Device:
         no look-ahead bound from an earlier launch's per-tile costs)."""
         check(self.lib.splat_composite_forget_history(self.ctx), self.ctx)
 
-    def compositeOptions(self, kernel=None, ahead=0, predict=None, slack=None):
-        """splat_composite_options: kernel None (library default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict None |
-        False | True; slack None | chunks.  ahead / predict / slack change the schedule only (same bytes); the two kernels agree within
-        the composite's stated tolerance."""
+    def compositeOptions(self, kernel=None, ahead=0, predict=None):
+        """splat_composite_options: kernel None (process default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict None |
+        False | True.  EVERY call sets all three (None / 0 = the process default, i.e. the environment's — not "as it was"); a choice
+        made here takes precedence over the environment variable.  ahead / predict change the schedule only (same bytes); the two
+        kernels agree within the composite's stated tolerance."""
         k = -1 if kernel is None else {"quadrant": 0, "pixel": 1}[kernel]
-        check(self.lib.splat_composite_options(self.ctx, k, int(ahead), -1 if predict is None else int(bool(predict)),
-                                               -1 if slack is None else int(slack)), self.ctx)
+        check(self.lib.splat_composite_options(self.ctx, k, int(ahead), -1 if predict is None else int(bool(predict))), self.ctx)
 
     def injectOrderFault(self, tile, position=0):
-        """TEST HOOK (splat_debug_inject_order_fault): the next per-tile sort leaves entries position, position + 1 of tile
-        `tile`'s list swapped."""
+        """TEST HOOK (splat_debug_inject_order_fault; the test build of the library only: SPLAT_LIB_PATH=libsplat_hip_hooks.so):
+        the next per-tile sort leaves entries position, position + 1 of tile `tile`'s list swapped."""
         check(self.lib.splat_debug_inject_order_fault(self.ctx, int(tile), int(position)), self.ctx)
 
     def destroy(self):
@@ -374,6 +378,8 @@ class SplatProjector:
             raise SplatError(-1, "uniform block needs 22 floats (VP, eye, time, screenW, screenH)")
         uptr = u.ctypes.data_as(C.POINTER(C.c_float))
         keys, payload = keysBuffer.ptr if keysBuffer else None, payloadBuffer.ptr if payloadBuffer else None
+        d.lastProjector = self
+        self.contents = "projected"
         if self.footprint == _lib.FOOTPRINT_DISC:
             if normalsBuffer is None:
                 raise SplatError(-1, "SplatProjector(footprint='disc').project needs normalsBuffer")
@@ -404,6 +410,8 @@ class SplatProjector:
         return self.discBuffer
 
     def destroy(self):  # :200-202
+        if self.device.lastProjector is self:
+            self.device.lastProjector = None
         self.projectedBuffer.destroy()
         if self.discBuffer is not None:
             self.discBuffer.destroy()
@@ -440,13 +448,8 @@ class RadixSorter:
         check(d.lib.splat_sort_run(self._s, n, bitBegin, bitEnd), d.ctx)
 
     def setMode(self, mode):
-        """0 = histogram + row scan + scatter per pass (default), 1 = onesweep / decoupled look-back."""
+        """0 = rank equal digits as the context's policy says (default), 2 = always with ballots."""
         check(self.device.lib.splat_sort_set_mode(self._s, mode), self.device.ctx)
-
-    def lookbackTimeouts(self):
-        f = C.c_uint32()
-        check(self.device.lib.splat_sort_lookback_timeouts(self._s, C.byref(f)), self.device.ctx)
-        return int(f.value)
 
     def getSortedIndicesBuffer(self):  # :269-271
         return Buffer(self.device, self.device.lib.splat_sort_sorted_payload(self._s), self.paddedSize * 4, owned=False)
@@ -502,6 +505,7 @@ class GPUTileBinner:
         check(d.lib.splat_bin_run(self._b, projectedBuffer.ptr, numSplats, sortedIndicesBuffer.ptr, n_sorted, screenWidth,
                                   screenHeight, tileRow0, tileRow1), d.ctx)
         self._tiles = -(-screenWidth // self.tileSize) * -(-screenHeight // self.tileSize)
+        d.lastBinner = self
 
     def _get(self, fn, size):
         p = C.c_void_p()
@@ -541,6 +545,8 @@ class GPUTileBinner:
         self.prefixSumScanner.cleanupTempBuffers()
 
     def destroy(self):  # :371-377
+        if self.device.lastBinner is self:
+            self.device.lastBinner = None
         if self._b:
             self.device.lib.splat_bin_destroy(self._b)
             self._b = None
@@ -645,28 +651,49 @@ class ComputeShaderRenderer:
 class TileRenderer(ComputeShaderRenderer):
     """src/TileRenderer.ts:5-355.  The reference draws instanced oriented quads per tile in a CPU
     loop over a fixed-stride index layout (:291); north_star names this class for the per-pixel
-    composite, so here it fronts the same HIP composite as ComputeShaderRenderer.  render() keeps
-    the reference's argument list; the projected records and prefix-sum offsets the composite
-    needs (absent from that list) are bound beforehand with bindTileData().  footprint="disc" gives
-    the reference TileRenderer's own footprint (the oriented quad of its vertex shader, the same as
-    SequentialRenderer's): bind the disc projector's getDiscBuffer() as the records then."""
+    composite, so here it fronts the same HIP composite as ComputeShaderRenderer.  render() has the
+    reference's eleven arguments (:234-246) and runs with nothing else: the projected records and the
+    prefix-sum offsets the composite needs — which that signature does not name — are those of the
+    SplatProjector and GPUTileBinner that last ran on the device (Device.lastProjector / lastBinner: their
+    project() / binSplats(), or a Renderer's frame); bindTileData() overrides them.  tileCountsData is the
+    reference's host array of counts per tile (Uint32Array: the reference's loop reads it on the CPU; here its
+    length is checked and the device-resident counts are what the kernel reads) or, as an extension, the
+    device buffer itself.  footprint="disc" gives the reference TileRenderer's own footprint (the oriented
+    quad of its vertex shader, the same as SequentialRenderer's): the disc projector's getDiscBuffer() is
+    then the record buffer."""
 
     def __init__(self, device, context=None, presentationFormat="rgba8unorm", **kw):
+        self._format_given = "recordFormat" in kw
         super().__init__(device, context, presentationFormat, **kw)
         self._projected = self._offsets = self._counts = None
 
     def bindTileData(self, projectedBuffer, tileCountsBuffer, tileOffsetsBuffer):
+        """Override: composite from these buffers (in this renderer's recordFormat) instead of the device's last projector / binner."""
         self._projected, self._counts, self._offsets = projectedBuffer, tileCountsBuffer, tileOffsetsBuffer
 
     def render(self, uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, tileCountsData,
                numTilesX, numTilesY, tileSize, maxSplatsPerTile, width, height, wantFloat=False):  # :234-348
-        if self._projected is None:
-            raise SplatError(-5, "TileRenderer.render: call bindTileData(projected, counts, offsets) first")
         if numTilesY != -(-height // tileSize):
             raise SplatError(-1, "numTilesY does not match ceil(height / tileSize)")
+        if isinstance(tileCountsData, np.ndarray) and tileCountsData.size != numTilesX * numTilesY:
+            raise SplatError(-1, "tileCountsData does not hold one count per tile (numTilesX * numTilesY)")
+        if self._projected is not None:
+            projected, counts, offsets = self._projected, self._counts, self._offsets
+        else:
+            p, b = self.device.lastProjector, self.device.lastBinner
+            if p is None or b is None:
+                raise SplatError(-5, "TileRenderer.render: no SplatProjector / GPUTileBinner has run on this device yet (and "
+                                     "bindTileData was not called): there are no projected records and tile offsets to composite from")
+            if self.footprint == _lib.FOOTPRINT_DISC:
+                projected = p.getDiscBuffer()
+            else:
+                projected = p.getRecordsBuffer()
+                if not self._format_given:  # what that projector left there: a frame's lit composite records, or ProjectedSplat records
+                    self.recordFormat = _lib.RECORDS_LIT32 if p.contents == "lit" else _lib.RECORDS_PROJECTED
+            counts = tileCountsData if isinstance(tileCountsData, Buffer) else b.getTileCountsBuffer()
+            offsets = b.getTileOffsetsBuffer()
         return ComputeShaderRenderer.render(self, uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer,
-                                            self._projected, self._counts, self._offsets, tileSize, numTilesX, width, height,
-                                            wantFloat)
+                                            projected, counts, offsets, tileSize, numTilesX, width, height, wantFloat)
 
 
 class SequentialRenderer:
@@ -781,9 +808,14 @@ class Renderer:
         prelit = isinstance(propertyBuffer, PropertyPlanes) and propertyBuffer.prelit
         ts = self.tileSize
         lit = self.records == "lit" and -(-width // ts) <= 256 and -(-height // ts) <= 256
-        self.recordFormat = _lib.RECORDS_LIT32 if lit else _lib.RECORDS_PROJECTED  # of projector.getRecordsBuffer() after this frame
-        self.projector.contents = "lit" if (lit and self.footprint == _lib.FOOTPRINT_ISOTROPIC) else "projected"
-        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], self.recordFormat, int(prelit),
+        # what the FRAME composites from (a disc frame with "lit": 48-byte lit disc records inside the binner) ...
+        frame_format = self.frameRecordFormat = _lib.RECORDS_LIT32 if lit else _lib.RECORDS_PROJECTED
+        # ... and what projector.getRecordsBuffer() holds after this frame — what a caller passes, with this format, to the staged
+        # composite: lit composite records for an isotropic "lit" frame, ProjectedSplat records otherwise (a disc frame's too)
+        iso_lit = lit and self.footprint == _lib.FOOTPRINT_ISOTROPIC
+        self.recordFormat = _lib.RECORDS_LIT32 if iso_lit else _lib.RECORDS_PROJECTED
+        self.projector.contents = "lit" if iso_lit else "projected"
+        cfg = CompositeCfg(self.mode, int(self.earlyOut), self.tileSize, tileRows[0], tileRows[1], frame_format, int(prelit),
                            self.footprint)
         tail = (normalsBuffer.ptr if normalsBuffer is not None else None, self.numPoints, width, height,
                 self.projector.projectedBuffer.ptr if self.writeProjected else None, self.output.ptr,
@@ -800,6 +832,7 @@ class Renderer:
             rc = fn(*args)
         check(rc, d.ctx)
         self.binner._tiles = -(-width // self.tileSize) * -(-height // self.tileSize)
+        d.lastProjector, d.lastBinner = self.projector, self.binner
         return self.output
 
     def finish(self):

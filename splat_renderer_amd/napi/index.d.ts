@@ -12,13 +12,16 @@ export class Buffer {
 }
 export class Device {
   constructor(ordinal?: number);
+  /** the SplatProjector / GPUTileBinner that last ran on this device: what TileRenderer.render composites from unless bindTileData overrides */
+  lastProjector: SplatProjector | null;
+  lastBinner: GPUTileBinner | null;
   queue: { writeBuffer(buffer: Buffer, offset: number, data: TypedArray): void; submit(commandBuffers?: unknown[]): void; onSubmittedWorkDone(): Promise<void> };
   createBuffer(desc: number | { size: number }): Buffer;
   createBufferFrom(data: TypedArray): Buffer;
   createCommandEncoder(): CommandEncoder;
   sync(): void;
   rankStatus(): { policy: string; atomicsOrdered: boolean; orderFaults: number };
-  compositeOptions(kernel?: 'quadrant' | 'pixel' | null, ahead?: number, predict?: boolean | null, slack?: number | null): void;
+  compositeOptions(kernel?: 'quadrant' | 'pixel' | null, ahead?: number, predict?: boolean | null): void;
   forgetCompositeHistory(): void;
   setTiming(enabled: boolean, stageMask?: number, every?: number): void;
   stageTimeStats(stage: number): { samples: number; totalMs: number };
@@ -229,13 +232,20 @@ export class SequentialRenderer {
   destroy(): void;
 }
 export class ComputeShaderRenderer {
-  constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean; footprint?: Footprint });
+  constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean; footprint?: Footprint; recordFormat?: number });
+  recordFormat: number;
+  ensureOutputTexture(width: number, height: number): void;
   render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, projectedBuffer: Buffer, tileListsBuffer: Buffer, tileOffsetsBuffer: Buffer, tileSize: number, numTilesX: number, width: number, height: number): void;
   readPixels(): Uint8Array;
   destroy(): void;
 }
+/** render() has the reference's eleven arguments (src/TileRenderer.ts:234-246) and needs nothing else: the projected records and
+ *  tile offsets are those of the device's last SplatProjector / GPUTileBinner; bindTileData overrides them. */
 export class TileRenderer extends ComputeShaderRenderer {
+  constructor(device: Device, context?: unknown, presentationFormat?: string, options?: { mode?: number; earlyOut?: boolean; footprint?: Footprint; recordFormat?: number });
   bindTileData(projectedBuffer: Buffer, tileCountsBuffer: Buffer, tileOffsetsBuffer: Buffer): void;
+  // @ts-ignore (the reference's TileRenderer.render: another argument list than ComputeShaderRenderer.render, and async)
+  render(uniformData: Float32Array, splatPropertyBuffer: Buffer, splatIndicesBuffer: Buffer, curvatureBuffer: Buffer, tileCountsData: Uint32Array | Buffer, numTilesX: number, numTilesY: number, tileSize: number, maxSplatsPerTile: number, width: number, height: number): Promise<void>;
 }
 export class Renderer {
   constructor(device: Device, context?: unknown, presentationFormat?: string, numPoints?: number, tileSize?: number, options?: { footprint?: Footprint; records?: "lit" | "projected" });

@@ -51,6 +51,10 @@ class Buffer_ {
 class Device {
   constructor(ordinal = 0) {
     this.ctx = native.ctx_create(ordinal);
+    // the SplatProjector and GPUTileBinner that last ran on this device (their project() / binSplats(), or a Renderer's frame):
+    // what TileRenderer.render — whose reference signature names neither — composites from unless told otherwise
+    this.lastProjector = null;
+    this.lastBinner = null;
     const self = this;
     this.queue = {
       writeBuffer(buffer, offset, data) {
@@ -78,13 +82,15 @@ class Device {
     const s = native.rank_status(this.ctx);
     return { policy: ['checked', 'atomic', 'ballot'][s[0]], atomicsOrdered: s[1] === 1, orderFaults: s[2] };
   }
-  /** splat_composite_options: which composite kernel this context runs and how far its builder looks ahead (ahead / predict /
-   *  slack change the schedule only: same bytes; the two kernels agree within the composite's stated tolerance).  kernel null (library default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict null |
-   *  boolean (the look-ahead bound from the previous launch's per-tile costs); slack null | chunks.  host.py Device.compositeOptions. */
-  compositeOptions(kernel = null, ahead = 0, predict = null, slack = null) {
+  /** splat_composite_options: which composite kernel this context runs and how far its builder looks ahead (ahead / predict
+   *  change the schedule only: same bytes; the two kernels agree within the composite's stated tolerance).  kernel null (process
+   *  default) | 'quadrant' | 'pixel'; ahead 0 (default) | 1 | 2; predict null | boolean (the look-ahead bound from the previous
+   *  launch's per-tile costs).  EVERY call sets all three: null / 0 = the process default, i.e. the environment's (not "as it
+   *  was"); a choice made here takes precedence over the environment variable.  host.py Device.compositeOptions. */
+  compositeOptions(kernel = null, ahead = 0, predict = null) {
     const k = kernel === null ? -1 : kernel === 'quadrant' ? 0 : kernel === 'pixel' ? 1 : NaN;
     if (Number.isNaN(k)) throw new Error("compositeOptions: kernel is null, 'quadrant' or 'pixel'");
-    native.composite_options(this.ctx, k, ahead, predict === null ? -1 : predict ? 1 : 0, slack === null ? -1 : slack);
+    native.composite_options(this.ctx, k, ahead, predict === null ? -1 : predict ? 1 : 0);
   }
   /** splat_composite_forget_history: the next composite behaves like a context's first (row-major tile order, no look-ahead bound). */
   forgetCompositeHistory() { native.composite_forget_history(this.ctx); }
@@ -212,6 +218,8 @@ class SplatProjector {
     const u = uniformFloats(uniformBuffer);
     if (u.length < 22) throw new Error('uniform block needs 22 floats (VP, eye, time, screenW, screenH)');
     const keys = keysBuffer ? keysBuffer.ptr : null, payload = payloadBuffer ? payloadBuffer.ptr : null;
+    this.device.lastProjector = this;
+    this.contents = 'projected';
     if (this.footprint === FOOTPRINT_DISC) {
       if (!normalsBuffer) throw new Error("SplatProjector(footprint 'disc').project needs normalsBuffer");
       native.project_disc(this.device.ctx, u, splatPropertyBuffer.ptr, 2, normalsBuffer.ptr, 1, this.numSplats, this.projectedBuffer.ptr,
@@ -236,6 +244,7 @@ class SplatProjector {
     return this.discBuffer;
   }
   destroy() {
+    if (this.device.lastProjector === this) this.device.lastProjector = null;
     this.projectedBuffer.destroy();
     if (this.discBuffer) this.discBuffer.destroy();
   }          // :200-202
@@ -295,6 +304,7 @@ class GPUTileBinner {
   async binSplats(commandEncoder, projectedBuffer, sortedIndicesBuffer, numSplats, screenWidth, screenHeight) { // :190-338
     native.bin_run(this.device.ctx, this.handle, projectedBuffer.ptr, numSplats, sortedIndicesBuffer.ptr, numSplats, screenWidth, screenHeight, 0, U32_MAX);
     this.numTiles = Math.ceil(screenWidth / this.tileSize) * Math.ceil(screenHeight / this.tileSize);
+    this.device.lastBinner = this;
   }
   // the natives throw Error("... Tile offsets buffer not initialized") etc. before binSplats, as :340-359
   getTileOffsetsBuffer() { return new Buffer_(this.device, native.bin_offsets(this.device.ctx, this.handle), this.numTiles * 4, false); }
@@ -307,6 +317,7 @@ class GPUTileBinner {
   getTileSize() { return this.tileSize; } // :361-363
   cleanupTempBuffers() { this.prefixSumScanner.cleanupTempBuffers(); }
   destroy() {
+    if (this.device.lastBinner === this) this.device.lastBinner = null;
     if (this.handle) native.bin_destroy(this.handle);
     this.handle = null;
   }
@@ -338,6 +349,9 @@ class ComputeShaderRenderer {
     this.mode = options.mode || MODE_FRONT_TO_BACK;
     this.earlyOut = options.earlyOut !== false;
     this.footprint = footprintCode(options.footprint);
+    // RECORDS_LIT32: projectedBuffer in render() holds lit composite records (what a Renderer with records 'lit' leaves in its
+    // projector's buffer); colours and normals are then not read
+    this.recordFormat = options.recordFormat || RECORDS_PROJECTED;
     // 'disc': projectedBuffer in render() is the disc projector's getDiscBuffer()
     this.outputTexture = null;
     this.width = 0;
@@ -354,7 +368,7 @@ class ComputeShaderRenderer {
   render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projectedBuffer, tileListsBuffer, tileOffsetsBuffer, tileSize, numTilesX, width, height) { // :362-462
     if (numTilesX !== Math.ceil(width / tileSize)) throw new Error('numTilesX does not match ceil(width / tileSize)');
     this.ensureOutputTexture(width, height);
-    native.composite(this.device.ctx, [this.mode, this.earlyOut ? 1 : 0, tileSize, 0, U32_MAX, 0, 0, this.footprint], splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
+    native.composite(this.device.ctx, [this.mode, this.earlyOut ? 1 : 0, tileSize, 0, U32_MAX, this.recordFormat, 0, this.footprint], splatPropertyBuffer.ptr + 16, 2, curvatureBuffer.ptr, 1,
       projectedBuffer.ptr, splatIndicesBuffer.ptr, tileListsBuffer.ptr, tileOffsetsBuffer.ptr, width, height, this.outputTexture.ptr, null);
   }
   readPixels() { return this.outputTexture.read(new Uint8Array(this.width * this.height * 4)); }
@@ -364,12 +378,38 @@ class ComputeShaderRenderer {
   } // :464-468
 }
 
-/** src/TileRenderer.ts:5-355 — fronts the same composite; bindTileData supplies what render()'s reference signature lacks */
+/** src/TileRenderer.ts:5-355 — fronts the same composite.  render() has the reference's eleven arguments (:234-246) and runs with
+ * nothing else: the projected records and the prefix-sum offsets the composite needs, which that signature does not name, are
+ * those of the SplatProjector and GPUTileBinner that last ran on the device (Device.lastProjector / lastBinner); bindTileData
+ * overrides them.  tileCountsData is the reference's host Uint32Array of counts per tile (its length is checked; the
+ * device-resident counts are what the kernel reads) or, as an extension, the device buffer itself. */
 class TileRenderer extends ComputeShaderRenderer {
+  constructor(device, context = null, presentationFormat = 'rgba8unorm', options = {}) {
+    super(device, context, presentationFormat, options);
+    this.bound = null;
+    this.formatGiven = options.recordFormat !== undefined;
+  }
   bindTileData(projectedBuffer, tileCountsBuffer, tileOffsetsBuffer) { this.bound = [projectedBuffer, tileCountsBuffer, tileOffsetsBuffer]; }
   async render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, tileCountsData, numTilesX, numTilesY, tileSize, maxSplatsPerTile, width, height) { // :234-348
-    if (!this.bound) throw new Error('TileRenderer.render: call bindTileData(projected, counts, offsets) first');
-    super.render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, this.bound[0], this.bound[1], this.bound[2], tileSize, numTilesX, width, height);
+    if (numTilesY !== Math.ceil(height / tileSize)) throw new Error('numTilesY does not match ceil(height / tileSize)');
+    if (tileCountsData instanceof Uint32Array && tileCountsData.length !== numTilesX * numTilesY) throw new Error('tileCountsData does not hold one count per tile (numTilesX * numTilesY)');
+    let projected, counts, offsets;
+    if (this.bound) {
+      projected = this.bound[0];
+      counts = this.bound[1];
+      offsets = this.bound[2];
+    } else {
+      const p = this.device.lastProjector, b = this.device.lastBinner;
+      if (!p || !b) throw new Error('TileRenderer.render: no SplatProjector / GPUTileBinner has run on this device yet (and bindTileData was not called)');
+      if (this.footprint === FOOTPRINT_DISC) projected = p.getDiscBuffer();
+      else {
+        projected = p.getRecordsBuffer();
+        if (!this.formatGiven) this.recordFormat = p.contents === 'lit' ? RECORDS_LIT32 : RECORDS_PROJECTED;
+      }
+      counts = tileCountsData instanceof Buffer_ ? tileCountsData : b.getTileCountsBuffer();
+      offsets = b.getTileOffsetsBuffer();
+    }
+    super.render(uniformData, splatPropertyBuffer, splatIndicesBuffer, curvatureBuffer, projected, counts, offsets, tileSize, numTilesX, width, height);
   }
 }
 
@@ -447,9 +487,14 @@ class Renderer {
       this.height = height;
     }
     const small = Math.ceil(width / this.tileSize) <= 256 && Math.ceil(height / this.tileSize) <= 256;
-    this.recordFormat = this.records === 'lit' && small ? RECORDS_LIT32 : RECORDS_PROJECTED; // of projector.getRecordsBuffer() after this frame
-    this.projector.contents = this.recordFormat === RECORDS_LIT32 && this.footprint !== FOOTPRINT_DISC ? 'lit' : 'projected';
-    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, this.recordFormat, propertyBuffer.prelit ? 1 : 0, this.footprint];
+    // what the FRAME composites from (a disc frame with 'lit': 48-byte lit disc records inside the binner) ...
+    const frameFormat = this.records === 'lit' && small ? RECORDS_LIT32 : RECORDS_PROJECTED;
+    // ... and what projector.getRecordsBuffer() holds after this frame — what a caller passes, with this format, to the staged
+    // composite: lit composite records for an isotropic 'lit' frame, ProjectedSplat records otherwise (a disc frame's too)
+    const isoLit = frameFormat === RECORDS_LIT32 && this.footprint !== FOOTPRINT_DISC;
+    this.recordFormat = isoLit ? RECORDS_LIT32 : RECORDS_PROJECTED;
+    this.projector.contents = isoLit ? 'lit' : 'projected';
+    const cfg = [MODE_FRONT_TO_BACK, 1, this.tileSize, 0, U32_MAX, frameFormat, propertyBuffer.prelit ? 1 : 0, this.footprint];
     if (propertyBuffer.isPlanes) { // SplatPropertyManager.getPropertyPlanes()
       native.render_frame_planes(this.device.ctx, this.sorter.handle, this.binner.handle, cfg, u, propertyBuffer.posRadius.ptr, propertyBuffer.colorOpacity.ptr,
         normalsBuffer.ptr, this.numPoints, width, height, this.projector.projectedBuffer.ptr, this.output.ptr, null);
@@ -458,6 +503,8 @@ class Renderer {
         propertyBuffer.ptr, normalsBuffer.ptr, this.numPoints, width, height, this.projector.projectedBuffer.ptr, this.output.ptr, null);
     }
     this.binner.numTiles = Math.ceil(width / this.tileSize) * Math.ceil(height / this.tileSize);
+    this.device.lastProjector = this.projector;
+    this.device.lastBinner = this.binner;
     return this.output;
   }
   // Settles a sync-free frame: waits for its report (pair total, overflow and order-check flags: include/splat.h) and, if

@@ -29,7 +29,16 @@ if (!threw) throw new Error('getter before binSplats did not throw');
   if (bad !== 0) throw new Error('PerTileSorter validator found ' + bad + ' out-of-order neighbours');
   renderer.render(uniforms, props.getPropertyBuffer(), binner.getTileIndicesBuffer(), normals, projector.getProjectedBuffer(),
     binner.getTileCountsBuffer(), binner.getTileOffsetsBuffer(), 16, Math.ceil(W / 16), W, H);
-  fs.writeFileSync(outPath, Buffer.from(renderer.readPixels().buffer));
+  const stagedPixels = renderer.readPixels();
+  fs.writeFileSync(outPath, Buffer.from(stagedPixels.buffer));
+  // TileRenderer.render with exactly the reference's eleven arguments (src/TileRenderer.ts:234-246; tileCountsData a host
+  // Uint32Array) and no bindTileData: it composites from the device's last projector and binner — the bytes of the staged composite
+  const tileRenderer = new sr.TileRenderer(device, null, 'rgba8unorm');
+  const tileCountsData = binner.getTileCountsBuffer().read(new Uint32Array(binner.numTiles));
+  await tileRenderer.render(uniforms, props.getPropertyBuffer(), binner.getTileIndicesBuffer(), normals, tileCountsData, Math.ceil(W / 16), Math.ceil(H / 16), 16, 4096, W, H);
+  const tilePixels = tileRenderer.readPixels();
+  const tileRendererEqualsStaged = tilePixels.length === stagedPixels.length && tilePixels.every((v, i) => v === stagedPixels[i]);
+  tileRenderer.destroy();
   if (orderPath) fs.writeFileSync(orderPath, Buffer.from(sorter.getSortedIndicesBuffer().read(new Uint32Array(n)).buffer));
   if (countsPath) fs.writeFileSync(countsPath, Buffer.from(binner.getTileCountsBuffer().read(new Uint32Array(binner.numTiles)).buffer));
   if (indicesPath) fs.writeFileSync(indicesPath, Buffer.from(binner.getTileIndicesBuffer().read(new Uint32Array(binner.getTotalIndices())).buffer));
@@ -43,12 +52,12 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     framePairs = whole.binner.getTotalIndices();
     recordFormat = whole.recordFormat;
     // the composite's per-context options and the timing detail from JS: the per-pixel-queue kernel under two schedules (one chunk
-    // of look-ahead bounded by history; two chunks, no history, a chunk of slack) gives the same bytes, and the default kernel's
+    // of look-ahead bounded by history; two chunks, no history) gives the same bytes, and the default kernel's
     // image within 1 LSB; one composite launch timed, its entries counted
-    device.compositeOptions('pixel', 1, true, null);
+    device.compositeOptions('pixel', 1, true);
     for (let k = 0; k < 3; k++) whole.render(uniforms, props.getPropertyPlanes(), normals, null, W, H);
     const pixelA = whole.readPixels();
-    device.compositeOptions('pixel', 2, false, 1);
+    device.compositeOptions('pixel', 2, false);
     device.forgetCompositeHistory();
     device.setTiming(true, (1 << 3) + 0x80000000, 1); // the bit of SPLAT_STAGE_COMPOSITE + SPLAT_TIMING_COUNT_ENTRIES
     whole.render(uniforms, props.getPropertyPlanes(), normals, null, W, H);
@@ -57,7 +66,7 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     kernelsWithinOneLsb = pixelA.length === framePixels.length && pixelA.every((v, i) => Math.abs(v - framePixels[i]) <= 1);
     timed = Object.assign(device.stageTimeStats(3), device.timingConsumed());
     device.setTiming(false);
-    device.compositeOptions(null, 0, null, null);
+    device.compositeOptions(null, 0, null);
     // north_star's multi-GPU frame from JS, on the one GPU there is: a one-rank RCCL communicator behind the C ABI,
     // project my slice -> all-gather -> my band (= every tile row) from the gathered 16-byte records
     const comm = new sr.Comm(device, 0, 1, sr.Comm.uniqueId());
@@ -97,6 +106,6 @@ if (!threw) throw new Error('getter before binSplats did not throw');
     fs.writeFileSync(discFramePath, Buffer.from(whole.readPixels().buffer));
     discFramePairs = whole.binner.getTotalIndices();
   }
-  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), framePairs, schedulesKeepTheBytes, kernelsWithinOneLsb, timed, seqPairs, discFramePairs, recordFormat, bandEqualsFrame, bandPairs,
+  console.log(JSON.stringify({ n, W, H, pairs: binner.getTotalIndices(), tileRendererEqualsStaged, framePairs, schedulesKeepTheBytes, kernelsWithinOneLsb, timed, seqPairs, discFramePairs, recordFormat, bandEqualsFrame, bandPairs,
     pointManagerOk, ranking: device.rankStatus(), uniforms: Array.from(uniforms) }));
 })().catch((e) => { console.error(e); process.exit(1); });

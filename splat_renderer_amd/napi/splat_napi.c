@@ -458,20 +458,11 @@ FN(probe_lds_atomic_order) { /* (ctx) -> mismatches */
     int rc = splat_probe_lds_atomic_order(x, &m);
     return check(env, x, rc, rc == SPLAT_OK ? mk_number(env, (double)m) : NULL);
 }
-FN(debug_inject_order_fault) { ARGS(3); splat_ctx *x = arg_external(&c, 0); uint32_t t = (uint32_t)arg_number(&c, 1), p = (uint32_t)arg_number(&c, 2); BAIL; return check(env, x, splat_debug_inject_order_fault(x, t, p), mk_undefined(env)); }
-FN(debug_set_tile_order) { ARGS(2); splat_ctx *x = arg_external(&c, 0); void *o = arg_dptr(&c, 1); BAIL; return check(env, x, splat_debug_set_tile_order(x, o), mk_undefined(env)); }
-FN(debug_set_tile_sort_order) { ARGS(2); splat_ctx *x = arg_external(&c, 0); void *o = arg_dptr(&c, 1); BAIL; return check(env, x, splat_debug_set_tile_sort_order(x, o), mk_undefined(env)); }
 FN(composite_forget_history) { ARGS(1); splat_ctx *x = arg_external(&c, 0); BAIL; return check(env, x, splat_composite_forget_history(x), mk_undefined(env)); }
-FN(composite_options) { /* (ctx, kernel, ahead, predict, slack): -1 leaves a setting as it is */
-    ARGS(5); splat_ctx *x = arg_external(&c, 0);
-    int k = (int)arg_number(&c, 1), a = (int)arg_number(&c, 2), p = (int)arg_number(&c, 3), sl = (int)arg_number(&c, 4); BAIL;
-    return check(env, x, splat_composite_options(x, k, a, p, sl), mk_undefined(env));
-}
-FN(sort_lookback_timeouts) { /* (sorter) -> flag */
-    ARGS(1); splat_sorter *s = arg_external(&c, 0); BAIL;
-    uint32_t f = 0;
-    int rc = splat_sort_lookback_timeouts(s, &f);
-    return check(env, NULL, rc, rc == SPLAT_OK ? mk_number(env, f) : NULL);
+FN(composite_options) { /* (ctx, kernel, ahead, predict): every call sets all three; -1 (kernel, predict) / 0 (ahead) = the process default (the environment's), as splat.h says */
+    ARGS(4); splat_ctx *x = arg_external(&c, 0);
+    int k = (int)arg_number(&c, 1), a = (int)arg_number(&c, 2), p = (int)arg_number(&c, 3); BAIL;
+    return check(env, x, splat_composite_options(x, k, a, p), mk_undefined(env));
 }
 FN(bin_dims) { /* (binner) -> [tilesX, tilesY] */
     ARGS(1); splat_binner *b = arg_external(&c, 0); BAIL;
@@ -538,8 +529,8 @@ static napi_value init(napi_env env, napi_value exports) {
         EXPORT(bin_indices), EXPORT(bin_total), EXPORT(bin_set_frame_order), EXPORT(validate_tile_order), EXPORT(composite), EXPORT(render_frame), EXPORT(render_frame_planes),
         EXPORT(project_slice_compact), EXPORT(band_frame), EXPORT(band_settle), EXPORT(comm_unique_id), EXPORT(comm_init), EXPORT(comm_destroy),
         EXPORT(ctx_create_on_stream), EXPORT(last_error), EXPORT(set_timing_stages), EXPORT(set_timing_sampling), EXPORT(stage_time_stats), EXPORT(timing_consumed),
-        EXPORT(buf_copy), EXPORT(probe_lds_atomic_order), EXPORT(debug_inject_order_fault), EXPORT(debug_set_tile_order), EXPORT(debug_set_tile_sort_order),
-        EXPORT(composite_forget_history), EXPORT(composite_options), EXPORT(sort_lookback_timeouts), EXPORT(bin_dims), EXPORT(bin_tile_size), EXPORT(project_slice),
+        EXPORT(buf_copy), EXPORT(probe_lds_atomic_order),
+        EXPORT(composite_forget_history), EXPORT(composite_options), EXPORT(bin_dims), EXPORT(bin_tile_size), EXPORT(project_slice),
         EXPORT(project_slice_disc), EXPORT(expand_compact), EXPORT(band_keys), EXPORT(band_kept), EXPORT(comm_rank), EXPORT(comm_count),
         EXPORT(allgather_records), EXPORT(sdf_gradients), EXPORT(sdf_update_positions), EXPORT(sdf_scale_factors), EXPORT(sdf_curvature), EXPORT(sdf_seed_positions), EXPORT(sdf_generate),
     };

@@ -9,9 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
+def declared_functions(hooks=False):
+    """The entry points include/splat.h declares: the product's (hooks=False), or the ones inside its #ifdef SPLAT_TEST_HOOKS
+    block (hooks=True: compiled only into the test build, libsplat_hip_hooks.so)."""
     text = open(os.path.join(ROOT, "include", "splat.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    blocks = re.findall(r"#ifdef SPLAT_TEST_HOOKS(.*?)#endif", text, flags=re.S)
+    text = "".join(blocks) if hooks else re.sub(r"#ifdef SPLAT_TEST_HOOKS.*?#endif", "", text, flags=re.S)
     names = re.findall(r"\b(splat_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))
 
@@ -29,6 +33,23 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.LIB_PATH)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in splat.h but not exported: {missing}"
+
+
+def test_hooks_live_in_the_test_build_only():
+    """splat_debug_* (and the kernel parameters behind them) are compiled under -DSPLAT_TEST_HOOKS only: the
+    shipped library exports none of them, the test build (libsplat_hip_hooks.so, built beside it) all of them plus the whole
+    product ABI; the Python binding keeps the two sets apart."""
+    import __graft_entry__ as g
+    from splat_renderer_amd import _lib
+    hooks = declared_functions(hooks=True)
+    assert hooks and all(n.startswith("splat_debug_") for n in hooks)
+    assert sorted(_lib.HOOK_SIGNATURES) == hooks and not set(hooks) & set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.HOOKS_LIB_PATH) or not os.path.exists(os.path.join(ROOT, "splat_renderer_amd", "libsplat_hip.so")):
+        g.build()
+    shipped = C.CDLL(os.path.join(ROOT, "splat_renderer_amd", "libsplat_hip.so"))
+    assert [n for n in hooks if hasattr(shipped, n)] == [], "the shipped library exports test hooks"
+    test_build = C.CDLL(_lib.HOOKS_LIB_PATH)
+    assert [n for n in hooks + declared_functions() if not hasattr(test_build, n)] == []
 
 
 def test_python_binding_covers_the_header():

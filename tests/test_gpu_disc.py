@@ -204,12 +204,13 @@ def test_disc_whole_frame(device, order, layout):
     # without the ProjectedSplat by-product (nothing in a disc frame reads it): same lists, same image bits
     # (and with plain 32-byte disc records — colour and normal gathered per staged entry, as the staged API does — instead of
     # the frame's default, the lit colour behind each disc record: the same arithmetic on the same numbers)
-    assert r.recordFormat == _lib.RECORDS_LIT32
+    # (what the FRAME composited from — lit disc records inside the binner — is not what getRecordsBuffer() holds: ProjectedSplat)
+    assert r.frameRecordFormat == _lib.RECORDS_LIT32 and r.recordFormat == _lib.RECORDS_PROJECTED
     r2 = sr.Renderer(device, None, "rgba8unorm", n, earlyOut=False, frameOrder=order, footprint="disc", writeProjected=False,
                      records="projected")
     r2.projector.getProjectedBuffer().zero()
     r2.render(u, src, nbuf, None, w, h, wantFloat=True)
-    assert r2.finish() == total and r2.recordFormat == _lib.RECORDS_PROJECTED
+    assert r2.finish() == total and r2.recordFormat == _lib.RECORDS_PROJECTED and r2.frameRecordFormat == _lib.RECORDS_PROJECTED
     assert_same(r2.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], "disc L189")
     assert_same(r2.readPixelsFloat().view(np.uint32), r.readPixelsFloat().view(np.uint32), "disc L190")
     assert not r2.projector.getProjectedBuffer().read(np.uint32).any()
@@ -254,6 +255,10 @@ def test_disc_rejects_what_it_does_not_support(device):
     cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, _lib.RECORDS_COMPACT, 0, _lib.FOOTPRINT_DISC)
     assert lib.splat_composite(ctx, C.byref(cfg), *args) == -1
     cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, 0, 0, 7)
+    assert lib.splat_composite(ctx, C.byref(cfg), *args) == -1
+    # lit disc records (48 bytes) exist only inside a frame's binner: the public composite does not take the pair
+    # (disc footprint, LIT32) at its word and read idx * 48 out of a caller's 32-byte records
+    cfg = _lib.CompositeCfg(_lib.MODE_FRONT_TO_BACK, 1, 16, 0, 0xFFFFFFFF, _lib.RECORDS_LIT32, 0, _lib.FOOTPRINT_DISC)
     assert lib.splat_composite(ctx, C.byref(cfg), *args) == -1
     # band frames exchange the isotropic footprint's records
     sorter, binner = sr.RadixSorter(device, n), sr.GPUTileBinner(device, 16)

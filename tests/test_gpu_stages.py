@@ -99,7 +99,7 @@ def test_project_and_keys_bit_exact(device, n, w, h, seed):
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 1023, 4095, 4096, 4097, 8191, 12289, 100000, 1000003])
 @pytest.mark.parametrize("kind", ["random", "few_values", "all_equal", "sorted_desc"])
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["rowscan", "onesweep", "rowscan-ballot"])
+@pytest.mark.parametrize("mode", [0, 2], ids=["policy", "ballot"])
 def test_radix_sort_stable(device, n, kind, mode):
     rng = np.random.default_rng(n * 7 + len(kind))
     if kind == "random":
@@ -118,7 +118,6 @@ def test_radix_sort_stable(device, n, kind, mode):
         s.getKeysBuffer().write(keys)
         s.getPayloadBuffer().write(payload)
     s.sort(n)
-    assert s.lookbackTimeouts() == 0
     order = np.argsort(keys, kind="stable").astype(np.uint32)
     assert_same(s.getSortedIndicesBuffer().read(np.uint32, n), order, "L122")
     assert_same(s.getSortedKeysBuffer().read(np.uint32, n), keys[order], "L123")
@@ -278,8 +277,7 @@ def test_bin_empty(device):
 #   px2_warm  the same after two launches over the same lists: every tile's look-ahead is what the launch before walked
 #   px2_under / px1_under  the launch before saw EMPTY lists (costs 0): every tile that needs a second chunk is mispredicted and
 #             takes the on-demand path (exposed gather, extra barrier)
-#   px2_slack the warm launch with two chunks of slack added to every bound
-COMPOSITE_KERNELS = ["default", "px1", "px2", "px2_warm", "px2_under", "px1_under", "px2_slack"]
+COMPOSITE_KERNELS = ["default", "px1", "px2", "px2_warm", "px2_under", "px1_under"]
 
 
 @pytest.mark.parametrize("n,w,h,seed,rs", CASES)
@@ -291,7 +289,7 @@ def test_composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel)
         pytest.skip("k_composite_px composites nearest-on-top only")
     try:
         if kernel != "default":
-            device.compositeOptions("pixel", ahead=1 if kernel.startswith("px1") else 2, predict=True, slack=2 if kernel == "px2_slack" else 0)
+            device.compositeOptions("pixel", ahead=1 if kernel.startswith("px1") else 2, predict=True)
         composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel)
     finally:
         device.compositeOptions()  # the library's defaults again (the context is shared)
@@ -315,7 +313,7 @@ def composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel):
             records = device.createBufferFrom(lit_records(u, props, normals))
         render = lambda: r.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], records,
                                   b.getTileCountsBuffer(), b.getTileOffsetsBuffer(), 16, ntx, w, h, wantFloat=True)
-        if kernel in ("px2_warm", "px2_slack"):  # two launches leave costs and an order behind for the third
+        if kernel == "px2_warm":  # two launches leave costs and an order behind for the third
             render()
             render()
         elif kernel.endswith("_under"):  # a launch over empty lists leaves cost 0 for every tile
@@ -350,8 +348,7 @@ def composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel):
             # at least every walked chunk, at most the look-ahead beyond them (2 built + 2 fetched); a tile is done when all
             # its pixels have stopped at a chunk's END, so one whose last pixel stops on a chunk's last entry walks no more
             assert np.all(cons[:, 0] >= np.minimum(counts64, cons[:, 1])), "entries staged per tile (k_composite_px): fewer than consumed"
-            slack = np.uint64(64 if kernel == "px2_slack" else 0)
-            assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(128) + slack)), "entries staged per tile (k_composite_px): beyond the look-ahead"
+            assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(128))), "entries staged per tile (k_composite_px): beyond the look-ahead"
             if kernel == "px2_warm":  # gathered: the chunks the tile touched in the launch before (the last walked, or the one after it) + one
                 assert np.all(cons[:, 0] <= np.minimum(counts64, walked + np.uint64(64))), "a warm launch gathers what the one before needed and one chunk more"
             staged_want = cons[:, 0]
@@ -369,21 +366,47 @@ def composite_vs_oracle(device, n, w, h, seed, rs, mode, early_out, kernel):
 
 
 def test_tile_renderer_fronts_composite(device):
+    """TileRenderer.render with EXACTLY the reference's eleven arguments (src/TileRenderer.ts:234-246: uniformData, splatPropertyBuffer,
+    splatIndicesBuffer, curvatureBuffer, tileCountsData: Uint32Array, numTilesX, numTilesY, tileSize, maxSplatsPerTile, width, height) and
+    no prior bind: the projected records and tile offsets are those of the projector and binner that last ran on the device — after
+    the staged stages, and after a whole-frame Renderer (whose projector leaves lit composite records).  bindTileData overrides."""
     n, w, h = 2000, 128, 96
     props, normals, u = make_case(n, w, h, 11, 2.0)
     ref = oracle_pipeline(props, normals, u, w, h)
     want, _, _ = O.composite(O.MODE_FRONT_TO_BACK, True, props[:, 4:], normals, ref["proj"], ref["indices"], ref["counts"],
                              ref["offsets"], w, h)
-    g = run_gpu_pipeline(device, props, normals, u, n, w, h)
+    fresh = sr.Device(0)  # nothing has run on it: nothing to composite from
+    with pytest.raises(sr.SplatError, match="no SplatProjector"):
+        sr.TileRenderer(fresh, None, "rgba8unorm").render(u, None, None, None, ref["counts"], 8, 6, 16, 4096, w, h)
+    fresh.destroy()
+    g = run_gpu_pipeline(device, props, normals, u, n, w, h)  # (SplatProjector.project ... GPUTileBinner.binSplats on `device`)
     b = g["binner"]
     tr = sr.TileRenderer(device, None, "rgba8unorm")
-    with pytest.raises(sr.SplatError):
-        tr.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], ref["counts"], 8, 6, 16, 4096, w, h)
-    tr.bindTileData(g["proj"].getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer())
-    tr.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], ref["counts"], 8, 6, 16, 4096, w, h,
-              wantFloat=True)
-    assert np.abs(tr.readPixelsFloat() - want).max() <= TOL_EARLY_OUT_BOUND
-    tr.destroy()
+    counts_host = b.getTileCountsBuffer().read(np.uint32)  # the reference's tileCountsData: a Uint32Array on the host
+    args = (u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], counts_host, 8, 6, 16, 4096, w, h)
+    tr.render(*args)  # the reference's call, argument for argument
+    first8 = tr.readPixels().copy()
+    tr.render(*args, wantFloat=True)  # (+ the float image, to hold it to the oracle)
+    assert_same(tr.readPixels(), first8, "tile renderer: the same call, the same bytes")
+    got = tr.readPixelsFloat().copy()
+    assert np.abs(got - want).max() <= TOL_EARLY_OUT_BOUND
+    with pytest.raises(sr.SplatError):  # a count per tile
+        tr.render(u, g["pm"].getPropertyBuffer(), b.getTileIndicesBuffer(), g["nbuf"], counts_host[:-1], 8, 6, 16, 4096, w, h)
+    # the override: the same buffers bound by hand give the same bits
+    tr2 = sr.TileRenderer(device, None, "rgba8unorm")
+    tr2.bindTileData(g["proj"].getProjectedBuffer(), b.getTileCountsBuffer(), b.getTileOffsetsBuffer())
+    tr2.render(*args, wantFloat=True)
+    assert_same(tr2.readPixelsFloat().view(np.uint32), got.view(np.uint32), "tile renderer: bound = found")
+    # after a whole frame: the Renderer's projector (lit composite records) and binner are the device's last
+    r = sr.Renderer(device, None, "rgba8unorm", n)
+    r.render(u, g["pm"].getPropertyBuffer(), g["nbuf"], None, w, h, wantFloat=True)
+    frame = r.readPixelsFloat().copy()
+    tr.render(u, g["pm"].getPropertyBuffer(), r.binner.getTileIndicesBuffer(), g["nbuf"], r.binner.getTileCountsBuffer().read(np.uint32),
+              8, 6, 16, 4096, w, h, wantFloat=True)
+    assert tr.recordFormat == _lib.RECORDS_LIT32
+    assert_same(tr.readPixelsFloat().view(np.uint32), frame.view(np.uint32), "tile renderer after a frame = the frame")
+    for o in (tr, tr2, r):
+        o.destroy()
     destroy_all(g)
 
 
@@ -527,9 +550,7 @@ def test_virtual_ranks_band_frame_matches_single_gpu(device, world):
     got = np.zeros_like(want)
     kept = []
     for br in renderers:  # phase 2: every rank renders its band from the gathered records
-        # (every other rank with the band's own lit composite records for the splats it keeps: splat_band_frame, SPLAT_RECORDS_LIT32)
-        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=True,
-                          lit_records=bool(br.rank & 1))
+        stages.band_frame(gathered, per * world, pt.data_ptr(), nt.data_ptr(), br.row0, br.row1, br.image, settle=True)
         torch.cuda.synchronize()
         r0, r1 = br.pixel_rows()
         got[r0:r1] = br.image.cpu().numpy()[r0:r1]
@@ -1006,101 +1027,25 @@ def test_timed_frames_count_entries_only_when_asked(device):
             o.destroy()
 
 
-def test_tile_sort_with_wide_digits(monkeypatch):
-    """SPLAT_TILE_SORT_DIGITS=12: the per-tile sort's two-pass variant (digits of up to 12 bits, 16-bit counters packed two
-    to a word; built and measured in round 3, slower than the byte passes and therefore not the default — DESIGN.md).  Same
-    lists and image as the oracle: both size classes, key ranges that need one, two and three wide passes, a tile of equal
-    keys, the global-memory passes of a list too long for LDS, both rankings."""
-    monkeypatch.setenv("SPLAT_TILE_SORT_DIGITS", "12")
-    for rank in (None, "ballot"):
-        if rank:
-            monkeypatch.setenv("SPLAT_RANK", rank)
-        dev = sr.Device(0)  # (both settings are resolved once per context)
-        try:
-            for n, w, h, seed, rs in [(3000, 128, 96, 41, 1.0), (20000, 640, 360, 42, 1.0), (20000, 64, 64, 43, 6.0), (30000, 48, 32, 44, 8.0),
-                                      (6000, 16, 16, 74, 30.0)]:
-                props, normals, u = make_case(n, w, h, seed, rs)
-                if seed == 43:  # a slab of equal depth keys (equal positions), and keys 2^27 apart in one tile (three wide passes)
-                    props[1000:3000, :3] = props[1000, :3]
-                    eye = np.asarray(u[16:19], np.float32)
-                    toward = -eye / np.linalg.norm(eye)
-                    near = np.random.default_rng(5).choice(n, 40, replace=False)
-                    props[near, :3] = eye + toward * np.random.default_rng(6).uniform(2e-5, 6e-5, size=(40, 1)).astype(np.float32)
-                    props[near, 3] = np.float32(2e-7)
-                if seed == 41:  # every depth within a few hundred ulps: one wide pass (and none for the tiles whose keys are equal)
-                    eye = np.asarray(u[16:19], np.float32)  # (depth = distance from the eye, SplatProjector.ts:77: a thin shell around it)
-                    ray = props[:, :3] - eye
-                    ray /= np.linalg.norm(ray, axis=1, keepdims=True)
-                    props[:, :3] = eye + ray * (3.0 + np.random.default_rng(7).uniform(0, 1e-4, (n, 1))).astype(np.float32)
-                ref = oracle_pipeline(props, normals, u, w, h)
-                pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
-                r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
-                for rep in range(2):  # first and sync-free
-                    r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-                    total = r.finish()
-                    assert not r.previousFrameOverflowed or rep == 0
-                    assert total == ref["indices"].shape[0], (n, w, h)
-                    assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("wide digits", rank, n, w, h, rep),
-                                offsets=ref["offsets"], keys=ref["keys"])
-                assert dev.rankStatus()["orderFaults"] == 0
-                got = r.readPixelsFloat()
-                r2 = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="sortFirst")
-                r2.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-                assert_same(got.view(np.uint32), r2.readPixelsFloat().view(np.uint32), ("wide digits image", rank, n, w, h))
-                for o in (r, r2, pbuf, nbuf):
-                    o.destroy()
-        finally:
-            dev.destroy()
-
-
-def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again(monkeypatch):
+def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
     """The default ranking of the tile-first frame rests on nothing unverified (include/splat.h, NOTE on ranking): the
-    per-tile sort checks every finished list for strictly increasing (depth key, splat index) order.  Here a list is
-    deliberately left as an out-of-lane-order rank would leave it (first two entries swapped, test hook): the frame's
-    report must carry the flag, the facade must get SPLAT_ERR_RETRY and render the frame again, the context must rank
-    with ballots from then on, and the lists and the image that come back must be the oracle's.  First (host-synchronised)
-    frame, sync-free frame, both size classes and a list long enough for the global-memory passes."""
-    # (position of the swapped pair in the victim's list: 0; 63 | 64 and 255 | 256 are the pairs the check reads across a
-    # wave / a round of the workgroup; 4000 lies in the long class's in-LDS range)
-    monkeypatch.delenv("SPLAT_RANK", raising=False)  # (the DEFAULT policy is what this is about, whatever the suite runs under)
-    cases = [(3000, 128, 96, 71, 1.0, False, 0), (20000, 640, 360, 72, 1.0, True, 63), (30000, 48, 32, 73, 8.0, True, 255),
-             (30000, 48, 32, 75, 8.0, False, 4000), (6000, 16, 16, 74, 30.0, False, 1000)]
-    for n, w, h, seed, rs, sync_free, position in cases:
-        dev = sr.Device(0)  # (a failed check switches its context to ballots for good: one context per case)
-        try:
-            assert dev.rankStatus() == {"policy": "checked", "atomicsOrdered": True, "orderFaults": 0}
-            props, normals, u = make_case(n, w, h, seed, rs)
-            ref = oracle_pipeline(props, normals, u, w, h)
-            victim = int(np.argmax(ref["counts"]))  # the longest list
-            assert ref["counts"][victim] >= position + 2, (ref["counts"][victim], position)
-            pbuf, nbuf = dev.createBufferFrom(props), dev.createBufferFrom(normals)
-            r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
-            if sync_free:  # a good first frame, then the fault hits a frame whose report is only read at the next call
-                r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-                good = r.readPixelsFloat().copy()
-            dev.injectOrderFault(victim, position)
-            r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-            total = r.finish()  # learns of the failed check, renders the frame again (with ballots)
-            # the facade books it as a MISRANKED frame, apart from capacity events (ADVICE r3: one flag for both hid it)
-            assert r.framesMisranked == 1 and not r.previousFrameOverflowed
-            st = dev.rankStatus()
-            assert st["policy"] == "ballot" and st["orderFaults"] == 1, st
-            assert total == ref["indices"].shape[0]
-            assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], ("order check", n, w, h, "counts"))
-            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("order check", n, w, h, "lists"),
-                        offsets=ref["offsets"], keys=ref["keys"])
-            img = r.readPixelsFloat()
-            if sync_free:
-                assert_same(img.view(np.uint32), good.view(np.uint32), ("order check", n, w, h, "image"))
-            # and it stays right, without further faults, on the ballot ranking
-            r.render(u, pbuf, nbuf, None, w, h, wantFloat=True)
-            assert r.finish() == total and dev.rankStatus()["orderFaults"] == 1
-            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("order check", n, w, h, "lists after"),
-                        offsets=ref["offsets"], keys=ref["keys"])
-            for o in (r, pbuf, nbuf):
-                o.destroy()
-        finally:
-            dev.destroy()
+    per-tile sort checks every finished list for strictly increasing (depth key, splat index) order.  tests/hooks_child.py
+    leaves a list as an out-of-lane-order rank would (two neighbours swapped — a TEST HOOK, compiled only into
+    libsplat_hip_hooks.so: the shipped kernels do not carry its parameters) and asserts the whole recovery; it runs as a
+    child process on that build, this process keeps the shipped library."""
+    import subprocess
+    import sys
+    assert not device_lib_has_hooks(), "the suite must run on the shipped library (SPLAT_LIB_PATH points at a hooks build?)"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPLAT_LIB_PATH=_lib.HOOKS_LIB_PATH)
+    env.pop("SPLAT_RANK", None)  # (the DEFAULT policy is what this is about, whatever the suite runs under)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "hooks_child.py"), "order_check"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and "order_check ok: 5 cases" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def device_lib_has_hooks():
+    return bool(getattr(_lib.load(), "has_hooks", False))
 
 
 def test_ranking_policies(monkeypatch):

@@ -137,6 +137,8 @@ def test_js_frame_matches_oracle(tmp_path):
     got8 = np.fromfile(tmp_path / "out.rgba8", np.uint8).reshape(h, w, 4)
     assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 3
     assert (np.abs(got8.astype(int) - want8.astype(int)).max(axis=2) > 1).mean() <= 2e-3
+    # TileRenderer.render from JS with the reference's eleven arguments and no bindTileData (src/TileRenderer.ts:234-246)
+    assert info["tileRendererEqualsStaged"] is True
     # the whole-frame facade from JS: Renderer.render on the two-plane property layout, tile-first order
     assert info["framePairs"] == ref["indices"].shape[0]
     frame8 = np.fromfile(tmp_path / "frame.rgba8", np.uint8).reshape(h, w, 4)
@@ -313,3 +315,59 @@ def test_index_js_is_the_stripped_twin_of_index_ts():
     heads_ts = re.findall(r"^  (?:static |get |set )?(\w+)(?:<[^>]*>)?\(", ts, flags=re.M)
     heads_js = re.findall(r"^  (?:static |get |set )?(\w+)\(", committed, flags=re.M)
     assert heads_ts == heads_js
+
+
+def test_index_d_ts_declares_what_index_ts_defines():
+    """napi/index.d.ts (what a TypeScript caller compiles against) is written by hand beside index.ts (no tsc in this image to emit
+    it): every exported class of index.ts is declared there, every method the declaration promises exists in index.ts with the
+    same number of parameters (optional ones included), and TileRenderer.render carries the reference's eleven arguments."""
+    import re
+    ts = open(os.path.join(NAPI, "index.ts")).read()
+    dts = open(os.path.join(NAPI, "index.d.ts")).read()
+
+    def split_top(text):
+        out, depth, cur = [], 0, ""
+        for k, ch in enumerate(text):
+            if ch in "([{<":
+                depth += 1
+            elif ch in ")]}" or (ch == ">" and text[k - 1] != "="):
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        return [x for x in out + [cur] if x.strip()]
+
+    def classes(text, decl):
+        found = {}
+        for m in re.finditer(r"^(?:export )?(?:declare )?class (\w+)(?: extends \w+)? \{[^\n]*\n(.*?)^\}", text, flags=re.M | re.S):
+            methods = {}
+            for line in m.group(2).split("\n"):
+                h = re.match(r"^  (?:static |async )*(\w+)(?:<[^>]*>)?\((.*)\)(?::[^{;]*)?[;{]", line) if decl else \
+                    re.match(r"^  (?:static |async )*(\w+)(?:<[^>]*>)?\((.*?)\)(?:: [^{]*)? \{", line)
+                if h and h.group(1) not in ("if", "for", "while", "switch", "return"):
+                    methods[h.group(1)] = len(split_top(h.group(2)))
+            found[m.group(1)] = methods
+        return found
+
+    one_liners = r"^export (?:declare )?class \w+(?: extends \w+)? \{.*\}[ \t]*$"  # (a whole declaration on one line: fields only)
+    defined, declared = classes(ts, False), classes(re.sub(one_liners, "", dts, flags=re.M), True)
+    exported = set(re.search(r"module\.exports = \{(.*?)\};", ts, flags=re.S).group(1).replace("\n", " ").replace(" ", "").split(","))
+    exported_classes = {c for c in defined if c in exported or c.rstrip("_") in exported}
+    declared_names = set(re.findall(r"export (?:declare )?class (\w+)", dts))  # (one-line declarations too)
+    assert {c.rstrip("_") for c in exported_classes} <= declared_names, sorted({c.rstrip("_") for c in exported_classes} - declared_names)
+    checked = 0
+    for cls, methods in declared.items():
+        impl = defined.get(cls) or defined.get(cls + "_")
+        assert impl is not None, f"index.d.ts declares class {cls}, index.ts has none"
+        for name, arity in methods.items():
+            owner = impl
+            if name not in owner:  # inherited (TileRenderer extends ComputeShaderRenderer)
+                base = re.search(rf"class {cls}_? extends (\w+)", ts)
+                owner = defined.get(base.group(1), {}) if base else {}
+            assert name in owner, f"index.d.ts: {cls}.{name} is not defined in index.ts"
+            assert owner[name] == arity, f"{cls}.{name}: {arity} parameters declared, {owner[name]} defined"
+            checked += 1
+    assert checked > 80
+    assert declared["TileRenderer"]["render"] == 11 and defined["TileRenderer"]["render"] == 11  # src/TileRenderer.ts:234-246

@@ -14,7 +14,10 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# (splat_debug_rerun_tile_sort is an experiment hook: the test build of the library carries it, the shipped one does not)
+os.environ.setdefault("SPLAT_LIB_PATH", os.path.join(ROOT, "splat_renderer_amd", "libsplat_hip_hooks.so"))
 import numpy as np
 import splat_renderer_amd as sr
 from splat_renderer_amd import _lib
@@ -30,9 +33,7 @@ cam.setAspect(w / h)
 u = cam.uniforms(w, h)
 dev = sr.Device(0)
 lib = dev.lib
-rerun = lib._dll.splat_debug_rerun_tile_sort  # (an experiment hook: not part of splat.h)
-rerun.restype = C.c_int
-rerun.argtypes = [C.c_void_p, C.c_void_p]
+rerun = lib.splat_debug_rerun_tile_sort
 pm = sr.SplatPropertyManager(dev, n)
 pm.setFromArrays(props)
 nbuf = dev.createBufferFrom(normals)
