@@ -42,6 +42,33 @@ def composite_traffic_model(p_staged, width, height, records, prelit, disc=False
     return per * p_staged + 4 * width * height
 
 
+def composite_model_floor(p_staged, alg_bytes, copy_gbs, ahead):
+    """DESIGN.md §4 "the composite's floor": the time k_composite_px AS DESIGNED (a builder and a consumer wave per 16x16 tile,
+    chunks of 32 entries, a trip = every lane of the consumer takes its next entry) cannot beat on this frame, from counted work
+    and measured constants (profiles/r04_a_px_list_cap_experiment_C2.txt, r04_o_trip_cost_C2.txt):
+      fixed      5.5 us  an empty launch of the grid (8161 workgroups at C2) incl. its drain
+                 4.5 us  a tile's start is three DEPENDENT memory round trips (tile descriptor -> list indices -> records) before its
+                         first build: ~1.5 us each under load, overlapped with nothing of the same tile
+      issue      chunks x (150 builder + trips_per_chunk x 41 consumer) wave-instructions, at one instruction per SIMD and cycle
+                 (1024 SIMDs x 2.4 GHz): every wave instruction of the kernel issued back to back with no stall at all
+      hbm        the algorithmic bytes at the box's measured copy rate
+    floor = max(fixed + issue, hbm).  The kernel's measured time follows 22 us + 0.58 us per 1000 chunks (early-out on): 2.3x the
+    issue term — VALU busy 0.50, waves parked at barriers / LDS latency the rest — over a 22 us intercept (the fixed part, the tiles'
+    first two chunks, and the ordering workgroup, which alone takes 22 us and runs beside the tiles)."""
+    chunks = p_staged / 32.0
+    trips = 8.8 if ahead == 1 else 6.4  # per chunk, measured at C2 (3.97e5 / 2.91e5 trips over 45k chunks)
+    instr = chunks * (150.0 + trips * (41.0 if ahead == 1 else 45.0))
+    issue_us = instr / (1024 * 2400.0)
+    hbm_us = alg_bytes / (copy_gbs * 1e3)
+    floor = max(10.0 + issue_us, hbm_us)
+    return {"model_floor_us": round(floor, 1), "fixed_us": 10.0, "issue_us": round(issue_us, 1), "hbm_at_copy_rate_us": round(hbm_us, 1),
+            "chunks": round(chunks), "frac_of_peak_at_floor": round(alg_bytes / (floor * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+            "fit_us": round(22.0 + 0.58 * chunks / 1000.0, 1) if ahead == 1 else None,
+            "note": "DESIGN.md section 4: what this design cannot beat on this frame (every wave instruction issued back to back on every "
+                    "SIMD, three dependent round trips per tile start, an empty launch); fit_us = the measured line 22 us + 0.58 us per "
+                    "1000 chunks (early-out on)"}
+
+
 def per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, lit, disc, pmc=None):
     """every kernel group of the tile-first frame against the 8 TB/s HBM roof, from the bytes each is
     built to move (the tile-first frame's own byte table, which replaces SURVEY §8d's sort / count / fill
@@ -110,7 +137,9 @@ def cpu_baseline(name, props, normals, u, width, height):
             "sample": f"1 full frame of {name} (N={n}, {width}x{height}), oracle/oracle.c model A, 1 thread",
             "seconds": round(t1, 3), "stage_ms": [round(x, 1) for x in r1["stage_ms"]],
             "all_cores": {"value": n / tn / 1e6, "cores": cores, "seconds": round(tn, 3),
-                          "note": "projector + composite banded over pthreads; sort and binning stay serial"},
+                          "note": "projector + composite banded over pthreads; the oracle's sort and binSorted stay serial: "
+                                  f"{round((r1['stage_ms'][2] + r1['stage_ms'][3]) / 1e3, 2)} s of these {round(tn, 2)} s "
+                                  "(stage_ms[2] + stage_ms[3] of the 1-thread run) — the ratio to 1 thread says nothing about what the host could do"},
             "model_b_sequential_raster": {"seconds": round(tb, 3), "cores": 1,
                                           "note": "oracle restatement of SequentialRenderer.ts raster only (sorted order given)"},
             "frame_u8": rn["out_u8"]}
@@ -417,6 +446,10 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                 "valu_frac": pmc.get("valu_busy_frac"),
                 "valu_frac_source": pmc.get("valu_source") if pmc.get("valu_busy_frac") else None,
                 "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs}
+    if px and not disc:
+        m = composite_model_floor(p_staged, comp_bytes, copy_gbs, ahead=1)
+        roofline["model_floor_us"] = m.pop("model_floor_us")
+        roofline["model"] = m
     result = {
         "metric": "Msplats/sec", "value": n * args.steps / dt / 1e6, "unit": "Msplats/s",
         "frames_per_s": args.steps / dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -436,7 +469,10 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                    # how the timed frames ranked equal digits (include/splat.h NOTE on ranking): 'checked' = returning LDS atomics +
                    # a complete order check of every tile list; orderFaults > 0 would mean frames were re-rendered with ballots and
                    # the rest of the run took the slower ballot path — asserted zero below
-                   "ranking": ranking},
+                   "ranking": ranking,
+                   # what ran before and inside the timed region besides the K frames
+                   "untimed_prewarm": "~12 ms of device-to-device copies (the box's copy rate) + ~40 ms of the frame itself before the W warm-up frames",
+                   "composite_event_stride": TIMED_EVERY},
         "roofline": roofline,
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "roofline_per_kernel": per_kernel_rooflines(stage_ms, n, pairs, p_used, width, height, args.records == "lit" and not disc, disc, pmc),
@@ -456,6 +492,7 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                 "avg_launch_ms": off["ms"], "pairs_consumed": round(off["consumed"]), "algorithmic_bytes_per_launch": ob,
                 "achieved_GBps": ob / (off["ms"] / 1e3) / 1e9, "frac": ob / (off["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
                 "traffic_model": composite_traffic_model(off["staged"], width, height, args.records, prelit),
+                "model": composite_model_floor(off["staged"], ob, copy_gbs, ahead=2) if px else None,
                 "note": "k_composite alone with the alpha>=0.99 break disabled on the timed frame's lists: SURVEY 8d composite-only figure"}}
     if not disc and not args.no_extras:
         # two frames in flight (PipelinedRenderer: frames alternate between two streams): the same frames, more of them
@@ -486,7 +523,15 @@ def run_single(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
         # (the composite's tile order and per-tile look-ahead, the sync-free pair limit).  Here: a left-button drag of
         # 0.5 degrees of azimuth per frame through the controller, frames enqueued back to back, nothing read in between.
         try:
-            result.setdefault("extra", {})["orbit"] = orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, dt / args.steps * 1e3, composite_ms)
+            orb = orbit_leg(dev, n, width, height, tile, args, pbuf, nbuf, dt / args.steps * 1e3, composite_ms)
+            result.setdefault("extra", {})["orbit"] = orb
+            # next to the headline, not under extra: `value` renders ONE view K times — the best case of what a frame
+            # learns from the frame before it; this is the same renderer with the camera turning 0.5 degrees per frame
+            result["moving_camera"] = {"value": orb["value"], "unit": "Msplats/s", "ms_per_step": orb["ms_per_step"],
+                                       "composite_ms": orb["composite_ms"], "over_static": orb["over_static"],
+                                       "over_standing_still_at_the_last_view": orb["over_standing_still_at_the_last_view"],
+                                       "frames": orb["frames"], "degrees_per_frame": orb["degrees_per_frame"],
+                                       "note": "FrameLoop + OrbitCameraController; detail under extra.orbit"}
         except Exception as e:  # (an extra: never costs the run its headline)
             result.setdefault("extra", {})["orbit"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
