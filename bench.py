@@ -138,8 +138,9 @@ def cpu_baseline(name, props, normals, u, width, height):
             "seconds": round(t1, 3), "stage_ms": [round(x, 1) for x in r1["stage_ms"]],
             "all_cores": {"value": n / tn / 1e6, "cores": cores, "seconds": round(tn, 3),
                           "note": "projector + composite banded over pthreads; the oracle's sort and binSorted stay serial: "
-                                  f"{round((r1['stage_ms'][2] + r1['stage_ms'][3]) / 1e3, 2)} s of these {round(tn, 2)} s "
-                                  "(stage_ms[2] + stage_ms[3] of the 1-thread run) — the ratio to 1 thread says nothing about what the host could do"},
+                                  f"{round((rn['stage_ms'][2] + rn['stage_ms'][3]) / 1e3, 2)} s of these {round(tn, 2)} s "
+                                  "(its own stage_ms[2] + stage_ms[3]) — the ratio to 1 thread says nothing about what the host could do",
+                          "stage_ms": [round(x, 1) for x in rn["stage_ms"]]},
             "model_b_sequential_raster": {"seconds": round(tb, 3), "cores": 1,
                                           "note": "oracle restatement of SequentialRenderer.ts raster only (sorted order given)"},
             "frame_u8": rn["out_u8"]}
