@@ -434,7 +434,7 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         const uint32_t band_tiles = tile_row1 > tile_row0 ? (tile_row1 - tile_row0) * ntx : 1u;
         stage_begin(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
-                              b->counts, b->d_total + 1, band_tiles >= 6144u ? (uint32_t)(b->total / band_tiles) : 0u);
+                              b->counts, b->d_total + 1, band_tiles >= 6144u ? (uint32_t)(b->total / band_tiles) : 0u, band_tiles);
         stage_end(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;

@@ -273,7 +273,7 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
                           uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list); // frame_flags: FRAME_FLAG_ORDER is raised if a list fails the order check
+                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list, uint32_t band_tiles = 0); // frame_flags: FRAME_FLAG_ORDER is raised if a list fails the order check
 int binner_settle(splat_binner *b); // resolves a pending report; SPLAT_ERR_CAPACITY if that frame overflowed, SPLAT_ERR_RETRY if its lists failed the order check
 // composite.hip: splat_composite with the frame's report attached (report != NULL: the launch's first workgroup stores
 // {frame_total[0], frame_total[1], seq} into the host-mapped report words; see tile_report)

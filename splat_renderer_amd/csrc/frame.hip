@@ -146,18 +146,21 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_prepare_tf(const float4 *
 constexpr uint32_t BTC_THREADS = 512, BTC_WAVES = BTC_THREADS / 64, BTC_PER_THREAD = 8, BTC_GROUP = BTC_THREADS * BTC_PER_THREAD;
 static_assert(BTC_GROUP == 4096 && BTC_PER_THREAD * BTC_WAVES == 64, "a group is 4096 records = 64 (row, wave) cells of 64 records");
 template <int FORMAT>
-__global__ __launch_bounds__(BTC_THREADS) void k_band_prepare_tfc(const float4 *__restrict__ records, uint32_t n, BinParams bp,
+__global__ __launch_bounds__(BTC_THREADS) __attribute__((amdgpu_waves_per_eu(FORMAT == SPLAT_RECORDS_COMPACT ? 6 : 4, 8))) void k_band_prepare_tfc(const float4 *__restrict__ records, uint32_t n, BinParams bp,
                                                                   uint32_t *__restrict__ keys_c, uint32_t *__restrict__ range_c,
                                                                   uint32_t *__restrict__ idx_c, uint32_t *__restrict__ kept_groups,
                                                                   TfHistOut ho) {
     __shared__ uint32_t lh[BTC_WAVES][256];
     __shared__ uint32_t rowcnt[64]; // kept per (row of 512 records, wave), then its exclusive scan: the cells in index order
     __shared__ uint32_t wsum[BTC_WAVES];
+    __shared__ uint32_t s_rng[BTC_GROUP]; // the kept splats' packed tile ranges, compacted: the histogram is counted over DENSE lanes
+    __shared__ uint32_t s_kept;
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (blockIdx.x == 0 && tid == 0) *ho.overflow_flag = 0;
+    const uint32_t blk = xcd_block_of(blockIdx.x, ho.xcd_per); // (each XCD a contiguous eighth of the groups: common.h)
+    if (blk >= ho.num_parts) return;
+    if (blk == 0 && tid == 0) *ho.overflow_flag = 0;
     for (uint32_t j = tid; j < BTC_WAVES * 256; j += BTC_THREADS) (&lh[0][0])[j] = 0;
-    __syncthreads();
-    const uint32_t g0 = blockIdx.x * BTC_GROUP;
+    const uint32_t g0 = blk * BTC_GROUP;
     // every record of the thread is in flight before the first is looked at (one memory round trip per workgroup)
     float4 ra[BTC_PER_THREAD], rb[BTC_PER_THREAD], rc[BTC_PER_THREAD];
 #pragma unroll
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(BTC_THREADS) void k_band_prepare_tfc(const float4 *
         }
     }
     uint32_t rng[BTC_PER_THREAD], key[BTC_PER_THREAD];
-    uint32_t okbits = 0, pairs = 0;
+    uint32_t okbits = 0;
 #pragma unroll
     for (uint32_t k = 0; k < BTC_PER_THREAD; ++k) {
         const uint32_t i = g0 + k * BTC_THREADS + tid;
@@ -206,16 +209,12 @@ __global__ __launch_bounds__(BTC_THREADS) void k_band_prepare_tfc(const float4 *
             if (ok) {
                 rng[k] = pack_range32(true, tx0, tx1, ty0, ty1);
                 key[k] = depth_key_of(depth);
-                pairs += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
             }
         }
         const unsigned long long m = __ballot(ok);
         okbits |= ok ? (1u << k) : 0u;
         if (lane == 0) rowcnt[k * BTC_WAVES + w] = (uint32_t)__popcll(m);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) pairs += __shfl_xor(pairs, d);
-    if (lane == 0) wsum[w] = pairs;
     __syncthreads();
     // where each (row, wave) cell's kept splats go: an exclusive scan of the 64 counts in (row, wave) order = ascending index
     if (w == 0) {
@@ -228,18 +227,9 @@ __global__ __launch_bounds__(BTC_THREADS) void k_band_prepare_tfc(const float4 *
         }
         rowcnt[lane] = incl - mine;
         if (lane == 63) {
-            kept_groups[blockIdx.x] = incl;
-            uint32_t ps = 0;
-#pragma unroll
-            for (uint32_t v = 0; v < BTC_WAVES; ++v) ps += wsum[v];
-            ho.blocksums[blockIdx.x] = ps;
+            kept_groups[blk] = incl;
+            s_kept = incl;
         }
-    }
-    if (tid <= ho.mask) {
-        uint32_t hs = 0;
-#pragma unroll
-        for (uint32_t v = 0; v < BTC_WAVES; ++v) hs += lh[v][tid];
-        ho.hist[(size_t)tid * ho.num_parts + blockIdx.x] = hs;
     }
     __syncthreads();
 #pragma unroll
@@ -247,11 +237,37 @@ __global__ __launch_bounds__(BTC_THREADS) void k_band_prepare_tfc(const float4 *
         const bool ok = (okbits >> k) & 1u;
         const unsigned long long m = __ballot(ok);
         if (ok) {
-            const uint32_t pos = g0 + rowcnt[k * BTC_WAVES + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            range_c[pos] = rng[k];
-            keys_c[pos] = key[k];
-            idx_c[pos] = g0 + k * BTC_THREADS + tid;
+            const uint32_t local = rowcnt[k * BTC_WAVES + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            range_c[g0 + local] = rng[k];
+            keys_c[g0 + local] = key[k];
+            idx_c[g0 + local] = g0 + k * BTC_THREADS + tid;
+            s_rng[local] = rng[k];
         }
+    }
+    __syncthreads();
+    // the first pass's histogram over the kept splats, one per lane (a band of an eighth of the screen keeps an eighth: counted
+    // where they stood, every wave ran the rectangle loops eight times over for its few kept lanes)
+    const uint32_t kept = s_kept;
+    uint32_t pairs = 0;
+    for (uint32_t j = tid; j < kept; j += BTC_THREADS) {
+        const uint32_t r = s_rng[j];
+        pairs += hist_add_rect(lh[w], r & 0xffu, (r >> 8) & 0xffu, (r >> 16) & 0xffu, r >> 24, bp.ntx, ho.mask);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pairs += __shfl_xor(pairs, d);
+    if (lane == 0) wsum[w] = pairs;
+    __syncthreads();
+    if (tid <= ho.mask) {
+        uint32_t hs = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < BTC_WAVES; ++v) hs += lh[v][tid];
+        ho.hist[(size_t)tid * ho.num_parts + blk] = hs;
+    }
+    if (tid == 0) {
+        uint32_t ps = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < BTC_WAVES; ++v) ps += wsum[v];
+        ho.blocksums[blk] = ps;
     }
 }
 
@@ -424,11 +440,13 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
             if (hipMalloc((void **)&binner->band_idx, slots * 4 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "band index hipMalloc");
             binner->band_idx_cap = n_records;
         }
-        const TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
+        TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
         if (compacting) {
+            ho.xcd_per = blocks >= 64u ? div_up(blocks, 8u) : 0u; // (the groups dealt as k_tf_scatter<COMPACTED> deals them)
+            const uint32_t grid_blocks = ho.xcd_per ? 8u * ho.xcd_per : blocks;
 #define SPLAT_BAND_PREPARE_C(FORMAT)                                                                                                  \
-    hipLaunchKernelGGL(k_band_prepare_tfc<FORMAT>, dim3(blocks), dim3(BTC_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp, \
+    hipLaunchKernelGGL(k_band_prepare_tfc<FORMAT>, dim3(grid_blocks), dim3(BTC_THREADS), 0, ctx->stream, (const float4 *)records, n_records, bp, \
                        sorter->keys, binner->range32, binner->band_idx, sorter->hist, ho)
             if (disc) SPLAT_BAND_PREPARE_C(SPLAT_RECORDS_DISC48);
             else if (compact) SPLAT_BAND_PREPARE_C(SPLAT_RECORDS_COMPACT);

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <=
 
 // mean_list: the frame's pairs per tile of its band, as far as the host knows them (the previous frame's in a sync-free frame).
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list) {
+                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list, uint32_t band_tiles) {
     {
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
@@ -648,11 +648,13 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
     const uint32_t inject_pos = ctx->inject_order_position;
     ctx->inject_order_fault = 0;
 #endif
-    // A screen of so few tiles that every workgroup of the long class's kernel is resident at once (three per CU) gains
-    // nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it does:
-    // a tenth of a C0 frame).
-    // (forcing one launch at C2: slower, profiles/r03_j_tile_sort_one_launch_C2.txt)
-    const bool one_class = tiles <= 3u * 256u;
+    // A screen — or a multi-GPU rank's band of tile rows — of so few tiles that the long class's kernel takes them in a round or
+    // a few gains nothing from a second, denser class: one launch sorts every tile (a dependent launch costs ~5 us whatever it
+    // does, and each launch ends with the life of its longest tile).  Measured with virtual ranks (profiles/r05_h_band_tile_sort_
+    // one_class.txt): bands of 840 tiles (C2, eight ranks) 32 -> 22 us, of 2040 (four ranks) 35 -> 29, of ~3000 (C3, eight ranks)
+    // 48 -> 44; a whole C2 screen (8160 tiles, 4969 of them non-empty) is slower with one launch (77 -> 83 us,
+    // profiles/r03_j_tile_sort_one_launch_C2.txt).
+    const bool one_class = (band_tiles ? band_tiles : tiles) <= 4200u;
     // The short class's size, by the frame's mean list length (measured, `bin_tile_sort` with 8 | 12 | 16 elements per thread:
     // C1, mean 570: 45.6 | 41.4 | 45.9 us; C3, mean 910: 193 | 180 | 188; C2, mean 1380: 77.0 | 76.6 | 72.9 — and a third
     // class in between loses its launch: profiles/r04_u_tile_sort_classes.txt).  SPLAT_TILE_SORT_SHORT=8 | 12 | 16 forces one.
