@@ -21,7 +21,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = sr.Device(0)
 t0, pairs_total, with_second_pass, worst = time.time(), 0, 0, 0
 for case in range(cases):
-    n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 8000), rng.integers(8000, 60000)]))
+    # (every tenth case is a frame of up to 400k splats: from 64 blocks / partitions up the kernels deal their blocks per XCD)
+    n = int(rng.integers(60000, 400000)) if case % 10 == 9 else int(rng.choice([rng.integers(1, 300), rng.integers(300, 8000), rng.integers(8000, 60000)]))
     side = lambda: int(rng.choice([rng.integers(1, 64), rng.integers(64, 700), rng.integers(700, 4097)]))
     w, h = side(), side()
     # keep the pair count in hand: splats scaled so that one covers a few tiles at most on this screen
