@@ -5,6 +5,6 @@ set -e
 name=$1; flags=$2
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$root/splat_renderer_amd/_variants"
-make -s -C "$root/splat_renderer_amd/csrc" -j8 BUILD=_obj_$name OUT=../_variants/libsplat_$name.so EXTRA="$flags"
+make -s -C "$root/splat_renderer_amd/csrc" -j8 BUILD=_obj_$name OUT=../_variants/libsplat_$name.so EXTRA="$flags" lib
 rm -rf "$root/splat_renderer_amd/csrc/_obj_$name"
 echo "built splat_renderer_amd/_variants/libsplat_$name.so ($flags)"
