@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 2
+#define SPLAT_ABI_VERSION 3 /* 3 (round 5): splat_composite_options lost its slack argument; splat_sort_lookback_timeouts and sort mode 1 are gone; the splat_debug_* hooks moved behind SPLAT_TEST_HOOKS */
 
 #define SPLAT_OK 0
 #define SPLAT_ERR_INVALID (-1)  /* bad argument */

@@ -56,7 +56,7 @@ def test_python_binding_covers_the_header():
     from splat_renderer_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     lib = _lib.load()
-    assert lib.splat_abi_version() == 2
+    assert lib.splat_abi_version() == 3
 
 
 def test_napi_addon_has_one_method_per_abi_entry_point():

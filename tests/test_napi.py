@@ -38,7 +38,7 @@ def test_addon_loads_and_exports():
     r = node("const a=require('./splat_napi.node');console.log(JSON.stringify({abi:a.abi_version(),names:Object.keys(a)}))")
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout)
-    assert d["abi"] == 2
+    assert d["abi"] == 3
     for name in ("ctx_create", "project", "extract_keys", "sort_run", "scan_u32", "bin_run", "composite", "render_frame",
                  "update_props", "buf_upload", "buf_download", "project_slice_compact", "band_frame", "band_settle",
                  "comm_unique_id", "comm_init", "comm_destroy", "allgather_records"):
