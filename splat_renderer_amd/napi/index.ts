@@ -161,7 +161,7 @@ class SplatPropertyManager {
   declare litValid: boolean;
   declare planes: PropertyPlanes | null;
   declare lit: PropertyPlanes | null;
-  declare litNormals: any;
+  declare litNormals: unknown; // (the normals buffer's device pointer the lit plane was shaded from)
   constructor(device: Device, numSplats: number) {
     this.device = device;
     this.numSplats = numSplats;
@@ -533,7 +533,7 @@ class Renderer {
   declare output: Buffer_ | null;
   declare width: number;
   declare height: number;
-  declare last: number;
+  declare last: [Float32Array | Buffer_, Buffer_ | PropertyPlanes, Buffer_, Buffer_ | null, number, number] | null;
   declare recordFormat: number;
   constructor(device: Device, context: unknown = null, presentationFormat: string = 'rgba8unorm', numPoints: number = 0, tileSize: number = 16, options: { footprint?: Footprint; records?: "lit" | "projected" } = {}) {
     this.device = device;
@@ -748,7 +748,7 @@ function scaleAABB(aabb: [ArrayLike<number>, ArrayLike<number>], scale: number):
 
 class PointManager {
   declare device: Device;
-  declare scene: SDFScene;
+  declare scene: SDFScene | null;
   declare seed: number;
   declare positions: Float32Array | null;
   declare numPoints: number;
@@ -841,7 +841,7 @@ let nextPrimId = 0, nextSminId = 0;
 const aabb = (p, e) => [Float32Array.from([p[0] - e[0], p[1] - e[1], p[2] - e[2]]), Float32Array.from([p[0] + e[0], p[1] + e[1], p[2] + e[2]])];
 class Primitive {
   declare id: string;
-  declare position: any;
+  declare position: Float32Array;
   constructor(id: string, position: ArrayLike<number>) {
     this.id = id || `prim_${nextPrimId++}`;
     this.position = Float32Array.from(position || [0, 0, 0]);
@@ -934,7 +934,7 @@ const union = (a, b) => binary(new Operation('union'), a, b), intersection = (a,
 const subtraction = (a, b) => binary(new Operation('subtraction'), a, b), smoothUnion = (k, a, b) => binary(new SmoothUnion(k), a, b);
 class SDFScene { // src/sdf/Scene.ts:72-152
   declare root: SceneNode | null;
-  declare primitiveMap: any;
+  declare primitiveMap: Map<string, Primitive>;
   constructor() {
     this.root = null;
     this.primitiveMap = new Map();
@@ -985,7 +985,7 @@ class SceneStage {
   declare device: Device;
   declare scene: SDFScene;
   declare numPoints: number;
-  declare currentStructureHash: any;
+  declare currentStructureHash: string;
   declare program: Float32Array;
   constructor(device: Device, scene: SDFScene, numPoints: number) {
     this.device = device;
@@ -1050,14 +1050,14 @@ class CurvatureSampler extends SceneStage { // src/CurvatureSampler.ts
  * EventEmitter adapter) or null: without one, feed the handlers synthetic events {clientX, clientY, button, deltaY}. */
 class OrbitCameraController {
   declare camera: Camera;
-  declare canvas: any;
+  declare canvas: unknown; // (headless: whatever the caller passes for the reference's HTMLCanvasElement)
   declare isDragging: boolean;
-  declare dragButton: any;
-  declare lastMouseX: any;
-  declare lastMouseY: any;
-  declare rotationSpeed: any;
-  declare panSpeed: any;
-  declare zoomSpeed: any;
+  declare dragButton: number;
+  declare lastMouseX: number;
+  declare lastMouseY: number;
+  declare rotationSpeed: number;
+  declare panSpeed: number;
+  declare zoomSpeed: number;
   constructor(camera: Camera, canvas: { addEventListener(type: string, handler: (e: PointerLikeEvent) => void, options?: unknown): void } | null = null) {
     this.camera = camera;
     this.canvas = canvas;
@@ -1180,15 +1180,15 @@ class BandRenderer {
   declare width: number;
   declare height: number;
   declare tileSize: number;
-  declare per: any;
-  declare first: any;
-  declare count: any;
+  declare per: number;
+  declare first: number;
+  declare count: number;
   declare row0: number;
   declare row1: number;
   declare sorter: RadixSorter;
   declare binner: GPUTileBinner;
-  declare shard: any;
-  declare gathered: any;
+  declare shard: Buffer_;
+  declare gathered: Buffer_;
   declare output: Buffer_ | null;
   constructor(device: Device, comm: Comm | null, numPoints: number, width: number, height: number, tileSize: number = 16) {
     this.device = device;

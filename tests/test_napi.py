@@ -371,3 +371,47 @@ def test_index_d_ts_declares_what_index_ts_defines():
             checked += 1
     assert checked > 80
     assert declared["TileRenderer"]["render"] == 11 and defined["TileRenderer"]["render"] == 11  # src/TileRenderer.ts:234-246
+
+
+def test_index_ts_field_annotations_agree_with_what_is_assigned():
+    """No TypeScript compiler is in this image (`declare bound: boolean` held an array, `last: number` a tuple).  A
+    check of the kind of error that slips through without one: for every `declare field: T;` of a class of napi/index.ts, every
+    `this.field = <literal>` in that class — an array literal, true / false, null, a number, a string, `new X(...)` — must be
+    admissible for T; and every field a class assigns is declared (by it or a base class)."""
+    import re
+    ts = open(os.path.join(NAPI, "index.ts")).read()
+    bodies = {m.group(1): (m.group(2), m.group(3)) for m in
+              re.finditer(r"^class (\w+)(?: extends (\w+))? \{[^\n]*\n(.*?)^\}", ts, flags=re.M | re.S)}
+    problems, checked = [], 0
+    for cls, (base, body) in bodies.items():
+        fields = dict(re.findall(r"^  declare (\w+): (.*?);(?: //.*)?$", body, flags=re.M))
+        for name, t in fields.items():
+            if re.search(r"\b(any|unknown)\b", t):
+                continue
+            for a in re.finditer(r"this\.%s = ([^;]+);" % re.escape(name), body):
+                rhs, ok = a.group(1).strip(), None
+                if rhs.startswith("["):
+                    ok = "[]" in t or "Array" in t or t.lstrip().startswith("[")
+                elif rhs in ("true", "false"):
+                    ok = "boolean" in t
+                elif rhs == "null":
+                    ok = "null" in t
+                elif re.fullmatch(r"-?\d+(\.\d+)?(e-?\d+)?", rhs):
+                    ok = "number" in t
+                elif re.fullmatch(r"'[^']*'|\"[^\"]*\"", rhs):
+                    ok = "string" in t or rhs.strip("'\"") in t
+                elif rhs.startswith("new "):
+                    c = re.match(r"new (\w+)", rhs).group(1)
+                    ok = c in t or c.rstrip("_") in t
+                if ok is not None:
+                    checked += 1
+                    if not ok:
+                        problems.append(f"{cls}.{name}: declared `{t}`, assigned `{rhs[:50]}`")
+        declared, b = set(fields), base
+        while b in bodies:
+            declared |= set(re.findall(r"^  declare (\w+):", bodies[b][1], flags=re.M))
+            b = bodies[b][0]
+        for u in sorted(set(re.findall(r"this\.(\w+) = ", body)) - declared):
+            problems.append(f"{cls}.{u}: assigned but not declared")
+    assert not problems, "\n".join(problems)
+    assert checked > 60
