@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r05_band_path_and_C3.sh <outdir>: VERDICT r4 items 1 and 2 in one call on the GPU box (run from the repository root):
+# tools/attic/r05_band_path_and_C3.sh <outdir>: VERDICT r4 items 1 and 2 in one call on the GPU box (run from the repository root):
 # bench.py's N > 1 path with one rank under torch.distributed.run (C2, C3; all-gather cut and --exchange auto), then C3's
 # kernel trace and counters (SQ, LDS, FETCH/WRITE) with the program directly after `--`.
 out=$1
