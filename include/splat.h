@@ -198,6 +198,10 @@ int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
 int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr);
 /* EXPERIMENT HOOK (tools/overlap_probe.py): the per-tile sort of the binner's last tile-first frame once more, on ctx's stream. */
 int splat_debug_rerun_tile_sort(splat_ctx *ctx, splat_binner *binner);
+/* EXPERIMENT HOOK (tools/lds_atomic_rate.py): milliseconds of a kernel that does iters x 4 LDS instructions per wave at random
+ * counters of the wave's own 256-entry table, workgroups_per_cu four-wave workgroups per CU: kind 0 returning atomic adds (the
+ * sort kernels' ranking instruction), 1 plain reads, 2 non-returning atomic adds. */
+int splat_debug_lds_rate(splat_ctx *ctx, int kind, uint32_t workgroups_per_cu, uint32_t iters, float *ms);
 #endif
 /* The lane-efficient composite keeps, per context, for each of the last few (four) bands of tile rows it composited (a band
  * = these rows of this binner's lists), what its previous launch over that band cost per tile (chunks of

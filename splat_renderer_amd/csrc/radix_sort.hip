@@ -499,6 +499,57 @@ __global__ __launch_bounds__(256) void k_probe_lds_atomic_order(uint32_t rounds,
     if (lane == 0 && bad) atomicAdd(mismatches, bad);
 }
 
+#ifdef SPLAT_TEST_HOOKS
+// EXPERIMENT HOOK (tools/lds_atomic_rate.py): what a CU's LDS delivers in RETURNING atomics — the per-tile sort's ranking
+// instruction — against plain reads.  WGS workgroups of four waves per CU (the per-tile sort holds three to six), every wave on its
+// own 256-counter table, `iters` rounds of four independent instructions at pseudo-random counters (the sort's digits); KIND 0 =
+// ds_add_rtn_u32, 1 = ds_read_b32, 2 = non-returning ds_add_u32.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_probe_lds_rate(uint32_t iters, uint32_t seed, uint32_t *sink) {
+    __shared__ uint32_t cnt[4][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (uint32_t i = lane; i < 256; i += 64) cnt[w][i] = 0;
+    __syncthreads();
+    uint32_t state = seed ^ (blockIdx.x * 2654435761u) ^ (tid * 40503u + 1u), acc = 0;
+    for (uint32_t r = 0; r < iters; ++r) {
+        uint32_t d[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            state = state * 1664525u + 1013904223u;
+            d[it] = (state >> 12) & 255u;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (KIND == 0) acc += atomicAdd(&cnt[w][d[it]], 1u);
+            else if (KIND == 1) acc += cnt[w][d[it]];
+            else __hip_atomic_fetch_add(&cnt[w][d[it]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), acc += d[it];
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc; // (keeps the results alive)
+}
+
+int radix_probe_lds_rate(splat_ctx *ctx, int kind, uint32_t wgs_per_cu, uint32_t iters, float *ms_out) {
+    int rc = ctx_ensure_scan_ws(ctx, 256);
+    if (rc != SPLAT_OK) return rc;
+    hipEvent_t a, b;
+    HIP_TRY(ctx, hipEventCreate(&a));
+    HIP_TRY(ctx, hipEventCreate(&b));
+    const dim3 grid(256u * wgs_per_cu);
+    for (int rep = 0; rep < 2; ++rep) { // (the second launch is the timed one)
+        HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+        if (kind == 0) hipLaunchKernelGGL(k_probe_lds_rate<0>, grid, dim3(256), 0, ctx->stream, iters, 777u, (uint32_t *)ctx->scan_ws);
+        else if (kind == 1) hipLaunchKernelGGL(k_probe_lds_rate<1>, grid, dim3(256), 0, ctx->stream, iters, 777u, (uint32_t *)ctx->scan_ws);
+        else hipLaunchKernelGGL(k_probe_lds_rate<2>, grid, dim3(256), 0, ctx->stream, iters, 777u, (uint32_t *)ctx->scan_ws);
+        HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
+    }
+    HIP_TRY(ctx, hipEventSynchronize(b));
+    HIP_TRY(ctx, hipEventElapsedTime(ms_out, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return SPLAT_OK;
+}
+#endif
+
 int radix_probe_lds_atomic_order(splat_ctx *ctx, uint64_t *mismatches_host) {
     int rc = ctx_ensure_scan_ws(ctx, 256);
     if (rc != SPLAT_OK) return rc;
@@ -693,6 +744,12 @@ int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ctx->debug_tile_order = (const uint32_t *)order_dptr;
     return SPLAT_OK;
+}
+
+int splat_debug_lds_rate(splat_ctx *ctx, int kind, uint32_t workgroups_per_cu, uint32_t iters, float *ms) {
+    if (!ctx || !ms) return ctx_fail(ctx, SPLAT_ERR_INVALID, "ctx/ms is NULL");
+    ARG_CHECK(ctx, kind >= 0 && kind <= 2 && workgroups_per_cu >= 1 && workgroups_per_cu <= 8 && iters >= 1 && iters <= (1u << 20));
+    return radix_probe_lds_rate(ctx, kind, workgroups_per_cu, iters, ms);
 }
 
 int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t position) {
