@@ -7,8 +7,11 @@
 
 A step = one frame (project -> depth keys -> radix sort -> tile bin -> composite) over inputs
 already resident in HBM.  N=1: workload C2 (5M Gaussians @1920x1080, the configuration
-BASELINE.json's metric is quoted on).  N>1: the same frame sharded by tile-row bands with one
-RCCL all-gather of projected splats (strong scaling: total work fixed).  Prints ONE JSON line.
+BASELINE.json's metric is quoted on).  N>1: the same frame sharded by tile-row bands (strong
+scaling: total work fixed) — with one RCCL all-gather of projected splats (north_star's cut), or
+with every rank projecting all splats for its own band and nothing exchanged; both are timed on
+the node after warm-up and the faster runs the timed region (--exchange auto, the default; the
+line says which, and both trial times).  Prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -295,11 +298,12 @@ def main():
                     help="isotropic: ComputeShaderRenderer's screen-space Gaussian (SURVEY §8a contract 3, the headline); "
                          "disc: SequentialRenderer's oriented disc (parity vs the CPU rasteriser of SequentialRenderer.ts; "
                          "48-byte exchange records at N>1)")
-    ap.add_argument("--exchange", default="allgather", choices=["auto", "allgather", "none"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "none"],
                     help="multi-GPU: allgather = every rank projects 1/N of the splats, ONE RCCL all-gather of the records, band work "
-                         "(north_star's cut); none = every rank projects all splats itself and renders its band (no collective); "
-                         "auto = a timed trial of both, the faster is run.  Default allgather; the other cut's trial time is "
-                         "reported as an extra key either way")
+                         "(north_star's cut); none = every rank projects all splats itself and renders its band (no collective: every "
+                         "rank holds the scene anyway); auto (default) = both cuts are set up and timed on THIS node after warm-up (8 frames "
+                         "each, slowest rank decides, all ranks take the same one) and the faster runs the timed region — which one ran "
+                         "is config.exchange_chosen, both trial times are config.frame_loop_trial_ms")
     ap.add_argument("--collective", default="abi", choices=["abi", "torch"],
                     help="multi-GPU: who issues the frame's all-gather — the C ABI's own RCCL communicator (splat_comm_init / "
                          "splat_allgather_records, default; falls back to torch if RCCL cannot be bound) or torch.distributed")
@@ -766,6 +770,7 @@ def _run_multi(args, name, n, width, height, tile, ntx, nty, props, normals, u, 
                                    f"tile-row bands x{world} (balanced by pairs per row) + 1 RCCL all-gather of {per * stages.rec_floats * 4} B "
                                    f"shards per frame" + ("" if pipe is None else "; 2 frames in flight: the next frame's projection + "
                                                            "all-gather run on a second stream under this frame's band work")),
+                   "exchange_policy": args.exchange, "exchange_chosen": "none" if local is not None else "allgather",
                    "collective": None if local is not None else collective,
                    "frame_loop_trial_ms": {k: round(v, 4) for k, v in loop_ms.items()},
                    "footprint": ("oriented disc (SequentialRenderer.ts:91-142)" if stages.disc else

@@ -224,6 +224,11 @@ struct TfHistOut {
     uint32_t mask, num_parts;
     uint32_t block = TF_BLOCK_LARGE; // splats per block
     uint32_t xcd_per = 0;            // (set by project_launch: xcd_block_of's second argument)
+    // a strict band's projector may leave the splats that can reach the band COMPACTED per group of 4096 (range and key at the
+    // front of the group's segment of range32 / keys, their indices in cidx, their number in kept_groups[group]; the histogram
+    // then has one column per group): k_tf_scatter<COMPACTED> runs over those only (frame.hip, k_band_prepare_tfc, does the same
+    // for gathered records)
+    uint32_t *cidx = nullptr, *kept_groups = nullptr;
 };
 // Which logical block (partition, 1024-splat block) workgroup i of a grid takes.  xcd_per == 0: block i.  Otherwise (xcd_per =
 // ceil(blocks / 8), grid = 8 * xcd_per): the hardware deals consecutive workgroups to the eight XCDs in turn, so workgroup i

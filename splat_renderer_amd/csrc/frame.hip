@@ -351,6 +351,32 @@ static int frame_order(const splat_binner *b) {
     return g_frame_order;
 }
 
+// A band that is a fraction of the screen keeps a fraction of the splats: its first pass compacts them per group of 4096 and the
+// scatter runs over the kept splats only.  Measured with virtual ranks at C2: a gain from a third of the rows down (four ranks:
+// level; eight: -10 us per rank), a loss at half of them (two ranks: +13 us: the compacting pass costs 7 us more than the plain
+// one).  (SPLAT_BAND_COMPACT=0 | 1 forces one of them.)
+static bool band_compacting(uint32_t row0, uint32_t row1, uint32_t nty) {
+    static int s_compact = -2;
+    if (s_compact == -2) {
+        const char *e = getenv("SPLAT_BAND_COMPACT");
+        s_compact = !e ? -1 : (e[0] == '0' ? 0 : 1);
+    }
+    return s_compact == 1 || (s_compact == -1 && 3u * (row1 - row0) <= nty);
+}
+
+// (the compacted splats' indices: one slot per record, rounded up to whole groups)
+static int binner_reserve_band_idx(splat_ctx *ctx, splat_binner *binner, uint32_t n_records) {
+    if (n_records <= binner->band_idx_cap) return SPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (binner->band_idx) (void)hipFree(binner->band_idx);
+    binner->band_idx = nullptr;
+    binner->band_idx_cap = 0;
+    const size_t slots = (size_t)div_up(n_records, BTC_GROUP) * BTC_GROUP;
+    if (hipMalloc((void **)&binner->band_idx, slots * 4 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "band index hipMalloc");
+    binner->band_idx_cap = n_records;
+    return SPLAT_OK;
+}
+
 extern "C" {
 
 int splat_band_keys(splat_ctx *ctx, splat_sorter *sorter, const void *projected, uint32_t n, uint32_t width, uint32_t height,
@@ -420,25 +446,11 @@ int splat_band_frame(splat_ctx *ctx, splat_sorter *sorter, splat_binner *binner,
         rc = binner_reserve(binner, ntx * nty, n_records);
         if (rc != SPLAT_OK) return rc;
         const BinParams bp = {width, height, tile, ntx, nty, row0, row1};
-        // A band that is a fraction of the screen keeps a fraction of the records: its prepare pass compacts them per group of
-        // 4096 records and the scatter runs over the kept splats only (k_band_prepare_tfc).  Measured with virtual ranks at C2:
-        // a gain from a third of the rows down (four ranks: level; eight: -10 us per rank), a loss at half of them (two ranks:
-        // +13 us: the compacting pass costs 7 us more than the plain one).  (SPLAT_BAND_COMPACT=0 | 1 forces one of them.)
-        static int s_compact = -2;
-        if (s_compact == -2) {
-            const char *e = getenv("SPLAT_BAND_COMPACT");
-            s_compact = !e ? -1 : (e[0] == '0' ? 0 : 1);
-        }
-        const bool compacting = s_compact == 1 || (s_compact == -1 && 3u * (row1 - row0) <= nty);
+        const bool compacting = band_compacting(row0, row1, nty);
         const uint32_t blocks = div_up(n_records, compacting ? BTC_GROUP : BTF_BLOCK);
-        if (compacting && n_records > binner->band_idx_cap) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (binner->band_idx) (void)hipFree(binner->band_idx);
-            binner->band_idx = nullptr;
-            binner->band_idx_cap = 0;
-            const size_t slots = (size_t)div_up(n_records, BTC_GROUP) * BTC_GROUP;
-            if (hipMalloc((void **)&binner->band_idx, slots * 4 + 256) != hipSuccess) return ctx_fail(ctx, SPLAT_ERR_OOM, "band index hipMalloc");
-            binner->band_idx_cap = n_records;
+        if (compacting) {
+            rc = binner_reserve_band_idx(ctx, binner, n_records);
+            if (rc != SPLAT_OK) return rc;
         }
         TfHistOut ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, blocks};
         stage_begin(ctx, SPLAT_STAGE_PROJECT);
@@ -631,13 +643,22 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
     ARG_CHECK(ctx, (((uintptr_t)props | (uintptr_t)projected) & 15) == 0);
     const bool tile_first = fast && frame_order(binner) == SPLAT_FRAME_TILE_FIRST;
     TfHistOut ho = {};
+    // a strict band of a fraction of the screen (the exchange-free multi-GPU cut): the projector leaves the splats that can reach
+    // it compacted per group of 4096 (project.hip: k_project_hist_bandc) and the scatter runs over those only
+    const bool band_compact = tile_first && bp.skip_outside && band_compacting(row0, row1, nty);
     if (tile_first) { // the projector also counts each 1024-splat block's pairs per low tile-id digit
         rc = binner_reserve(binner, ntx * nty, n);
         if (rc != SPLAT_OK) return rc;
         // small frames: 256-splat blocks, so that the first pass is more than a handful of workgroups
-        const uint32_t block = (n <= TF_SMALL_FRAME_SPLATS && !bp.skip_outside) ? TF_BLOCK_SMALL : TF_BLOCK_LARGE;
+        const uint32_t block = band_compact ? BTC_GROUP : (n <= TF_SMALL_FRAME_SPLATS && !bp.skip_outside) ? TF_BLOCK_SMALL : TF_BLOCK_LARGE;
         ho = {binner->tf_hist, binner->blocksums, binner->d_total + 1, (1u << tile_id_low_bits(ntx * nty)) - 1u, div_up(n, block), block};
         binner->tf_block = block;
+        if (band_compact) {
+            rc = binner_reserve_band_idx(ctx, binner, n);
+            if (rc != SPLAT_OK) return rc;
+            ho.cidx = binner->band_idx;
+            ho.kept_groups = sorter->hist; // (free in the tile-first order: the sorter's own passes do not run)
+        }
     }
     if (disc && n > binner->discs_cap) { // (48 bytes per splat: room for the lit records)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -658,6 +679,8 @@ static int render_frame_impl(splat_ctx *ctx, splat_sorter *sorter, splat_binner 
                         tile_first ? &ho : nullptr, normals, 1, disc ? binner->discs : nullptr, &lio);
     if (rc != SPLAT_OK) return rc;
     binner->tf_hist_ready = tile_first;
+    binner->tf_cidx = band_compact ? binner->band_idx : nullptr;
+    binner->tf_kept = band_compact ? sorter->hist : nullptr;
     // (with per-index tile ranges the binner never reads the records; it only wants a non-null pointer)
     const void *bin_records = projected ? projected : (const void *)binner->discs;
     if (tile_first) {

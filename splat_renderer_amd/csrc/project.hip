@@ -136,7 +136,8 @@ template <bool WITH_KEYS, bool WITH_RANGE, bool DISC, bool LIT = false>
 __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const SplatIn &in, uint32_t i, uint32_t index_base,
                                                 float4 *__restrict__ projected, uint32_t *__restrict__ keys,
                                                 uint32_t *__restrict__ payload, uint32_t *__restrict__ range32, const BinParams &bp,
-                                                const DiscIO &dio, const LitIO &lio = LitIO{}) {
+                                                const DiscIO &dio, const LitIO &lio = LitIO{}, uint32_t kslot = 0xffffffffu) {
+    const uint32_t ks = kslot == 0xffffffffu ? i : kslot; // where the key and the packed range go (k_project_hist_bandc: a compacted slot)
     float4 a, b;
     float depth;
     if (DISC) {
@@ -169,15 +170,15 @@ __device__ __forceinline__ uint32_t project_one(const FrameUniforms &u, const Sp
         projected[(size_t)i * 2 + 1] = b;
     }
     if (WITH_KEYS) {
-        keys[i] = depth_key(depth);
-        if (payload) payload[i] = index_base + i; // (frame path: the sort's first pass synthesises it)
+        keys[ks] = depth_key(depth);
+        if (payload) payload[ks] = index_base + i; // (frame path: the sort's first pass synthesises it)
     }
     uint32_t packed = 1u;
     if (WITH_RANGE) { // the binner's clamped tile range while the bounds are still in registers
         uint32_t tx0, tx1, ty0, ty1;
         const bool ok = tile_range(a, bp.width, bp.height, bp.tile, bp.ntx, bp.nty, bp.row0, bp.row1, tx0, tx1, ty0, ty1);
         packed = pack_range32(ok, tx0, tx1, ty0, ty1);
-        range32[i] = packed;
+        range32[ks] = packed;
     }
     return packed;
 }
@@ -350,6 +351,113 @@ __global__ __launch_bounds__(256) void k_project_hist_band(FrameUniforms u, cons
     }
 }
 
+// The strict band's projector for bands of a fraction of the screen (the exchange-free multi-GPU cut: every rank projects all
+// splats for its own tile rows): groups of 4096 splats, the conservative test for all of them (every position load of a thread in
+// flight at once), the survivors compacted through LDS, their full projection on DENSE lanes, and what the binner's first pass
+// reads of them — packed tile range, depth key, splat index — left compacted at the front of the group's segment
+// (ho.cidx / ho.kept_groups): k_tf_scatter<COMPACTED> then runs one workgroup per group over the survivors only, as it does after
+// k_band_prepare_tfc for gathered records.  Same records, keys, ranges, histogram and lists as k_project_hist_band.
+// (256 threads x 16 splats — every group of a 5 M-splat frame resident at once instead of two rounds — measured the same: 51 us at
+// C2 on eight ranks.  20 us of that are the test of all splats, at the copy rate; the survivors' exact projection — ~550
+// instructions a splat with its fourteen IEEE divides, behind a gather — is the rest: VALU 0.34 busy, waves waiting 0.55 of their
+// cycles: profiles/r05_r_exchange_free_band_projector.txt)
+constexpr uint32_t PBC_THREADS = 512, PBC_WAVES = PBC_THREADS / 64, PBC_PER = 8, PBC_GROUP = PBC_THREADS * PBC_PER;
+static_assert(PBC_GROUP == 4096 && PBC_PER * PBC_WAVES == 64, "a group is 4096 splats = 64 (row, wave) cells of 64 splats");
+template <bool DISC, bool LIT>
+__global__ __launch_bounds__(PBC_THREADS) void k_project_hist_bandc(FrameUniforms u, const float4 *__restrict__ pos_radius, uint32_t stride_vec4,
+                                                                    uint32_t n, float4 *__restrict__ projected, uint32_t *__restrict__ keys_c,
+                                                                    uint32_t *__restrict__ range_c, BinParams bp, TfHistOut ho, DiscIO dio, LitIO lio) {
+    __shared__ uint32_t lh[PBC_WAVES][256];
+    __shared__ uint32_t rowcnt[64];
+    __shared__ uint32_t wsum[PBC_WAVES];
+    __shared__ uint32_t s_list[PBC_GROUP];
+    __shared__ uint32_t s_kept;
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const uint32_t blk = xcd_block_of(blockIdx.x, ho.xcd_per);
+    if (blk >= ho.num_parts) return;
+    if (blk == 0 && tid == 0) *ho.overflow_flag = 0;
+    for (uint32_t j = tid; j < PBC_WAVES * 256; j += PBC_THREADS) (&lh[0][0])[j] = 0;
+    const uint32_t g0 = blk * PBC_GROUP;
+    uint32_t okbits = 0;
+#pragma unroll
+    for (uint32_t k0 = 0; k0 < PBC_PER; k0 += 8) {
+        float4 pr[8], nr[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t i = g0 + (k0 + k) * PBC_THREADS + tid;
+            pr[k] = nr[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i < n) {
+                pr[k] = pos_radius[(size_t)i * stride_vec4];
+                if (DISC) nr[k] = dio.normals[(size_t)i * dio.normal_stride];
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t i = g0 + (k0 + k) * PBC_THREADS + tid;
+            bool keep = false;
+            if (i < n) {
+                float r = fabsf(pr[k].w);
+                if (DISC) r *= fmaxf(1.0f, 1.001f * __builtin_amdgcn_sqrtf((nr[k].x * nr[k].x + nr[k].y * nr[k].y) + nr[k].z * nr[k].z));
+                keep = !cannot_reach_band<DISC>(u, pr[k], r, bp); // (NaN radius or normal: kept, the exact path decides)
+            }
+            const unsigned long long m = __ballot(keep);
+            okbits |= keep ? (1u << (k0 + k)) : 0u;
+            if (lane == 0) rowcnt[(k0 + k) * PBC_WAVES + w] = (uint32_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if (w == 0) { // the cells in (row, wave) order = ascending splat index
+        const uint32_t mine = rowcnt[lane];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += x;
+        }
+        rowcnt[lane] = incl - mine;
+        if (lane == 63) {
+            ho.kept_groups[blk] = incl;
+            s_kept = incl;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PBC_PER; ++k) {
+        const bool keep = (okbits >> k) & 1u;
+        const unsigned long long m = __ballot(keep);
+        if (keep) s_list[rowcnt[k * PBC_WAVES + w] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = g0 + k * PBC_THREADS + tid;
+    }
+    __syncthreads();
+    const uint32_t kept = s_kept;
+    uint32_t local = 0;
+    for (uint32_t j = tid; j < kept; j += PBC_THREADS) {
+        const uint32_t i = s_list[j];
+        const SplatIn in = load_splat<DISC, LIT>(pos_radius, stride_vec4, i, dio, lio);
+        // (the record goes to the splat's own index — the composite gathers it by that —, key and range to the compacted slot)
+        const uint32_t r = project_one<true, true, DISC, LIT>(u, in, i, 0, projected, keys_c, nullptr, range_c, bp, dio, lio, g0 + j);
+        ho.cidx[g0 + j] = i;
+        const uint32_t tx0 = r & 0xffu, tx1 = (r >> 8) & 0xffu, ty0 = (r >> 16) & 0xffu, ty1 = r >> 24;
+        if (tx0 > tx1 || ty0 > ty1) continue; // (passed the conservative test, reaches no tile of the band: an empty range in the list)
+        local += hist_add_rect(lh[w], tx0, tx1, ty0, ty1, bp.ntx, ho.mask);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if (lane == 0) wsum[w] = local;
+    __syncthreads();
+    if (tid <= ho.mask) {
+        uint32_t hs = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < PBC_WAVES; ++v) hs += lh[v][tid];
+        ho.hist[(size_t)tid * ho.num_parts + blk] = hs;
+    }
+    if (tid == 0) {
+        uint32_t ps = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < PBC_WAVES; ++v) ps += wsum[v];
+        ho.blocksums[blk] = ps;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_extract_keys(const float4 *__restrict__ projected, uint32_t n, uint32_t n_padded,
                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ payload) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -438,7 +546,20 @@ int project_launch(splat_ctx *ctx, const float *uniforms, const void *pos_radius
             hipLaunchKernelGGL((k_project_hist<D, L, 4>), grid_, block, 0, ctx->stream, u, src, pr_stride_vec4, n, n_padded,               \
                                (float4 *)projected, (uint32_t *)keys, range32, *bp, ho_, dio, lio);                                        \
     } while (0)
-    if (hist_out && keys && range32 && !payload && index_base == 0) {
+    if (hist_out && hist_out->cidx && bp->skip_outside && keys && range32 && !payload && index_base == 0) {
+        // a strict band of a fraction of the screen: groups of 4096 splats, the survivors left compacted (hist_out->num_parts = groups)
+        TfHistOut ho_ = *hist_out;
+        ho_.xcd_per = ho_.num_parts >= 64u ? div_up(ho_.num_parts, 8u) : 0u;
+        const dim3 grid_(ho_.xcd_per ? 8u * ho_.xcd_per : ho_.num_parts);
+#define SPLAT_PROJECT_BANDC(D, L)                                                                                                      \
+    hipLaunchKernelGGL((k_project_hist_bandc<D, L>), grid_, dim3(PBC_THREADS), 0, ctx->stream, u, src, pr_stride_vec4, n, (float4 *)projected, \
+                       (uint32_t *)keys, range32, *bp, ho_, dio, lio)
+        if (disc_lit) SPLAT_PROJECT_BANDC(true, true);
+        else if (disc) SPLAT_PROJECT_BANDC(true, false);
+        else if (with_lit) SPLAT_PROJECT_BANDC(false, true);
+        else SPLAT_PROJECT_BANDC(false, false);
+#undef SPLAT_PROJECT_BANDC
+    } else if (hist_out && keys && range32 && !payload && index_base == 0) {
         // (a strict band's kernel works in 1024-splat blocks only: the caller keeps hist_out->block at TF_BLOCK_LARGE for it)
         if (disc_lit && bp->skip_outside) SPLAT_PROJECT_HIST_LAUNCH(k_project_hist_band, true, true);
         else if (disc_lit) SPLAT_PROJECT_HIST_LAUNCH_PER(true, true);

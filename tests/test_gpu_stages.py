@@ -1769,8 +1769,9 @@ def test_bench_band_path_runs_as_a_fresh_process(device, launcher):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--band-path", "--config", "C1", "--steps", "6", "--warmup", "2",
-            "--exchange", "auto"]
+    # (torchrun: the default policy, --exchange auto — both cuts timed, the faster run; plain: north_star's all-gather cut forced)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--band-path", "--config", "C1", "--steps", "6", "--warmup", "2"] + \
+           ([] if launcher == "torchrun" else ["--exchange", "allgather"])
     if launcher == "torchrun":
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -1795,4 +1796,7 @@ def test_bench_band_path_runs_as_a_fresh_process(device, launcher):
     assert cfg["ranking"]["orderFaults"] == [0] and (os.environ.get("SPLAT_RANK") or cfg["ranking"]["policy"] == ["checked"])
     assert cfg["per_rank"][0]["tile_rows"] == [0, -(-h // 16)] and cfg["per_rank"][0]["pairs_consumed"] > 0
     assert {"serial", "no_exchange_every_rank_projects_all"} <= set(cfg["frame_loop_trial_ms"])
+    assert cfg["exchange_policy"] == ("auto" if launcher == "torchrun" else "allgather")
+    assert cfg["exchange_chosen"] in (("allgather", "none") if launcher == "torchrun" else ("allgather",))
+    assert (cfg["collective"] is None) == (cfg["exchange_chosen"] == "none") and ex["in_timed_region"] == (cfg["exchange_chosen"] == "allgather")
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel"] == "k_composite_px"
