@@ -352,16 +352,16 @@ static int frame_order(const splat_binner *b) {
 }
 
 // A band that is a fraction of the screen keeps a fraction of the splats: its first pass compacts them per group of 4096 and the
-// scatter runs over the kept splats only.  Measured with virtual ranks at C2: a gain from a third of the rows down (four ranks:
-// level; eight: -10 us per rank), a loss at half of them (two ranks: +13 us: the compacting pass costs 7 us more than the plain
-// one).  (SPLAT_BAND_COMPACT=0 | 1 forces one of them.)
+// scatter runs over the kept splats only.  Measured with virtual ranks at C2: a gain up to a third of the rows and still at 23 of
+// 68 (the tallest of four pair-balanced bands: 0.200 -> 0.185 ms without an exchange, 0.184 -> 0.178 with), a loss at half of
+// them (two ranks: +3..8 us).  The rule: bands of at most two fifths of the rows.  (SPLAT_BAND_COMPACT=0 | 1 forces one of them.)
 static bool band_compacting(uint32_t row0, uint32_t row1, uint32_t nty) {
     static int s_compact = -2;
     if (s_compact == -2) {
         const char *e = getenv("SPLAT_BAND_COMPACT");
         s_compact = !e ? -1 : (e[0] == '0' ? 0 : 1);
     }
-    return s_compact == 1 || (s_compact == -1 && 3u * (row1 - row0) <= nty);
+    return s_compact == 1 || (s_compact == -1 && 5u * (row1 - row0) <= 2u * nty);
 }
 
 // (the compacted splats' indices: one slot per record, rounded up to whole groups)
