@@ -198,6 +198,9 @@ int splat_debug_set_tile_order(splat_ctx *ctx, const void *order_dptr);
 int splat_debug_set_tile_sort_order(splat_ctx *ctx, const void *order_dptr);
 /* EXPERIMENT HOOK (tools/overlap_probe.py): the per-tile sort of the binner's last tile-first frame once more, on ctx's stream. */
 int splat_debug_rerun_tile_sort(splat_ctx *ctx, splat_binner *binner);
+/* TEST HOOK: how many k_tile_sort launches this context's last per-tile sort made (2: a short and a long size class; 1: a band of
+ * few tiles, or a sync-free frame after one that had no tile beyond the short class). */
+int splat_debug_tile_sort_launches(splat_ctx *ctx, uint32_t *launches);
 /* EXPERIMENT HOOK (tools/lds_atomic_rate.py): milliseconds of a kernel that does iters x 4 LDS instructions per wave at random
  * counters of the wave's own 256-entry table, workgroups_per_cu four-wave workgroups per CU: kind 0 returning atomic adds (the
  * sort kernels' ranking instruction), 1 plain reads, 2 non-returning atomic adds. */

@@ -135,6 +135,7 @@ HOOK_SIGNATURES = {
     "splat_debug_set_tile_order": (_i, [_vp, _vp]),
     "splat_debug_set_tile_sort_order": (_i, [_vp, _vp]),
     "splat_debug_rerun_tile_sort": (_i, [_vp, _vp]),
+    "splat_debug_tile_sort_launches": (_i, [_vp, C.POINTER(_u32)]),
     "splat_debug_lds_rate": (_i, [_vp, _i, _u32, _u32, C.POINTER(C.c_float)]),
 }
 HOOKS_LIB_PATH = os.path.join(_HERE, "libsplat_hip_hooks.so")

@@ -432,12 +432,16 @@ int binner_run(splat_binner *b, const void *projected, uint32_t n_splats, const 
         //  every class is one round of workgroups and the smallest short class is the fastest: measured at G = 2, 4, 8,
         //  profiles/r04_u_tile_sort_classes.txt)
         const uint32_t band_tiles = tile_row1 > tile_row0 ? (tile_row1 - tile_row0) * ntx : 1u;
+        const uint64_t band_key = ((uint64_t)tile_row0 << 48) ^ ((uint64_t)tile_row1 << 32) ^ tiles; // (same screen, same band)
         stage_begin(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         rc = tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload,
-                              b->counts, b->d_total + 1, band_tiles >= 6144u ? (uint32_t)(b->total / band_tiles) : 0u, band_tiles);
+                              b->counts, b->d_total + 1, band_tiles >= 6144u ? (uint32_t)(b->total / band_tiles) : 0u, band_tiles,
+                              (async && b->last_band_key == band_key) ? b->last_long_tiles : 0xffffffffu, &b->last_short_class);
         stage_end(ctx, SPLAT_STAGE_BIN_TILE_SORT);
         if (rc != SPLAT_OK) return rc;
         b->pairs.result_in_primary = true;
+        b->pending_tile_first = true;
+        b->last_band_key = band_key;
         b->report_for_composite = b->pinned_dev;
         b->report_seq = ++b->seq;
         b->pending = true;
@@ -504,6 +508,10 @@ int binner_settle(splat_binner *b) {
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint32_t total = ((volatile uint32_t *)b->pinned)[0], flags = ((volatile uint32_t *)b->pinned)[1];
+    // (tile-first frames: how many tiles that frame's short size class could not hold — what the next frame's per-tile sort
+    // launches by: tile_sort_launch)
+    b->last_long_tiles = b->pending_tile_first ? ((volatile uint32_t *)b->pinned)[3] : 0xffffffffu;
+    b->pending_tile_first = false;
     b->last_total = total;
     b->have_last = true;
     b->total = total;
@@ -546,7 +554,7 @@ int splat_debug_rerun_tile_sort(splat_ctx *ctx, splat_binner *b) {
     const uint32_t tiles = b->ntx * b->nty;
     const bool primary = tile_id_bits(tiles) - tile_id_low_bits(tiles) == 0;
     return tile_sort_launch(ctx, b->offsets, tiles, primary ? b->wide_a : b->wide_b, primary ? b->wide_b : b->wide_a, b->pairs.payload_b,
-                            nullptr, b->d_total + 3, tiles >= 6144u ? (uint32_t)(b->total / tiles) : 0u);
+                            nullptr, b->d_total + 4, tiles >= 6144u ? (uint32_t)(b->total / tiles) : 0u); // (flags and counters of its own: words 4..6)
 }
 #endif
 
@@ -559,7 +567,7 @@ int splat_bin_create(splat_ctx *ctx, uint32_t tile_size, splat_binner **out) {
     b->ctx = ctx;
     b->tile = tile_size;
     b->pairs.ctx = ctx;
-    if (hipMalloc((void **)&b->d_total, 16) != hipSuccess || hipHostMalloc((void **)&b->pinned, 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipMalloc((void **)&b->d_total, 32) != hipSuccess || hipHostMalloc((void **)&b->pinned, 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&b->pinned_dev, b->pinned, 0) != hipSuccess ||
         hipEventCreateWithFlags(&b->readback_done, hipEventDisableTiming) != hipSuccess) {
         if (b->d_total) (void)hipFree(b->d_total);

@@ -48,6 +48,7 @@ struct splat_ctx {
     const uint32_t *debug_sort_order = nullptr; // experiment hook (splat_debug_set_tile_sort_order)
     uint32_t inject_order_fault = 0; // test hook (splat_debug_inject_order_fault): tile + 1 whose list the next tile sort swaps ...
     uint32_t inject_order_position = 0; // ... at entries position, position + 1
+    uint32_t tile_sort_launches = 0; // test hook (splat_debug_tile_sort_launches): k_tile_sort launches of the last per-tile sort
 #endif
     // splat_composite_options (-1 / 0 = the process default, i.e. the environment's): which kernel composites nearest-on-top
     // isotropic frames (0 quadrant, 1 pixel), and k_composite_px's schedule
@@ -193,6 +194,11 @@ struct splat_binner {
     bool pending = false;      // an async {total, overflow} readback is in flight
     bool have_last = false;
     uint32_t last_total = 0;
+    // the previous tile-first frame's count of tiles beyond its short size class (0xffffffff: not known), of which band
+    uint32_t last_long_tiles = 0xffffffffu;
+    uint64_t last_band_key = ~0ull;
+    uint32_t last_short_class = 0; // (the short class that frame's count is relative to: tile_sort_launch)
+    bool pending_tile_first = false;
     uint32_t pair_limit = 0;   // pairs this frame's grids / stores are bounded by
     uint32_t *pinned = nullptr; // 4 u32, host-pinned, mapped into the device's address space as pinned_dev
     uint32_t *pinned_dev = nullptr;
@@ -258,6 +264,7 @@ static inline uint32_t tile_id_low_bits(uint32_t tiles) {
 __device__ __forceinline__ void tile_report(const uint32_t *d_total, uint32_t *report, uint32_t seq) {
     report[0] = d_total[0];
     report[1] = d_total[1];
+    report[3] = d_total[3]; // (tile-first frames: tiles beyond the per-tile sort's short class, counted by its first launch)
     __threadfence_system();
     __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls this word
 }
@@ -278,7 +285,8 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
                           uint32_t tiles, uint32_t lo_bits, uint32_t hi_bits, uint32_t *hist, uint32_t *offsets, const uint32_t *d_total);
 int radix_rowscan_launch(splat_ctx *ctx, uint32_t *hist, uint32_t parts, uint32_t rows); // rows -> exclusive prefixes, totals at hist + 256*parts
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list, uint32_t band_tiles = 0); // frame_flags: FRAME_FLAG_ORDER is raised if a list fails the order check
+                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list, uint32_t band_tiles = 0,
+                     uint32_t long_tiles_hint = 0xffffffffu, uint32_t *short_class_io = nullptr); // frame_flags: FRAME_FLAG_ORDER is raised if a list fails the order check
 int binner_settle(splat_binner *b); // resolves a pending report; SPLAT_ERR_CAPACITY if that frame overflowed, SPLAT_ERR_RETRY if its lists failed the order check
 // composite.hip: splat_composite with the frame's report attached (report != NULL: the launch's first workgroup stores
 // {frame_total[0], frame_total[1], seq} into the host-mapped report words; see tile_report)

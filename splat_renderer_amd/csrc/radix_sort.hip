@@ -752,6 +752,12 @@ int splat_debug_lds_rate(splat_ctx *ctx, int kind, uint32_t workgroups_per_cu, u
     return radix_probe_lds_rate(ctx, kind, workgroups_per_cu, iters, ms);
 }
 
+int splat_debug_tile_sort_launches(splat_ctx *ctx, uint32_t *launches) {
+    if (!ctx || !launches) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx/launches is NULL");
+    *launches = ctx->tile_sort_launches;
+    return SPLAT_OK;
+}
+
 int splat_debug_inject_order_fault(splat_ctx *ctx, uint32_t tile, uint32_t position) {
     if (!ctx) return ctx_fail(nullptr, SPLAT_ERR_INVALID, "ctx is NULL");
     ARG_CHECK(ctx, tile != 0xffffffffu);

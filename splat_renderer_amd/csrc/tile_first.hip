@@ -222,6 +222,7 @@ __global__ __launch_bounds__(TF_THREADS, TF_SCATTER_WAVES) void k_tf_scatter(con
         if (tid == 0) {
             d_total[0] = all_pairs;
             d_total[2] = fits ? all_pairs : 0u;
+            d_total[3] = 0u; // (k_tile_sort's first launch counts the tiles beyond its short class here)
             if (!fits) atomicOr(overflow, 1u);
         }
         // the second pass's view of this output: per low digit where its run starts and how many pairs it holds,
@@ -449,7 +450,10 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <=
     constexpr uint32_t inject_tile = 0xffffffffu, inject_pos = 0; // (no tile is the victim: the swap below folds away)
 #endif
     const uint32_t base = offsets[t], n = offsets[t + 1] - base;
-    if (counts && tid == 0) counts[t] = n; // (first launch: the tile counts the composite reads)
+    if (counts && tid == 0) { // (first launch: the tile counts the composite reads, and how many tiles are beyond this class)
+        counts[t] = n;
+        if (n > TS_MAX_ITEMS * TS_THREADS) atomicAdd(frame_flags + 2, 1u);
+    }
     if (n <= n_above || (!LAST_CLASS && n > TS_CAP)) return; // empty, or another class's tile
     uint2 *src = vals + base, *dst = scratch + base;
     const bool in_lds = !LAST_CLASS || n <= TS_CAP;
@@ -577,6 +581,9 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <=
     }
 
     // ---- long list: the same passes through global memory -------------------------------------
+    // (in chunks of as many pairs per thread as the in-LDS path holds: a short class that runs as the last one must not
+    // pay registers for this path)
+    constexpr uint32_t CH_ITEMS = TS_MAX_ITEMS < TS_CHUNK_ITEMS ? TS_MAX_ITEMS : TS_CHUNK_ITEMS;
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const uint32_t shift = pass * 8;
         // digit totals of the whole list -> start of every digit's run
@@ -588,14 +595,14 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <=
         const uint32_t start = ts_scan256(sh.wave_sums, tot, tid);
         run_base[tid] = start;
         __syncthreads();
-        for (uint32_t c0 = 0; c0 < n; c0 += TS_CHUNK) {
+        for (uint32_t c0 = 0; c0 < n; c0 += CH_ITEMS * TS_THREADS) {
             for (uint32_t i = tid; i < TS_WAVES * 256; i += TS_THREADS) (&sh.wave_hist[0][0])[i] = 0;
             __syncthreads();
-            uint2 el[TS_CHUNK_ITEMS];
-            uint32_t rank[TS_CHUNK_ITEMS];
+            uint2 el[CH_ITEMS];
+            uint32_t rank[CH_ITEMS];
 #pragma unroll
-            for (uint32_t i = 0; i < TS_CHUNK_ITEMS; ++i) {
-                const uint32_t p = c0 + w * (TS_CHUNK_ITEMS * 64) + i * 64 + lane;
+            for (uint32_t i = 0; i < CH_ITEMS; ++i) {
+                const uint32_t p = c0 + w * (CH_ITEMS * 64) + i * 64 + lane;
                 el[i] = src[p < n ? p : n - 1];
                 rank[i] = 0;
                 if (p < n) rank[i] = wave_rank<RANK_ATOMIC>(sh.wave_hist[w], ((el[i].x - kmin) >> shift) & 255u);
@@ -607,8 +614,8 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <=
             run_base[tid] = rb + dcount;
             __syncthreads();
 #pragma unroll
-            for (uint32_t i = 0; i < TS_CHUNK_ITEMS; ++i) {
-                const uint32_t p = c0 + w * (TS_CHUNK_ITEMS * 64) + i * 64 + lane;
+            for (uint32_t i = 0; i < CH_ITEMS; ++i) {
+                const uint32_t p = c0 + w * (CH_ITEMS * 64) + i * 64 + lane;
                 if (p < n) {
                     const uint32_t d = ((el[i].x - kmin) >> shift) & 255u;
                     dst[sh.digit_base[d] + sh.wave_hist[w][d] + rank[i]] = el[i];
@@ -637,7 +644,8 @@ __global__ __launch_bounds__(TS_THREADS, TS_MAX_ITEMS <= 8 ? 6 : TS_MAX_ITEMS <=
 
 // mean_list: the frame's pairs per tile of its band, as far as the host knows them (the previous frame's in a sync-free frame).
 int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, uint2 *vals, uint2 *scratch, uint32_t *out_idx,
-                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list, uint32_t band_tiles) {
+                     uint32_t *counts, uint32_t *frame_flags, uint32_t mean_list, uint32_t band_tiles, uint32_t long_tiles_hint,
+                     uint32_t *short_class_io) {
     {
         int prc = ctx_resolve_rank_mode(ctx); // (probe of the LDS atomics' lane order, once per context)
         if (prc != SPLAT_OK) return prc;
@@ -675,16 +683,29 @@ int tile_sort_launch(splat_ctx *ctx, const uint32_t *offsets, uint32_t tiles, ui
         if (ra) SPLAT_TILE_SORT_(true, ITEMS, LAST, ABOVE, COUNTS);  \
         else SPLAT_TILE_SORT_(false, ITEMS, LAST, ABOVE, COUNTS);    \
     } while (0)
+    bool no_long = false;
     if (one_class) {
         SPLAT_TILE_SORT(TS_LONG_ITEMS, true, 0u, counts);
     } else {
-        if (short_items == 8u) SPLAT_TILE_SORT(8, false, 0u, counts);
-        else if (short_items == 12u) SPLAT_TILE_SORT(12, false, 0u, counts);
-        else SPLAT_TILE_SORT(16, false, 0u, counts);
-        SPLAT_TILE_SORT(TS_LONG_ITEMS, true, short_cap, nullptr);
+        // The frame before (same band, sync-free) had NO tile beyond the short class: the long class's launch would be 5 us of
+        // workgroups that look at their tile and leave (C1: every frame).  The short class's kernel then runs as the last
+        // class: a tile that has outgrown it since goes through its global-memory passes — slow, correct, and counted, so
+        // that the next frame launches both classes again.
+        // (the count is of the tiles beyond THAT frame's short class: it says nothing when the class has changed since)
+        no_long = long_tiles_hint == 0u && short_class_io && *short_class_io == short_items;
+        if (short_class_io) *short_class_io = short_items;
+        if (short_items == 8u) { if (no_long) SPLAT_TILE_SORT(8, true, 0u, counts); else SPLAT_TILE_SORT(8, false, 0u, counts); }
+        else if (short_items == 12u) { if (no_long) SPLAT_TILE_SORT(12, true, 0u, counts); else SPLAT_TILE_SORT(12, false, 0u, counts); }
+        else { if (no_long) SPLAT_TILE_SORT(16, true, 0u, counts); else SPLAT_TILE_SORT(16, false, 0u, counts); }
+        if (!no_long) SPLAT_TILE_SORT(TS_LONG_ITEMS, true, short_cap, nullptr);
     }
 #undef SPLAT_TILE_SORT_
 #undef SPLAT_TILE_SORT
+#ifdef SPLAT_TEST_HOOKS
+    ctx->tile_sort_launches = one_class || no_long ? 1u : 2u;
+#else
+    (void)no_long;
+#endif
     LAUNCH_CHECK(ctx, "k_tile_sort");
     return SPLAT_OK;
 }

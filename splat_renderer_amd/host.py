@@ -162,6 +162,12 @@ class Device:
         the next per-tile sort leaves entries position, position + 1 of tile `tile`'s list swapped."""
         check(self.lib.splat_debug_inject_order_fault(self.ctx, int(tile), int(position)), self.ctx)
 
+    def tileSortLaunches(self):
+        """TEST HOOK (splat_debug_tile_sort_launches; the test build only): k_tile_sort launches of the last per-tile sort."""
+        v = C.c_uint32(0)
+        check(self.lib.splat_debug_tile_sort_launches(self.ctx, C.byref(v)), self.ctx)
+        return int(v.value)
+
     def destroy(self):
         if self.ctx:
             self.lib.splat_ctx_destroy(self.ctx)

@@ -4,6 +4,7 @@ process with SPLAT_LIB_PATH = libsplat_hip_hooks.so — the shipped library neit
 parameters, and the test process itself stays on the shipped library.
 
     python tests/hooks_child.py order_check
+    python tests/hooks_child.py long_class_skip
 """
 import os
 import sys
@@ -65,7 +66,65 @@ def order_check():
     print(f"order_check ok: {len(cases)} cases")
 
 
+def long_class_skip():
+    """A sync-free frame after one that had no tile beyond the per-tile sort's short class launches that class alone
+    (tile_sort_launch: the long class's launch would find nothing to do).  A tile that outgrows the class in such a frame —
+    here a few thousand splats moved onto one spot between two frames — is sorted by the short kernel's global-memory
+    passes and counted, the frame after launches both classes again, and every frame's lists are the oracle's."""
+    n, w, h = 60000, 1920, 1080  # (8160 tiles: beyond a band's single class)
+    dev = sr.Device(0)
+    try:
+        flat, normals, u = make_case(n, w, h, 83, 0.4)
+        ref_f = oracle_pipeline(flat, normals, u, w, h)
+        # the splat in the middle of the fullest tile: 5000 others are moved onto it (a hair apart in depth)
+        ntx = -(-w // 16)
+        full = int(np.argmax(ref_f["counts"]))
+        lst = ref_f["indices"][ref_f["offsets"][full]:ref_f["offsets"][full] + ref_f["counts"][full]]
+        tx, ty = (full % ntx) * 16 + 8, (full // ntx) * 16 + 8
+        c = ref_f["proj"][lst]
+        anchor = int(lst[np.argmin((c[:, 0] - tx) ** 2 + (c[:, 1] - ty) ** 2)])
+        piled = flat.copy()
+        movers = np.setdiff1d(np.arange(n), [anchor])[:5000]
+        rng = np.random.default_rng(5)
+        piled[movers, 0:3] = flat[anchor, 0:3] + rng.uniform(-1e-4, 1e-4, (5000, 3)).astype(np.float32)
+        ref_p = oracle_pipeline(piled, normals, u, w, h)
+        assert ref_f["counts"].max() <= 2048 and ref_p["counts"].max() > 4096, (ref_f["counts"].max(), ref_p["counts"].max())
+        pf, pp = int(ref_f["indices"].shape[0]), int(ref_p["indices"].shape[0])
+        assert pp < pf + pf // 2, (pf, pp)  # (the piled frame stays within the sync-free frames' headroom: no overflow path)
+        fbuf, pbuf, nbuf = dev.createBufferFrom(flat), dev.createBufferFrom(piled), dev.createBufferFrom(normals)
+        r = sr.Renderer(dev, None, "rgba8unorm", n, frameOrder="tileFirst")
+
+        def frame(buf, ref, launches, what):
+            r.render(u, buf, nbuf, None, w, h, wantFloat=True)
+            assert dev.tileSortLaunches() == launches, (what, dev.tileSortLaunches(), launches)
+            img = r.readPixelsFloat().copy()
+            assert not r.previousFrameOverflowed and r.framesMisranked == 0, what
+            total = r.binner.getTotalIndices()
+            assert total == ref["indices"].shape[0], (what, total)
+            assert_same(r.binner.getTileCountsBuffer().read(np.uint32), ref["counts"], ("long class skip", what, "counts"))
+            assert_same(r.binner.getTileIndicesBuffer().read(np.uint32, total), ref["indices"], ("long class skip", what, "lists"),
+                        offsets=ref["offsets"], keys=ref["keys"])
+            return img
+
+        a0 = frame(fbuf, ref_f, 2, "first frame (host-synchronised: nothing known)")
+        a1 = frame(fbuf, ref_f, 1, "second frame")
+        assert_same(a1.view(np.uint32), a0.view(np.uint32), ("long class skip", "image 2"))
+        b0 = frame(pbuf, ref_p, 1, "piled frame, short class alone")
+        b1 = frame(pbuf, ref_p, 2, "piled frame again, both classes")
+        assert_same(b1.view(np.uint32), b0.view(np.uint32), ("long class skip", "piled image"))
+        a2 = frame(fbuf, ref_f, 2, "flat again (the frame before had long tiles)")
+        a3 = frame(fbuf, ref_f, 1, "flat, settled")
+        assert_same(a2.view(np.uint32), a0.view(np.uint32), ("long class skip", "image 5"))
+        assert_same(a3.view(np.uint32), a0.view(np.uint32), ("long class skip", "image 6"))
+        assert dev.rankStatus()["orderFaults"] == 0
+        for o in (r, fbuf, pbuf, nbuf):
+            o.destroy()
+    finally:
+        dev.destroy()
+    print("long_class_skip ok: 6 frames")
+
+
 if __name__ == "__main__":
     from splat_renderer_amd import _lib
     assert _lib.load().has_hooks, f"{_lib.LIB_PATH} is not the test build (make -C splat_renderer_amd/csrc hooks)"
-    {"order_check": order_check}[sys.argv[1]]()
+    {"order_check": order_check, "long_class_skip": long_class_skip}[sys.argv[1]]()

@@ -1044,6 +1044,21 @@ def test_order_check_catches_a_misranked_list_and_the_frame_is_rendered_again():
     assert p.returncode == 0 and "order_check ok: 5 cases" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
+def test_long_class_launch_is_skipped_only_while_no_tile_needs_it():
+    """tile_sort_launch launches the per-tile sort's short class alone in a sync-free frame whose predecessor had no tile
+    beyond it; tests/hooks_child.py counts the launches (a TEST HOOK) through a sequence in which a tile outgrows the class
+    between two frames, and holds every frame's lists against the oracle's."""
+    import subprocess
+    import sys
+    if os.environ.get("SPLAT_BIN_SYNC") == "1":
+        pytest.skip("SPLAT_BIN_SYNC=1: no frame is sync-free")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPLAT_LIB_PATH=_lib.HOOKS_LIB_PATH)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "hooks_child.py"), "long_class_skip"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and "long_class_skip ok: 6 frames" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
 def device_lib_has_hooks():
     return bool(getattr(_lib.load(), "has_hooks", False))
 
