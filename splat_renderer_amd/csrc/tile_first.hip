@@ -55,7 +55,7 @@ constexpr uint32_t TS_THREADS = 256, TS_WAVES = 4;
 //           through global memory
 constexpr uint32_t TS_LONG_ITEMS = 24; // (the short class holds 8, 12 or 16 elements per thread: tile_sort_launch picks per frame)
 constexpr uint32_t TS_LDS_ELEMS = 5888; // 46 KiB + 5 KiB of counters: three workgroups in a CU's 160 KiB
-constexpr uint32_t TS_CHUNK_ITEMS = 16, TS_CHUNK = TS_CHUNK_ITEMS * TS_THREADS;
+constexpr uint32_t TS_CHUNK_ITEMS = 16; // pairs per thread and chunk of the global-memory passes (at most: a class of fewer holds fewer)
 
 struct TileSortShared {
     uint32_t wave_hist[TS_WAVES][256];
