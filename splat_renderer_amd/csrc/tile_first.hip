@@ -817,7 +817,7 @@ __device__ __forceinline__ void tf_offsets_block(uint32_t block, const TfOffsets
 
 // NW waves per workgroup (4: sixteen pairs per thread; 8: eight)
 template <bool RANK_ATOMIC, uint32_t NW>
-__global__ __launch_bounds__(NW * 64, 3) void k_tf_downsweep2(const uint8_t *__restrict__ hi_in, const uint2 *__restrict__ val_in,
+__global__ __launch_bounds__(NW * 64, 4) void k_tf_downsweep2(const uint8_t *__restrict__ hi_in, const uint2 *__restrict__ val_in,
                                                               uint2 *__restrict__ val_out, TfRuns runs, uint32_t hmask,
                                                               uint32_t num_parts, const uint32_t *__restrict__ scanned,
                                                               const uint32_t *__restrict__ totals, TfOffsetsArgs off, uint32_t part_blocks,
@@ -825,7 +825,10 @@ __global__ __launch_bounds__(NW * 64, 3) void k_tf_downsweep2(const uint8_t *__r
     constexpr uint32_t THREADS = NW * 64, ITEMS = TF2_PART / THREADS;
     __shared__ TfDownsweepShared<NW> sh;
     __shared__ uint2 s_val[TF2_PART];
-    __shared__ uint8_t s_dig[TF2_PART];
+    // the reordered pairs' digits live where the waves' counters were (every position is computed before the first digit is
+    // stored): 37.9 instead of 42.3 KB, FOUR workgroups per CU instead of three
+    static_assert(sizeof(sh.wave_hist) >= TF2_PART, "s_dig aliases the wave counters");
+    uint8_t *const s_dig = reinterpret_cast<uint8_t *>(&sh.wave_hist[0][0]);
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (blockIdx.x >= part_blocks) { // (uniform) not a partition: a block of 256 tile offsets
         tf_offsets_block(blockIdx.x - part_blocks, off, runs, num_parts, scanned, totals, sh.global_base, sh.wave_sums);
@@ -911,10 +914,12 @@ __global__ __launch_bounds__(NW * 64, 3) void k_tf_downsweep2(const uint8_t *__r
     __syncthreads();
     // reorder inside the partition: same-digit pairs become contiguous, stable
 #pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) rank[i] += sh.wave_hist[w][dig[i]]; // (now the pair's position in the partition)
+    __syncthreads();
+#pragma unroll
     for (uint32_t i = 0; i < ITEMS; ++i) {
-        const uint32_t pos = sh.wave_hist[w][dig[i]] + rank[i];
-        s_val[pos] = val[i];
-        s_dig[pos] = (uint8_t)dig[i];
+        s_val[rank[i]] = val[i];
+        s_dig[rank[i]] = (uint8_t)dig[i];
     }
     __syncthreads();
     // consecutive lanes write consecutive addresses inside each digit run
@@ -944,11 +949,16 @@ int tf_second_pass_launch(splat_ctx *ctx, const uint8_t *hi, const uint2 *val_in
         const dim3 grid(part_blocks + div_up(tiles + 1, 256)); // the partitions, then the blocks of tile offsets
         const bool ra = rank_atomic_ok(ctx, true); // (checked: k_tile_sort verifies every list this pass contributes to)
         // (512 threads per partition, eight pairs per thread: measured level with this, profiles/r05_b_second_pass_xcd_C3_C2.txt)
+        // Workgroups per CU: four fit (37.9 KB each) and are what a pass of 7-bit digits likes (C1 22.4 -> 21.0 us, C2 level);
+        // with 8-bit digits (screens beyond 2^14 tiles: C3, where a partition leaves 128-byte fragments) a fourth resident
+        // workgroup LOSES — 135 -> 143 us, and two are worse still (154) —, so there 4 KB of dynamic LDS that nobody uses
+        // keep it at three (profiles/r05_x_downsweep2_workgroups_per_cu.txt).
+        const uint32_t pad = hi_bits >= 8u ? 4096u : 0u;
         if (ra)
-            hipLaunchKernelGGL((k_tf_downsweep2<true, 4>), grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
+            hipLaunchKernelGGL((k_tf_downsweep2<true, 4>), grid, dim3(TF_THREADS), pad, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
                                totals, off, part_blocks, xcd_per);
         else
-            hipLaunchKernelGGL((k_tf_downsweep2<false, 4>), grid, dim3(TF_THREADS), 0, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
+            hipLaunchKernelGGL((k_tf_downsweep2<false, 4>), grid, dim3(TF_THREADS), pad, ctx->stream, hi, val_in, val_out, *runs, hmask, num_parts, hist,
                                totals, off, part_blocks, xcd_per);
         LAUNCH_CHECK(ctx, "k_tf_downsweep2");
     }
